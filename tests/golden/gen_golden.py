@@ -1,0 +1,353 @@
+#!/usr/bin/env python
+"""Generate the committed golden fixtures by IMPORTING the reference (build container only).
+
+Run from the repo root:   python tests/golden/gen_golden.py
+Needs /root/reference (read-only) + transformers 5.15.0 on CPU.  Nothing from the reference is
+copied: fixtures hold only (config, seed, state-dict key->shape table, inputs, reference outputs).
+Weights are regenerated on any machine from the seed by `u-llava_amd/weights.py`.
+
+While generating, every fixture is also run through `oracle/ullava_oracle.py` and must be
+BIT-EXACT (torch.equal) with the reference output -- this is what pins the oracle.
+"""
+import importlib
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+import transformers  # noqa: E402
+from transformers import CLIPVisionModel, LlamaForCausalLM  # noqa: E402,F401  (touch before stubbing torchvision)
+
+# in-memory torchvision stub: the reference imports these names at module import time only
+_tv = types.ModuleType("torchvision")
+_ops = types.ModuleType("torchvision.ops")
+_boxes = types.ModuleType("torchvision.ops.boxes")
+_tr = types.ModuleType("torchvision.transforms")
+_trf = types.ModuleType("torchvision.transforms.functional")
+
+
+def _na(*a, **k):
+    raise NotImplementedError
+
+
+_boxes.box_area = _na
+_boxes.batched_nms = _na
+_ops.box_iou = _na
+_ops.boxes = _boxes
+_trf.resize = _na
+_trf.to_pil_image = _na
+_tr.functional = _trf
+_tv.ops = _ops
+_tv.transforms = _tr
+for _n, _m in [("torchvision", _tv), ("torchvision.ops", _ops), ("torchvision.ops.boxes", _boxes),
+               ("torchvision.transforms", _tr), ("torchvision.transforms.functional", _trf)]:
+    sys.modules[_n] = _m
+torch.Tensor.cuda = lambda self, *a, **k: self  # reference hard-codes .cuda() (models/ullava.py:173,...)
+
+import models.ullava as ref_ullava  # noqa: E402
+from models.segment_anything import build_sam as ref_build_sam  # noqa: E402
+from models.ullava import UllavaConfig, UllavaForCausalLM  # noqa: E402
+from models.ullava_core import UllavaCoreConfig, UllavaCoreForCausalLM  # noqa: E402
+
+W = importlib.import_module("u-llava_amd.weights")
+from oracle import ullava_oracle as O  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+MM = dict(IMG_START=90, IMG_END=91, IMG_PATCH=92, VID_START=93, VID_END=94, VID_PATCH=95)
+META = dict(torch=str(torch.__version__), transformers=str(transformers.__version__), attn="eager",
+            reference="OPPOMKLab/u-LLaVA @ /root/reference")
+
+
+def core_cfg_dict(d=64, layers=2, heads=4, inter=128, vocab=100, v_hidden=32, v_layers=3, v_heads=2, v_inter=64,
+                  image=28, patch=14, projector="mlp", hidden_layer=-2):
+    return dict(hidden_size=d, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter,
+                vocab_size=vocab, rms_norm_eps=1e-6, rope_theta=10000.0, vision_hidden_layer=hidden_layer,
+                projector_type=projector, mm_token_ids=dict(MM),
+                vision_config=dict(hidden_size=v_hidden, num_hidden_layers=v_layers, num_attention_heads=v_heads,
+                                   intermediate_size=v_inter, image_size=image, patch_size=patch, num_channels=3,
+                                   layer_norm_eps=1e-5))
+
+
+def build_ref_core(cd):
+    vc = dict(cd["vision_config"])
+    cfg = UllavaCoreConfig(vision_config=vc, vision_hidden_layer=cd["vision_hidden_layer"],
+                           projector_type=cd["projector_type"], projector_from_scratch=False,
+                           mm_token_ids=cd["mm_token_ids"], hidden_size=cd["hidden_size"],
+                           intermediate_size=cd["intermediate_size"], num_hidden_layers=cd["num_hidden_layers"],
+                           num_attention_heads=cd["num_attention_heads"], num_key_value_heads=cd["num_attention_heads"],
+                           vocab_size=cd["vocab_size"], rms_norm_eps=cd["rms_norm_eps"], attn_implementation="eager")
+    cfg.vision_config._attn_implementation = "eager"
+    m = UllavaCoreForCausalLM(cfg).eval()
+    assert m.config._attn_implementation == "eager" and m.vision_encoder.config._attn_implementation == "eager"
+    return m
+
+
+def load_seeded(model, seed, dtype):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = W.seeded_state_dict(shapes, seed, torch.float32)
+    model.load_state_dict(sd, strict=True)
+    model.to(dtype)
+    # model.to(bf16) also rounds the NON-persistent fp32 RoPE inv_freq buffer, which a real
+    # from_pretrained(torch_dtype=bf16) load never does (buffers are built in fp32 at init and
+    # only parameters are cast).  Restore the fp32 buffer so the fixture reflects deployed behaviour.
+    for mod in model.modules():
+        if hasattr(mod, "inv_freq") and hasattr(mod, "compute_default_rope_parameters"):
+            inv, _ = mod.compute_default_rope_parameters(mod.config)
+            mod.inv_freq = inv.float()
+            mod.original_inv_freq = inv.float().clone()
+    return shapes, {k: v.to(dtype) for k, v in sd.items()}
+
+
+def eq(a, b, what):
+    assert a.dtype == b.dtype and a.shape == b.shape, (what, a.dtype, b.dtype, a.shape, b.shape)
+    assert torch.equal(a, b), f"oracle != reference for {what}: max|d|={(a.float() - b.float()).abs().max().item()}"
+
+
+def _compact(o):
+    """torch.save keeps a view's WHOLE storage: clone every tensor to its own compact storage."""
+    if isinstance(o, torch.Tensor):
+        return o.detach().contiguous().clone()
+    if isinstance(o, dict):
+        return {k: _compact(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_compact(v) for v in o)
+    return o
+
+
+def save(name, obj):
+    obj = _compact(obj)
+    obj["meta"] = dict(META)
+    path = os.path.join(OUT, name)
+    torch.save(obj, path)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def img_ids(n_patch, n_text, start=MM["IMG_START"], patch=MM["IMG_PATCH"], end=MM["IMG_END"], seed=0):
+    g = torch.Generator().manual_seed(seed)
+    txt = torch.randint(5, 90, (n_text,), generator=g).tolist()
+    return [1, start] + [patch] * n_patch + [end] + txt
+
+
+# --------------------------------------------------------------------------- G1 / G2 / G5
+def gen_core(name, cd, dtype, seed, with_greedy):
+    print(f"[{name}]")
+    m = build_ref_core(cd)
+    shapes, sd = load_seeded(m, seed, dtype)
+    n_patch = (cd["vision_config"]["image_size"] // cd["vision_config"]["patch_size"]) ** 2
+    a = img_ids(n_patch, 6, seed=1)
+    b = img_ids(n_patch, 3, seed=2)
+    S = len(a)
+    ids = torch.tensor([a, b + [0] * (S - len(b))])
+    mask = torch.tensor([[1] * S, [1] * len(b) + [0] * (S - len(b))])
+    g = torch.Generator().manual_seed(seed + 7)
+    images = torch.randn(2, 3, cd["vision_config"]["image_size"], cd["vision_config"]["image_size"], generator=g).to(dtype)
+    with torch.no_grad():
+        r = m(input_ids=ids, attention_mask=mask, images=images, output_hidden_states=True)
+        r_feat = m.encode_image(images)
+    o = O.core_forward(sd, cd, ids, mask, images)
+    eq(o["logits"], r.logits, "logits")
+    assert len(o["hidden_states"]) == len(r.hidden_states)
+    for i, (x, y) in enumerate(zip(o["hidden_states"], r.hidden_states)):
+        eq(x, y, f"hidden_states[{i}]")
+    eq(O.encode_image(sd, cd, images), r_feat, "encode_image")
+    fx = dict(cfg=cd, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=ids, attention_mask=mask, images=images,
+              logits=r.logits, hidden_states=list(r.hidden_states), image_features=r_feat, inputs_embeds=o["inputs_embeds"])
+    if with_greedy:
+        # G2: greedy ids, HF generate(use_cache=False) vs manual loop vs oracle
+        one = ids[:1]
+        with torch.no_grad():
+            gen = m.generate(input_ids=one, images=images[:1], do_sample=False, use_cache=False, max_new_tokens=8,
+                             pad_token_id=0, eos_token_id=None)
+        seq, last_h = O.greedy_generate(sd, cd, one, images[:1], None, 8)
+        assert torch.equal(gen, seq), (gen, seq)
+        with torch.no_grad():
+            rh = m(input_ids=seq[:, :-1], images=images[:1], output_hidden_states=True).hidden_states[-1]
+        eq(last_h, rh, "greedy last hidden")
+        # KV-cache path of the reference forward (manual loop)
+        with torch.no_grad():
+            cur = one
+            out = m(input_ids=cur, images=images[:1], use_cache=True)
+            pkv = out.past_key_values
+            toks = [out.logits[:, -1].float().argmax(-1, keepdim=True)]
+            for t in range(7):
+                pos = torch.tensor([[one.shape[1] + t]])
+                out = m(input_ids=toks[-1], images=images[:1], use_cache=True, past_key_values=pkv, position_ids=pos)
+                pkv = out.past_key_values
+                toks.append(out.logits[:, -1].float().argmax(-1, keepdim=True))
+        seq_kv = torch.cat([one] + toks, dim=1)
+        fx.update(greedy_prompt=one, greedy_sequences=gen, greedy_last_hidden=rh, greedy_sequences_kvcache=seq_kv,
+                  greedy_kv_equal=bool(torch.equal(seq_kv, gen)))
+        print("   greedy:", gen[0, one.shape[1]:].tolist(), "kv-cache equal:", fx["greedy_kv_equal"])
+    save(name, fx)
+
+
+# --------------------------------------------------------------------------- G3 video
+def gen_video(name, dtype, seed):
+    print(f"[{name}]")
+    cd = core_cfg_dict()
+    m = build_ref_core(cd)
+    shapes, sd = load_seeded(m, seed, dtype)
+    T, n_patch = 8, 4
+    a = [1, MM["VID_START"]] + [MM["VID_PATCH"]] * (T + n_patch) + [MM["VID_END"]] + [7, 8, 9, 10, 11]
+    ids = torch.tensor([a])
+    g = torch.Generator().manual_seed(seed + 11)
+    videos = torch.randn(1, 3, T, 28, 28, generator=g).to(dtype)
+    with torch.no_grad():
+        r = m(input_ids=ids, attention_mask=torch.ones_like(ids), videos=videos, output_hidden_states=True)
+        rf = m.encode_video(videos)
+    o = O.core_forward(sd, cd, ids, torch.ones_like(ids), None, videos)
+    eq(o["logits"], r.logits, "video logits")
+    eq(O.encode_video(sd, cd, videos), rf, "encode_video")
+    save(name, dict(cfg=cd, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=ids, videos=videos, logits=r.logits,
+                    video_features=rf, last_hidden=r.hidden_states[-1]))
+
+
+# --------------------------------------------------------------------------- G4 text-only + mixed
+def gen_mixed(name, dtype, seed):
+    print(f"[{name}]")
+    # reference hard-codes zeros(256, 1024) for text-only samples -> CLIP width must be 1024
+    cd = core_cfg_dict(v_hidden=1024, v_layers=2, v_heads=16, v_inter=64)
+    m = build_ref_core(cd)
+    shapes, sd = load_seeded(m, seed, dtype)
+    a = img_ids(4, 5, seed=3)                  # image sample
+    S = len(a)
+    b = [1] + [6, 7, 8, 9, 10, 11, 12] + [0] * (S - 8)   # text-only sample, right padded
+    c = img_ids(4, 2, seed=4)
+    c = c + [0] * (S - len(c))
+    ids = torch.tensor([b, a, c])
+    mask = (ids != 0).long()
+    mask[0, :8] = 1
+    g = torch.Generator().manual_seed(seed + 13)
+    images = torch.randn(2, 3, 28, 28, generator=g).to(dtype)   # only rows for samples that have an image
+    with torch.no_grad():
+        r = m(input_ids=ids, attention_mask=mask, images=images, output_hidden_states=True)
+    o = O.core_forward(sd, cd, ids, mask, images)
+    eq(o["logits"], r.logits, "mixed logits")
+    save(name, dict(cfg=cd, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=ids, attention_mask=mask, images=images,
+                    logits=r.logits, last_hidden=r.hidden_states[-1]))
+
+
+# --------------------------------------------------------------------------- G7 SAM prompt-enc + mask decoder (full dims)
+def gen_sam_decoder(name, dtype, seed, n_list=(1, 3)):
+    print(f"[{name}]")
+    sam = ref_build_sam(checkpoint=None)
+    dec_sd_ref = {"visual_model." + k: v for k, v in sam.state_dict().items() if not k.startswith("image_encoder.")}
+    shapes = {k: tuple(v.shape) for k, v in dec_sd_ref.items()}
+    sd32 = W.seeded_state_dict(shapes, seed, torch.float32)
+    sam.load_state_dict({k[len("visual_model."):]: v for k, v in sd32.items()}, strict=False)
+    sam.prompt_encoder.to(dtype)
+    sam.mask_decoder.to(dtype)
+    sd = {k: v.to(dtype) for k, v in sd32.items()}
+    g = torch.Generator().manual_seed(seed + 17)
+    emb = torch.randn(1, 256, 64, 64, generator=g).to(dtype)
+    # the [1,256,64,64] embedding is the FIRST draw of Generator(seed+17): regenerated by the tests, not stored
+    fx = dict(seed=seed, dtype=str(dtype), shapes=shapes, image_embedding_seed=seed + 17, cases=[])
+    with torch.no_grad():
+        pe_ref = sam.prompt_encoder.get_dense_pe()
+    eq(O.dense_pe(sd, (64, 64)), pe_ref, "dense_pe")
+    fx["dense_pe_sample"] = pe_ref[:, ::8, ::4, ::4].contiguous()
+    fx["dense_pe_sum"] = pe_ref.double().sum().item()
+    fx["dense_pe_abs_sum"] = pe_ref.double().abs().sum().item()
+    for n in n_list:
+        text = torch.randn(n, 1, 256, generator=g).to(dtype)
+        with torch.no_grad():
+            sp, de = sam.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text)
+            sp = sp.to(dtype)
+            lr, iou = sam.mask_decoder(image_embeddings=emb, image_pe=pe_ref, sparse_prompt_embeddings=sp,
+                                       dense_prompt_embeddings=de, multimask_output=False)
+            pm = sam.postprocess_masks(lr, input_size=(768, 1024), original_size=(480, 640))
+        osp, ode = O.prompt_encoder_text(sd, text, (64, 64))
+        olr, oiou = O.mask_decoder(sd, emb, O.dense_pe(sd, (64, 64)), osp.to(dtype), ode, False)
+        eq(olr, lr, f"low_res_masks n={n}")
+        eq(oiou, iou, f"iou n={n}")
+        eq(O.postprocess_masks(olr, (768, 1024), (480, 640)), pm, f"postprocess n={n}")
+        # full-res masks are big: keep the low-res logits + a strided sample of the final masks
+        fx["cases"].append(dict(n=n, text_embeds=text, low_res_masks=lr, iou=iou, post_sample=pm[:, :, ::8, ::8].contiguous(),
+                                post_sum=pm.double().sum().item(), post_abs_sum=pm.double().abs().sum().item()))
+    save(name, fx)
+
+
+# --------------------------------------------------------------------------- G8 full forward with shrunk SAM
+SAM_TINY = dict(embed_dim=64, depth=2, num_heads=2, global_attn_indexes=[1], window_size=14, patch_size=16, img_size=1024,
+                out_chans=256)
+
+
+def gen_full(name, dtype, seed):
+    print(f"[{name}]")
+    from models.segment_anything.build_sam import _build_sam
+    ref_ullava.build_sam_vit_h = lambda checkpoint=None: _build_sam(
+        encoder_embed_dim=SAM_TINY["embed_dim"], encoder_depth=SAM_TINY["depth"], encoder_num_heads=SAM_TINY["num_heads"],
+        encoder_global_attn_indexes=SAM_TINY["global_attn_indexes"], checkpoint=None)
+    cd = core_cfg_dict(vocab=120)
+    SEG, LOC = 101, 102
+    llm_cfg = dict(vision_config=dict(cd["vision_config"]), vision_hidden_layer=cd["vision_hidden_layer"],
+                   projector_type="mlp", projector_from_scratch=False, mm_token_ids=cd["mm_token_ids"],
+                   hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
+                   num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"],
+                   num_key_value_heads=cd["num_attention_heads"], vocab_size=cd["vocab_size"], rms_norm_eps=1e-6,
+                   attn_implementation="eager")
+    cfg = UllavaConfig(llm_config=llm_cfg, seg_token_idx=SEG, loc_token_idx=LOC, out_dim=256)
+    cfg.llm_config.vision_config._attn_implementation = "eager"
+    m = UllavaForCausalLM(cfg).eval()
+    assert m.llm.config._attn_implementation == "eager" and m.llm.vision_encoder.config._attn_implementation == "eager"
+    shapes, sd = load_seeded(m, seed, dtype)
+    # sample 0: two [SEG] + one [LOC]; sample 1: one [SEG], two [LOC], right padded
+    a = [1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * 4 + [MM["IMG_END"], 11, 12, SEG, 13, LOC, 14, 15, SEG, 16]
+    b = [1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * 4 + [MM["IMG_END"], 21, LOC, SEG, 22, LOC]
+    S = len(a)
+    ids = torch.tensor([a, b + [0] * (S - len(b))])
+    mask = torch.tensor([[1] * S, [1] * len(b) + [0] * (S - len(b))])
+    g = torch.Generator().manual_seed(seed + 19)
+    images = torch.randn(2, 3, 28, 28, generator=g).to(dtype)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(dtype)
+    size_list = [(480, 640), (333, 500)]
+    resize_list = [(768, 1024), (682, 1024)]
+    with torch.no_grad():
+        r = m(images_sam=images_sam, images=images, input_ids=ids, labels=None, attention_mask=mask,
+              mask_list=[None, None], size_list=size_list, resize_list=resize_list, bbox_list=[None, None], inference=True)
+    ocfg = dict(llm=cd, sam=SAM_TINY, seg_token_idx=SEG, loc_token_idx=LOC)
+    o = O.ullava_forward(sd, ocfg, images_sam, images, ids, mask, size_list, resize_list)
+    eq(o["logits"], r["logits"], "full logits")
+    for i in range(2):
+        eq(o["pred_masks"][i], r["pred_masks"][i], f"pred_masks[{i}]")
+        eq(o["pred_boxes"][i], r["pred_boxes"][i], f"pred_boxes[{i}]")
+    assert sorted(r.keys()) == ["gt_boxes", "gt_masks", "logits", "pred_boxes", "pred_masks"]
+    # images_sam is 2x3x1024x1024: regenerate from the seed instead of storing it
+    save(name, dict(cfg=ocfg, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=ids, attention_mask=mask, images=images,
+                    images_sam_seed=seed + 19, size_list=size_list, resize_list=resize_list, logits=r["logits"],
+                    pred_boxes=[t for t in r["pred_boxes"]], low_res_masks=o["low_res_masks"],
+                    pred_mask_samples=[t[:, ::8, ::8].contiguous() for t in r["pred_masks"]],
+                    pred_mask_sums=[t.double().sum().item() for t in r["pred_masks"]],
+                    pred_mask_shapes=[tuple(t.shape) for t in r["pred_masks"]],
+                    image_embeddings_sample=o["image_embeddings"][:, ::16, ::4, ::4].contiguous(),
+                    dict_keys=sorted(r.keys())))
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:])
+
+    def want(n):
+        return not which or n in which
+    if want("core"):
+        gen_core("g1_core_tiny_fp32.pt", core_cfg_dict(), torch.float32, 1, True)
+        gen_core("g1_core_tiny_bf16.pt", core_cfg_dict(), torch.bfloat16, 1, True)
+        gen_core("g5_core_mlp2x_bf16.pt", core_cfg_dict(projector="mlp2x"), torch.bfloat16, 5, False)
+    if want("video"):
+        gen_video("g3_video_bf16.pt", torch.bfloat16, 3)
+    if want("mixed"):
+        gen_mixed("g4_mixed_bf16.pt", torch.bfloat16, 4)
+    if want("samdec"):
+        gen_sam_decoder("g7_sam_decoder_fp32.pt", torch.float32, 7)
+        gen_sam_decoder("g7_sam_decoder_bf16.pt", torch.bfloat16, 7)
+    if want("full"):
+        gen_full("g8_full_tiny_fp32.pt", torch.float32, 8)
+        gen_full("g8_full_tiny_bf16.pt", torch.bfloat16, 8)
+    print("all fixtures bit-exact between reference and oracle")

@@ -1,0 +1,97 @@
+"""CPU: the oracle replays every committed golden fixture BIT-EXACTLY.
+
+The fixtures were produced by importing the reference itself (tests/golden/gen_golden.py, build
+container only); here neither /root/reference nor transformers is needed.
+"""
+import torch
+import pytest
+
+from conftest import load_fixture, fixture_state_dict
+from oracle import ullava_oracle as O
+
+
+def _eq(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape
+    assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
+@pytest.mark.parametrize("name", ["g1_core_tiny_fp32.pt", "g1_core_tiny_bf16.pt", "g5_core_mlp2x_bf16.pt"])
+def test_core_forward(name):
+    fx = load_fixture(name)
+    sd = fixture_state_dict(fx)
+    o = O.core_forward(sd, fx["cfg"], fx["input_ids"], fx["attention_mask"], fx["images"])
+    _eq(o["logits"], fx["logits"])
+    for x, y in zip(o["hidden_states"], fx["hidden_states"]):
+        _eq(x, y)
+    _eq(o["inputs_embeds"], fx["inputs_embeds"])
+    _eq(O.encode_image(sd, fx["cfg"], fx["images"]), fx["image_features"])
+
+
+@pytest.mark.parametrize("name", ["g1_core_tiny_fp32.pt", "g1_core_tiny_bf16.pt"])
+def test_greedy_ids(name):
+    fx = load_fixture(name)
+    sd = fixture_state_dict(fx)
+    seq, last_h = O.greedy_generate(sd, fx["cfg"], fx["greedy_prompt"], fx["images"][:1], None, 8)
+    assert torch.equal(seq, fx["greedy_sequences"])
+    assert torch.equal(seq, fx["greedy_sequences_kvcache"]) == fx["greedy_kv_equal"]
+    _eq(last_h, fx["greedy_last_hidden"])
+
+
+def test_video_branch():
+    fx = load_fixture("g3_video_bf16.pt")
+    sd = fixture_state_dict(fx)
+    o = O.core_forward(sd, fx["cfg"], fx["input_ids"], torch.ones_like(fx["input_ids"]), None, fx["videos"])
+    _eq(o["logits"], fx["logits"])
+    _eq(O.encode_video(sd, fx["cfg"], fx["videos"]), fx["video_features"])
+
+
+def test_text_only_and_mixed_batch():
+    fx = load_fixture("g4_mixed_bf16.pt")
+    sd = fixture_state_dict(fx)
+    o = O.core_forward(sd, fx["cfg"], fx["input_ids"], fx["attention_mask"], fx["images"])
+    _eq(o["logits"], fx["logits"])
+    _eq(o["hidden_states"][-1], fx["last_hidden"])
+
+
+@pytest.mark.parametrize("name", ["g7_sam_decoder_fp32.pt", "g7_sam_decoder_bf16.pt"])
+def test_sam_prompt_encoder_mask_decoder(name):
+    fx = load_fixture(name)
+    sd = fixture_state_dict(fx)
+    dt = next(iter(sd.values())).dtype
+    g = torch.Generator().manual_seed(fx["image_embedding_seed"])
+    emb = torch.randn(1, 256, 64, 64, generator=g).to(dt)
+    pe = O.dense_pe(sd, (64, 64))
+    _eq(pe[:, ::8, ::4, ::4].contiguous(), fx["dense_pe_sample"])
+    assert pe.double().sum().item() == fx["dense_pe_sum"]
+    for case in fx["cases"]:
+        sp, de = O.prompt_encoder_text(sd, case["text_embeds"], (64, 64))
+        assert sp.dtype == torch.float32          # the fp32 detour (prompt_encoder.py:165-177)
+        lr, iou = O.mask_decoder(sd, emb, pe, sp.to(dt), de, False)
+        _eq(lr, case["low_res_masks"])
+        _eq(iou, case["iou"])
+        pm = O.postprocess_masks(lr, (768, 1024), (480, 640))
+        assert pm.dtype == torch.float32 and tuple(pm.shape) == (case["n"], 1, 480, 640)
+        _eq(pm[:, :, ::8, ::8].contiguous(), case["post_sample"])
+        assert pm.double().sum().item() == case["post_sum"]
+
+
+@pytest.mark.parametrize("name", ["g8_full_tiny_fp32.pt", "g8_full_tiny_bf16.pt"])
+def test_full_forward_tiny_sam(name):
+    fx = load_fixture(name)
+    sd = fixture_state_dict(fx)
+    dt = next(iter(sd.values())).dtype
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)           # `images` was the first draw
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(dt)
+    o = O.ullava_forward(sd, fx["cfg"], images_sam, fx["images"], fx["input_ids"], fx["attention_mask"],
+                         fx["size_list"], fx["resize_list"])
+    _eq(o["logits"], fx["logits"])
+    for i in range(2):
+        _eq(o["pred_boxes"][i], fx["pred_boxes"][i])
+        _eq(o["low_res_masks"][i], fx["low_res_masks"][i])
+        assert tuple(o["pred_masks"][i].shape) == tuple(fx["pred_mask_shapes"][i])
+        _eq(o["pred_masks"][i][:, ::8, ::8].contiguous(), fx["pred_mask_samples"][i])
+        assert o["pred_masks"][i].double().sum().item() == fx["pred_mask_sums"][i]
+    # [SEG]/[LOC] shift: sample 0 has 2 [SEG] + 1 [LOC]; sample 1 has 1 [SEG] + 2 [LOC]
+    assert [m.shape[0] for m in o["pred_masks"]] == [2, 1]
+    assert [b.shape[0] for b in o["pred_boxes"]] == [1, 2]
