@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the u-LLaVA multimodal forward (CLIP ViT-L/14-336 -> projector -> LLaMA-7B -> lm_head)
+on MI355X through the HIP path, with the roofline of the dominant kernel and a CPU-oracle baseline.
+
+  python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one forward of the per-GPU batch (BASELINE.json config C4: 336x336 synthetic images, 64-token prompts,
+S = 643, per-GPU batch 32, weak scaling).  Inputs and random-init weights are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MM = dict(IMG_START=32001, IMG_END=32002, IMG_PATCH=32003, VID_START=32004, VID_END=32005, VID_PATCH=32006)
+WORKLOADS = {
+    # name: (image_size, prompt_tokens, per_gpu_batch, description)
+    "c4": (336, 64, 32, "C4: ViT-L/14-336 + LLaMA-7B instruct forward, 336x336 image + 64-token prompt (S=643), batch 32/GPU"),
+    "c2": (224, 64, 16, "C2: ViT-L/14-224 + LLaMA-7B VQA forward, 224x224 image + 64-token prompt (S=323), batch 16"),
+}
+PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def llama_flops(S, V, D=4096, I=11008, L=32):
+    """32*[2S(4D^2 + 3DI) + 4S^2 D] + 2SDV per sample (2*MAC, undiscounted attention)."""
+    return L * (2 * S * (4 * D * D + 3 * D * I) + 4 * S * S * D) + 2 * S * D * V
+
+
+def clip_flops(P, D=1024, I=4096, L=23, K=588):
+    T = P + 1
+    return L * (2 * T * (4 * D * D + 2 * D * I) + 4 * T * T * D) + 2 * P * K * D
+
+
+def init_random_(model, seed):
+    """HF-style random init directly on the GPU (N(0, 0.02) matrices, ones for norm weights, zero biases)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for name, p in model.named_parameters():
+        if p.dim() == 1 and ("norm" in name or "layrnorm" in name) and name.endswith("weight"):
+            p.data.fill_(1.0)
+        elif p.dim() == 1 and name.endswith("bias"):
+            p.data.zero_()
+        else:
+            p.data.normal_(0.0, 0.02, generator=g)
+
+
+def build_model(image_size, device, seed=0):
+    C = importlib.import_module("u-llava_amd.configuration")
+    M = importlib.import_module("u-llava_amd.modeling_core")
+    cfg = C.UllavaCoreConfig(vision_config=dict(image_size=image_size, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
+                             mm_token_ids=dict(MM), vocab_size=32011)
+    model = M.UllavaCoreForCausalLM(cfg, device=device)
+    init_random_(model, seed)
+    model.strict_checks = False        # no host sync inside the timed region (the check itself is covered by tests)
+    model.pack_weights()
+    return model, cfg
+
+
+def make_inputs(cfg, batch, prompt_tokens, device, seed):
+    g = torch.Generator(device="cuda").manual_seed(1000 + seed)
+    P = (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2
+    images = torch.randn(batch, 3, cfg.vision_config.image_size, cfg.vision_config.image_size, device=device, generator=g).to(torch.bfloat16)
+    txt = torch.randint(5, 32000, (batch, prompt_tokens), device=device, generator=g)
+    head = torch.tensor([1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * P + [MM["IMG_END"]], device=device).expand(batch, -1)
+    ids = torch.cat([head, txt], dim=1).contiguous()
+    return images, ids, torch.ones_like(ids)
+
+
+def gemm_roofline(cfg, tokens, device, iters=5):
+    """Time the four GEMM launches of one LLaMA layer at the benchmark's token count with HIP events on the launch stream."""
+    ops = importlib.import_module("u-llava_amd.ops")
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    shapes = [("qkv", 3 * D, D, False), ("o_proj", D, D, False), ("gate_up+swiglu", 2 * I, D, True), ("down", D, I, False)]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    per = []
+    tot_t = tot_f = 0.0
+    for name, N, K, sw in shapes:
+        x = (torch.randn(tokens, K, device=device, generator=g)).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=device, generator=g) * 0.02).to(torch.bfloat16)
+        out = torch.empty(tokens, N // 2 if sw else N, device=device, dtype=torch.bfloat16)
+        for _ in range(2):
+            ops.linear(x, w, swiglu=sw, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.linear(x, w, swiglu=sw, out=out)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        fl = 2.0 * tokens * N * K
+        per.append(dict(gemm=name, M=tokens, N=N, K=K, ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
+        tot_t += ms
+        tot_f += fl
+    achieved = tot_f / tot_t / 1e9
+    return dict(bound="mfma", kernel="gemm_bf16_nt_kernel (LLaMA-7B layer: qkv, o, gate/up+SwiGLU, down)", achieved=round(achieved, 1),
+                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, per_launch=per)
+
+
+def cpu_baseline(image_size, prompt_tokens):
+    """Oracle (CPU restatement of the reference path, torch bf16) on a bounded sample: ONE image at the benchmark shape
+    through 2 of 23 CLIP layers and 2 of 32 LLaMA layers + lm_head, extrapolated linearly in layer count."""
+    from oracle import ullava_oracle as O
+    W = importlib.import_module("u-llava_amd.weights")
+    torch.set_num_threads(os.cpu_count())
+    P = (image_size // 14) ** 2
+    S = 2 + P + 1 + prompt_tokens
+    D, I, V, Dv, Iv = 4096, 11008, 32011, 1024, 4096
+    nl, nv = 2, 2
+    shapes = {"model.embed_tokens.weight": (V, D), "model.norm.weight": (D,), "lm_head.weight": (V, D),
+              "vision_projector.weight": (D, Dv), "vision_projector.bias": (D,)}
+    for l in range(nl):
+        p = f"model.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            shapes[p + f"self_attn.{n}.weight"] = (D, D)
+        shapes[p + "mlp.gate_proj.weight"] = (I, D)
+        shapes[p + "mlp.up_proj.weight"] = (I, D)
+        shapes[p + "mlp.down_proj.weight"] = (D, I)
+        shapes[p + "input_layernorm.weight"] = (D,)
+        shapes[p + "post_attention_layernorm.weight"] = (D,)
+    ve = "vision_encoder."
+    shapes.update({ve + "embeddings.class_embedding": (Dv,), ve + "embeddings.patch_embedding.weight": (Dv, 3, 14, 14),
+                   ve + "embeddings.position_embedding.weight": (P + 1, Dv), ve + "pre_layrnorm.weight": (Dv,), ve + "pre_layrnorm.bias": (Dv,)})
+    for l in range(nv):
+        p = f"{ve}encoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            shapes[p + f"self_attn.{n}.weight"] = (Dv, Dv)
+            shapes[p + f"self_attn.{n}.bias"] = (Dv,)
+        shapes.update({p + "layer_norm1.weight": (Dv,), p + "layer_norm1.bias": (Dv,), p + "layer_norm2.weight": (Dv,), p + "layer_norm2.bias": (Dv,),
+                       p + "mlp.fc1.weight": (Iv, Dv), p + "mlp.fc1.bias": (Iv,), p + "mlp.fc2.weight": (Dv, Iv), p + "mlp.fc2.bias": (Dv,)})
+    sd = W.seeded_state_dict(shapes, 0, torch.bfloat16, hf_init=True)
+    vcfg = dict(hidden_size=Dv, num_attention_heads=16, num_hidden_layers=nv, patch_size=14, layer_norm_eps=1e-5)
+    lcfg = dict(hidden_size=D, num_attention_heads=32, num_hidden_layers=nl, rms_norm_eps=1e-6)
+    img = torch.randn(1, 3, image_size, image_size).to(torch.bfloat16)
+    emb = torch.randn(1, S, D).to(torch.bfloat16)
+
+    def t(fn, n=2):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return (time.perf_counter() - t0) / n
+    with torch.no_grad():
+        t_clip = t(lambda: O.clip_vision_hidden_states(sd, vcfg, img, n_layers_to_run=nv))
+        t_clip0 = t(lambda: O.clip_vision_hidden_states(sd, vcfg, img, n_layers_to_run=0))
+        t_llm = t(lambda: O.llama_model(sd, lcfg, emb))
+        lcfg0 = dict(lcfg, num_hidden_layers=0)
+        t_llm0 = t(lambda: O.llama_model(sd, lcfg0, emb))
+        hs = O.llama_model(sd, lcfg0, emb)[0][-1]
+        t_head = t(lambda: torch.nn.functional.linear(hs, sd["lm_head.weight"]))
+    per_img = t_clip0 + (t_clip - t_clip0) / nv * 23 + t_llm0 + (t_llm - t_llm0) / nl * 32 + t_head
+    return dict(value=round(1.0 / per_img, 4), unit="images/sec", cores=os.cpu_count(), kind="port",
+                sample=f"oracle (torch-CPU bf16 restatement of the reference path), 1 image {image_size}x{image_size} S={S}: "
+                       f"{nv}/23 CLIP layers + {nl}/32 LLaMA-7B layers + lm_head timed, extrapolated linearly in layer count "
+                       f"({per_img:.2f} s/image)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        dist = dist_
+    image_size, prompt, batch, desc = WORKLOADS[a.workload]
+    batch = a.batch or batch
+
+    model, cfg = build_model(image_size, dev, seed=rank)
+    images, ids, mask = make_inputs(cfg, batch, prompt, dev, rank)
+    S = ids.shape[1]
+
+    def step():
+        return model.forward(input_ids=ids, attention_mask=mask, images=images)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # the path's only collective: a scalar over xGMI
+    elapsed = float(t.item())
+    total_images = batch * world * a.steps
+    value = total_images / elapsed
+
+    if rank == 0:
+        P = (image_size // 14) ** 2
+        flops_img = llama_flops(S, cfg.vocab_size) + clip_flops(P) + 2 * (P + 1) * 1024 * 4096
+        line = {"metric": "images/sec (ViT-L/14 + projector + LLaMA-7B multimodal forward)", "value": round(value, 3), "unit": "images/sec",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": desc, "per_gpu_batch": batch, "global_batch": batch * world, "seq_len": S, "image": image_size,
+                           "parallelism": f"dp{world}", "weights": "random-init N(0,0.02), ViT-L/14 + LLaMA-7B (V=32011) shapes"},
+                "images_per_sec_per_gpu": round(value / world, 3),
+                "model_tflops_per_image": round(flops_img / 1e12, 3),
+                "model_tflops_per_sec_per_gpu": round(flops_img * value / world / 1e12, 1),
+                "frac_of_bf16_peak_end_to_end": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        if not a.no_roofline:
+            with torch.no_grad():
+                line["roofline"] = gemm_roofline(cfg, batch * S, dev)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(image_size, prompt)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

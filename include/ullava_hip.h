@@ -1,0 +1,100 @@
+/* ullava_hip.h -- C ABI of libullava_hip.so, the MI355X (gfx950) kernels of the u-LLaVA forward path.
+ *
+ * The reference (OPPOMKLab/u-LLaVA) has no FFI: its hot path is PyTorch nn.Modules calling ATen.  Each entry
+ * point below replaces the ATen calls of the reference lines it cites (paths relative to the reference repo;
+ * "hf:" = transformers, the reference's pinned third-party dependency, cited from v5.15.0).
+ *
+ * Conventions: borrowed device pointers (no ownership transfer), caller-provided outputs and
+ * workspace, all tensors bf16 (raw uint16 bits) unless noted, element strides, `stream` = hipStream_t (NULL =
+ * default stream), no hidden synchronisation, no internal threads, re-entrant per stream.
+ * Return 0 on success, negative ULL_ERR_* otherwise (the Python host raises RuntimeError).
+ */
+#ifndef ULLAVA_HIP_H
+#define ULLAVA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ULL_OK 0
+#define ULL_ERR_ARG (-1)    /* null pointer / non-positive size */
+#define ULL_ERR_SHAPE (-2)  /* alignment or shape constraint violated */
+#define ULL_ERR_LAUNCH (-3) /* HIP launch error */
+#define ULL_ERR_LDS (-4)    /* problem does not fit the 160 KiB LDS budget of the kernel */
+
+/* ull_gemm_bf16 epilogue flags */
+#define ULL_EPI_BIAS 1
+#define ULL_EPI_ACT_QUICK_GELU (1 << 1) /* hf: activations.py QuickGELUActivation (CLIP MLP) */
+#define ULL_EPI_ACT_GELU (2 << 1)       /* torch.nn.GELU (erf): SAM MLPBlock, mlp2x projector, mask-decoder upscaling */
+#define ULL_EPI_ACT_RELU (3 << 1)       /* seg/det projectors, SAM decoder MLPs */
+#define ULL_EPI_RESID 8                 /* out = bf16(R + bf16(linear)) : residual adds of LlamaDecoderLayer / CLIPEncoderLayer */
+#define ULL_EPI_SWIGLU 16               /* W = gate/up rows interleaved in groups of 16; out[N/2] = silu(gate)*up (hf: LlamaMLP.forward) */
+#define ULL_EPI_OUT_F32 32              /* C is float32 */
+
+/* C[M,N] = epilogue(X[M,K] * W[N,K]^T).  K % 64 == 0, ldx % 8 == 0, ldw % 8 == 0.
+ * Replaces every nn.Linear on the path: hf llama/modeling_llama.py LlamaAttention q/k/v/o_proj, LlamaMLP;
+ * hf clip/modeling_clip.py CLIPAttention, CLIPMLP; models/ullava_core.py:117-129 (vision_projector), :325 (lm_head);
+ * models/ullava.py:86-118 (seg/det projector, det_decoder); segment_anything/modeling/image_encoder.py:235-260,
+ * common.py:13-26, transformer.py:220-242, mask_decoder.py:169-191. */
+int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
+                  int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+
+/* y = w * bf16(x * rsqrt(mean(x^2) + eps)).  hf: LlamaRMSNorm.forward. */
+int ull_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+
+/* torch.nn.LayerNorm over the last dim (hf CLIPEncoderLayer.layer_norm1/2; SAM Block.norm1/2, TwoWayAttentionBlock.norm1-4). */
+int ull_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int64_t rows, int64_t D, float eps,
+                       void* stream);
+
+/* hf: CLIPVisionEmbeddings.forward (cat(class, patches) + position_embedding) fused with CLIPVisionModel.pre_layrnorm. */
+int ull_clip_embed_ln_bf16(const void* patch, int64_t ldp, const void* cls, const void* pos, const void* w, const void* b, void* y,
+                           int64_t ldy, int64_t n_img, int64_t tokens, int64_t D, float eps, void* stream);
+
+/* Attention with the score strip in LDS.  hf: llama eager_attention_forward (causal + key padding mask),
+ * clip eager_attention_forward (no mask); scale_mode 1 multiplies after the matmul like both.
+ * Q/K: [B,H,S,hd] by strides, hd contiguous.  Vt: [B,H,hd,vt_len] key-contiguous, zero for keys >= Sk.
+ * key_mask: int32 [B,Sk] (nonzero = attend) or NULL. */
+int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs, int64_t k_ss,
+                       const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O, int64_t o_bs, int64_t o_hs,
+                       int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal,
+                       int scale_mode, float scale, void* stream);
+
+/* hf: apply_rotary_pos_emb on n_heads consecutive heads (q heads then k heads of a fused QKV row), in place.
+ * positions int64 [tokens]; inv_freq float32 [hd/2] computed by the host exactly as LlamaRotaryEmbedding does. */
+int ull_rope_inplace_bf16(void* x, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads,
+                          int64_t hd, void* stream);
+
+/* V [B,S,H,hd] -> Vt [B,H,hd,pitch] with zeros for s in [S,pitch): the K-contiguous B-operand layout of P*V. */
+int ull_transpose_v_bf16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch,
+                         void* stream);
+
+/* Patch extraction for conv(kernel = stride = ps): out[(img,py,px)][(c*ps+ky)*ps+kx], zero padded to Kp columns.
+ * hf: CLIPVisionEmbeddings.patch_embedding; segment_anything/modeling/image_encoder.py:395-426 (PatchEmbed). */
+int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp, void* stream);
+
+/* models/ullava_core.py:205-226,248-251: per-sample start/end token counts, first start position, running feature index.
+ * spans int32 [B,4] = {kind 0 text / 1 image / 2 video, first start pos, feature index, error(counts differ)}. */
+int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_start, int64_t img_end, int64_t vid_start, int64_t vid_end,
+                 void* spans, void* stream);
+
+/* models/ullava_core.py:191,243-245,266-268: token-embedding lookup with the projected visual tokens spliced in after
+ * the first start token (the torch.cat of the reference, done as one gather).  Image i's n_img_tok feature rows start
+ * at row i*img_pitch + img_off of img_feat (pitch = patches + 1, off = 1 skips the CLS row without a copy). */
+int ull_embed_splice_bf16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch,
+                          int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B, int64_t S,
+                          int64_t D, void* stream);
+
+/* models/ullava_core.py:173-178: f[b,t,tok_pitch,d] (patches = tokens tok_off..tok_off+N) -> concat([mean over n (temporal), mean over t (spatial)], dim=1). */
+int ull_video_pool_bf16(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch, int64_t tok_off,
+                        void* stream);
+
+/* dst[i,:] = src[idx[i],:]  (models/ullava.py:190-199: boolean-mask gather of [SEG]/[LOC] rows, done BEFORE the projector). */
+int ull_gather_rows_bf16(const void* src, int64_t lds, const void* idx, void* dst, int64_t ldd, int64_t n, int64_t D, void* stream);
+
+/* out = bf16(a + b[row % b_rows])  (bf16 tensor adds: queries + query_pe, keys + key_pe, x + pos_embed). */
+int ull_add_rows_bf16(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULLAVA_HIP_H */

@@ -1,0 +1,78 @@
+"""Shared test plumbing: build the HIP-backed model from a golden fixture and compare with the reference
+outputs stored in the fixture and with the CPU oracle.  (Imports `oracle/` -- tests only.)"""
+import importlib
+import os
+
+import torch
+
+from oracle import ullava_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pkg(sub=""):
+    return importlib.import_module("u-llava_amd" + ("." + sub if sub else ""))
+
+
+def load_fixture(name):
+    return torch.load(os.path.join(GOLDEN, name), map_location="cpu", weights_only=True)
+
+
+def fixture_sd(fx, dtype=None):
+    W = pkg("weights")
+    dt = dtype or getattr(torch, fx["dtype"].split(".")[-1])
+    return {k: v.to(dt) for k, v in W.seeded_state_dict(fx["shapes"], fx["seed"], torch.float32).items()}
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b| in fp32."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def assert_close_bf16(a, b, ulps=2.0, floor=None, what=""):
+    """|a-b| <= ulps * 2^-8 * max(|b|, floor): agreement to a couple of bf16 ulps; `floor` defaults to 1% of max|b|."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    fl = float(b.abs().max()) * 0.01 if floor is None else floor
+    tol = ulps * 2.0 ** -8 * torch.maximum(b.abs(), torch.full_like(b, fl))
+    bad = (a - b).abs() > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max|d|={float((a - b).abs().max()):.4g} " \
+                                f"max|ref|={float(b.abs().max()):.4g}"
+
+
+def core_model_from_fixture(fx, device):
+    M = pkg("modeling_core")
+    C = pkg("configuration")
+    cd = fx["cfg"]
+    cfg = C.UllavaCoreConfig(vision_config=cd["vision_config"], vision_hidden_layer=cd["vision_hidden_layer"],
+                             projector_type=cd["projector_type"], projector_from_scratch=False, mm_token_ids=cd["mm_token_ids"],
+                             vocab_size=cd["vocab_size"], hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
+                             num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"],
+                             rms_norm_eps=cd["rms_norm_eps"], rope_theta=cd["rope_theta"])
+    model = M.UllavaCoreForCausalLM(cfg, device=device)
+    sd = fixture_sd(fx, torch.bfloat16)
+    missing = model.load_state_dict(sd, strict=True)
+    return model, sd
+
+
+def run_core_fixture(name, device="cuda:0"):
+    """HIP forward on a G1-style fixture -> error statistics (used by smoke() and the gpu tests)."""
+    fx = load_fixture(name)
+    model, sd = core_model_from_fixture(fx, device)
+    ids, mask, images = fx["input_ids"].to(device), fx["attention_mask"].to(device), fx["images"].to(device)
+    out = model(input_ids=ids, attention_mask=mask, images=images, output_hidden_states=True)
+    torch.cuda.synchronize()
+    # fp32 "truth": same bf16-rounded weights/inputs, fp32 arithmetic
+    sd32 = {k: v.float() for k, v in sd.items()}
+    truth = O.core_forward(sd32, fx["cfg"], fx["input_ids"], fx["attention_mask"], fx["images"].float())
+    e_ref = rel_err(fx["logits"], truth["logits"])
+    e_hip = rel_err(out.logits, truth["logits"])
+    stats = dict(logits_err_vs_ref=rel_err(out.logits, fx["logits"]), ref_err_vs_fp32=e_ref, hip_err_vs_fp32=e_hip,
+                 hidden_err_vs_ref=[round(rel_err(h, r), 5) for h, r in zip(out.hidden_states, fx["hidden_states"])],
+                 tol=max(3.0 * e_ref, 2.0 ** -6))
+    if "greedy_prompt" in fx:
+        seq = model.generate(input_ids=fx["greedy_prompt"].to(device), images=images[:1], max_new_tokens=8, do_sample=False)
+        stats["greedy_equal"] = bool(torch.equal(seq.cpu(), fx["greedy_sequences"]))
+        stats["greedy"] = seq[0, fx["greedy_prompt"].shape[1]:].tolist()
+    return stats

@@ -1,0 +1,223 @@
+"""GPU parity of each HIP kernel (called through the C-ABI) against the CPU oracle's restatement of the same
+reference op on the same seeded inputs.  Tolerance: a couple of bf16 ulps (2^-8 relative) -- the kernels keep the
+reference's bf16 rounding points, so differences come only from fp32 summation order."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import pkg, assert_close_bf16, rel_err
+from oracle import ullava_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def _mm_ref(x, w):
+    """bf16 matmul with fp32 accumulation, output rounded to bf16 (what torch's bf16 Linear does)."""
+    return (x.float() @ w.float().t()).to(BF)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (77, 100, 192), (1, 4, 64), (300, 32011 // 13, 256),
+                                   (515, 12288, 4096), (1029, 4096, 11008)])
+def test_gemm_plain(M, N, K):
+    ops = pkg("ops")
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    y = ops.linear(x.to(DEV), w.to(DEV))
+    assert_close_bf16(y, _mm_ref(x, w), what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_transpose_detecting():
+    """A = I against an asymmetric W catches swapped operands / C layouts."""
+    ops = pkg("ops")
+    K = 128
+    x = torch.eye(K).to(BF)
+    w = (torch.arange(256 * K).reshape(256, K) % 251).float().to(BF) / 16
+    y = ops.linear(x.to(DEV), w.to(DEV))
+    assert torch.equal(y.cpu().float(), w.float().t()), "C layout / operand swap"
+
+
+@pytest.mark.parametrize("act", [None, "quick_gelu", "gelu", "relu"])
+def test_gemm_bias_act_residual(act):
+    ops = pkg("ops")
+    M, N, K = 200, 264, 320
+    x, w, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5), _rand(N, seed=5), _rand(M, N, seed=6)
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=act)
+    t = F.linear(x.float(), w.float(), b.float()).to(BF)
+    ref = {None: lambda v: v, "quick_gelu": O.quick_gelu, "gelu": F.gelu, "relu": F.relu}[act](t)
+    assert_close_bf16(y, ref, what=f"bias+{act}")
+    y2 = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=r.to(DEV))
+    assert_close_bf16(y2, r + t, what="bias+residual")
+
+
+def test_gemm_swiglu():
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    M, I, K = 150, 352, 256
+    x, wg, wu = _rand(M, K, seed=7), _rand(I, K, seed=8, scale=K ** -0.5), _rand(I, K, seed=9, scale=K ** -0.5)
+    y = ops.linear(x.to(DEV), M_.interleave_gate_up(wg, wu).to(DEV), swiglu=True)
+    ref = F.silu(_mm_ref(x, wg)) * _mm_ref(x, wu)
+    assert_close_bf16(y, ref, what="swiglu")
+
+
+def test_gemm_odd_ldc_lm_head_shape():
+    ops = pkg("ops")
+    M, N, K = 70, 32011, 128
+    x, w = _rand(M, K, seed=10), _rand(N, K, seed=11, scale=K ** -0.5)
+    y = ops.linear(x.to(DEV), w.to(DEV))
+    assert_close_bf16(y, _mm_ref(x, w), what="odd N")
+
+
+def test_gemm_f32_out_and_strided_x():
+    ops = pkg("ops")
+    x_full = _rand(90, 3 * 128, seed=12)
+    w = _rand(64, 128, seed=13, scale=128 ** -0.5)
+    xg = x_full.to(DEV)
+    y = ops.linear(xg[:, 128:256], w.to(DEV), out_f32=True)
+    ref = x_full[:, 128:256].float() @ w.float().t()
+    assert y.dtype == torch.float32
+    assert rel_err(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("rows,D", [(5, 64), (33, 256), (300, 1024), (129, 1280), (1000, 4096)])
+def test_rmsnorm_layernorm(rows, D):
+    ops = pkg("ops")
+    x, w, b = _rand(rows, D, seed=20, scale=3.0), (1 + 0.1 * torch.randn(D)).to(BF), (0.1 * torch.randn(D)).to(BF)
+    y = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6)
+    assert_close_bf16(y, O.rms_norm(x, w, 1e-6), ulps=1.01, what="rmsnorm")
+    y = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    assert_close_bf16(y, F.layer_norm(x, (D,), w, b, 1e-5), ulps=1.01, what="layernorm")
+
+
+@pytest.mark.parametrize("hd,H", [(128, 4), (16, 4)])
+def test_rope(hd, H):
+    ops = pkg("ops")
+    B, S = 2, 37
+    D = H * hd
+    qkv = _rand(B * S, 3 * D, seed=30)
+    pos = torch.stack([torch.arange(S), torch.arange(S) + 500])
+    cos, sin = O.rope_tables(pos, hd, 10000.0, BF)
+    q = qkv[:, :D].view(B, S, H, hd).transpose(1, 2)
+    k = qkv[:, D:2 * D].view(B, S, H, hd).transpose(1, 2)
+    qr, kr = O.apply_rope(q, k, cos, sin)
+    g = qkv.to(DEV)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(DEV)
+    ops.rope_inplace(g, 3 * D, pos.reshape(-1).to(DEV), inv, B * S, 2 * H, hd)
+    out = g.cpu()
+    assert_close_bf16(out[:, :D].view(B, S, H, hd).transpose(1, 2), qr, ulps=1.01, what="rope q")
+    assert_close_bf16(out[:, D:2 * D].view(B, S, H, hd).transpose(1, 2), kr, ulps=1.01, what="rope k")
+    assert torch.equal(out[:, 2 * D:], qkv[:, 2 * D:]), "v must be untouched"
+
+
+def _attn_ref(q, k, v, scale, causal, key_mask):
+    """eager attention on bf16 tensors: q,k,v [B,H,S,hd]."""
+    w = torch.matmul(q, k.transpose(2, 3)) * scale
+    B, H, Sq, Sk = w.shape
+    if causal or key_mask is not None:
+        allowed = torch.ones(B, 1, Sq, Sk, dtype=torch.bool)
+        if causal:
+            allowed = allowed & (torch.arange(Sk)[None, :] <= torch.arange(Sq)[:, None] + (Sk - Sq))[None, None]
+        if key_mask is not None:
+            allowed = allowed & (key_mask[:, None, None, :] != 0)
+        w = w + torch.where(allowed, torch.zeros((), dtype=BF), torch.full((), torch.finfo(BF).min, dtype=BF))
+    w = F.softmax(w, dim=-1, dtype=torch.float32).to(BF)
+    return torch.matmul(w, v)
+
+
+@pytest.mark.parametrize("B,H,S,hd,causal,masked", [(2, 4, 11, 16, True, True), (1, 2, 5, 16, False, False), (2, 3, 257, 64, False, False),
+                                                    (2, 2, 291, 128, True, True), (1, 2, 643, 128, True, False), (1, 1, 196, 80, False, False),
+                                                    (1, 2, 1024, 128, True, False)])
+def test_attention(B, H, S, hd, causal, masked):
+    ops = pkg("ops")
+    D = H * hd
+    qkv = _rand(B * S, 3 * D, seed=40 + S)
+    km = None
+    if masked:
+        km = torch.ones(B, S, dtype=torch.int32)
+        km[-1, S - S // 3:] = 0                      # right padding on the last sample
+    q = qkv[:, :D].view(B, S, H, hd).transpose(1, 2)
+    k = qkv[:, D:2 * D].view(B, S, H, hd).transpose(1, 2)
+    v = qkv[:, 2 * D:].view(B, S, H, hd).transpose(1, 2)
+    ref = _attn_ref(q, k, v, hd ** -0.5, causal, km).transpose(1, 2).reshape(B * S, D)
+    g = qkv.to(DEV)
+    vt = ops.transpose_v(g[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
+    assert torch.equal(vt[..., :S].cpu(), v.transpose(2, 3)), "V^T"
+    assert float(vt[..., S:].abs().sum()) == 0.0, "V^T padding must be zero"
+    out = torch.empty(B * S, D, device=DEV, dtype=BF)
+    ops.attention(g, g[:, D:], vt, out, B, H, S, S, hd, (S * 3 * D, hd, 3 * D), (S * 3 * D, hd, 3 * D), (S * D, hd, D),
+                  None if km is None else km.to(DEV), causal=causal, scale_mode=1, scale=hd ** -0.5)
+    got = out.cpu()
+    if masked:      # rows of padded queries are don't-care in the reference's callers too; compare the valid ones
+        valid = km.bool().reshape(-1)
+        got, ref = got[valid], ref[valid]
+    assert_close_bf16(got, ref, ulps=3.0, what=f"attention S={S} hd={hd}")
+
+
+def test_patch_embed_and_clip_pre_ln():
+    ops = pkg("ops")
+    n, C, HW, ps, Dv = 3, 3, 56, 14, 64
+    img = _rand(n, C, HW, HW, seed=50)
+    w = _rand(Dv, C, ps, ps, seed=51, scale=(C * ps * ps) ** -0.5)
+    cls, pos = _rand(Dv, seed=52), _rand((HW // ps) ** 2 + 1, Dv, seed=53)
+    lw, lb = (1 + 0.1 * torch.randn(Dv)).to(BF), (0.1 * torch.randn(Dv)).to(BF)
+    K = C * ps * ps
+    Kp = ((K + 63) // 64) * 64
+    cols = ops.im2col(img.to(DEV), ps, Kp)
+    ref_cols = F.unfold(img.float(), ps, stride=ps).transpose(1, 2).reshape(-1, K).to(BF)
+    assert torch.equal(cols[:, :K].cpu(), ref_cols) and float(cols[:, K:].abs().sum()) == 0.0
+    wp = torch.zeros(Dv, Kp, dtype=BF)
+    wp[:, :K] = w.reshape(Dv, K)
+    patches = ops.linear(cols, wp.to(DEV))
+    pe = F.conv2d(img, w, None, stride=ps).flatten(2).transpose(1, 2)
+    assert_close_bf16(patches.view(n, -1, Dv), pe, what="patch conv")
+    T = pe.shape[1] + 1
+    h = ops.clip_embed_ln(patches, cls.to(DEV), pos.to(DEV), lw.to(DEV), lb.to(DEV), n, T, 1e-5)
+    ref = F.layer_norm(torch.cat([cls.expand(n, 1, -1), patches.cpu().view(n, -1, Dv)], 1) + pos[None], (Dv,), lw, lb, 1e-5)
+    assert_close_bf16(h, ref, ulps=1.01, what="clip embeddings + pre-LN")
+
+
+def test_embed_splice_and_spans():
+    ops = pkg("ops")
+    V, D, P = 50, 64, 4
+    table = _rand(V, D, seed=60)
+    ids = torch.tensor([[1, 7, 8, 9, 10, 11, 12, 13, 14, 15],          # text only
+                        [1, 40, 42, 42, 42, 42, 41, 5, 6, 7],          # image at pos 1
+                        [1, 2, 43, 45, 45, 45, 45, 45, 44, 9],         # video (5 tokens) at pos 2
+                        [1, 3, 3, 40, 42, 42, 42, 42, 41, 0]])         # image at pos 3
+    img_feat = _rand(2, P + 1, D, seed=61)      # with a leading CLS row that must be skipped
+    vid_feat = _rand(1, 5, D, seed=62)
+    spans = ops.mm_spans(ids.to(DEV), 40, 41, 43, 44)
+    assert spans.cpu().tolist() == [[0, -1, 0, 0], [1, 1, 0, 0], [2, 2, 0, 0], [1, 3, 1, 0]]
+    out = ops.embed_splice(ids.to(DEV), table.to(DEV), img_feat.to(DEV), vid_feat.to(DEV), spans, P, P + 1, 1).cpu()
+    ref = table[ids].clone()
+    ref[1, 2:6] = img_feat[0, 1:]
+    ref[2, 3:8] = vid_feat[0]
+    ref[3, 4:8] = img_feat[1, 1:]
+    assert torch.equal(out, ref)
+    bad = torch.tensor([[1, 40, 42, 41, 41, 5]])
+    assert int(ops.mm_spans(bad.to(DEV), 40, 41, 43, 44)[0, 3]) == 1      # start/end count mismatch is flagged
+
+
+def test_video_pool():
+    ops = pkg("ops")
+    B, T, N, D = 2, 8, 4, 64
+    f = _rand(B * T, N + 1, D, seed=70)
+    out = ops.video_pool(f.to(DEV), B, T, N, tok_pitch=N + 1, tok_off=1).cpu()
+    ff = f[:, 1:].reshape(B, T, N, D)
+    ref = torch.concat([ff.mean(dim=2), ff.mean(dim=1)], dim=1)
+    assert_close_bf16(out, ref, ulps=1.01, what="video pool")
+
+
+def test_gather_and_add():
+    ops = pkg("ops")
+    src = _rand(40, 128, seed=80)
+    idx = torch.tensor([3, 39, 0, 3])
+    assert torch.equal(ops.gather_rows(src.to(DEV), idx.to(DEV)).cpu(), src[idx])
+    a, b = _rand(6, 4, 128, seed=81), _rand(4, 128, seed=82)
+    assert torch.equal(ops.add_rows(a.to(DEV), b.to(DEV)).cpu(), a + b)

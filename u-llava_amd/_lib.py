@@ -1,0 +1,60 @@
+"""ctypes binding of libullava_hip.so (the C-ABI declared in include/ullava_hip.h).
+
+There is no fallback: if the library is missing or a symbol is absent this raises, and every op in
+`ops.py` goes through here.  The library is built in-tree by `__graft_entry__.build()` /
+`make -C u-llava_amd/csrc` so it travels with the repo snapshot.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libullava_hip.so")
+
+_i64, _i32, _f32, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (restype is always int)
+SIGNATURES = {
+    "ull_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
+    "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
+    "ull_layernorm_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
+    "ull_clip_embed_ln_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
+    "ull_attention_bf16": [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64,
+                           _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _ptr],
+    "ull_rope_inplace_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "ull_transpose_v_bf16": [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "ull_im2col_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "ull_mm_spans": [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    "ull_embed_splice_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "ull_video_pool_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "ull_gather_rows_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "ull_add_rows_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+}
+
+ERRORS = {-1: "ULL_ERR_ARG (null pointer / bad size)", -2: "ULL_ERR_SHAPE (alignment or shape constraint)",
+          -3: "ULL_ERR_LAUNCH (HIP launch failed)", -4: "ULL_ERR_LDS (does not fit the LDS budget)"}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and attach argtypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"u-llava_amd: HIP library not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C u-llava_amd/csrc`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"u-llava_amd: {name} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,144 @@
+// Row normalisations for gfx950: RMSNorm (LLaMA), LayerNorm (CLIP / SAM), CLIP embedding assembly +
+// pre-LayerNorm.  HBM-bound streaming kernels: 16-byte bf16x8 loads, the whole row held in registers
+// (read once, written once), fp32 statistics reduced across the sub-wave that owns the row.
+//
+// reference semantics:
+//   RMSNorm  : transformers LlamaRMSNorm.forward  -> w * bf16(x * rsqrt(mean(x^2) + eps))   (two roundings)
+//   LayerNorm: torch.nn.LayerNorm on bf16          -> bf16(((x - mean) * rstd) * g + b)       (one rounding)
+//   CLIP embed: transformers CLIPVisionEmbeddings.forward + CLIPVisionModel.pre_layrnorm
+#include "ull_common.h"
+
+namespace {
+
+// A row of D elements is owned by LPR lanes (power of two, <= 64); lane s of the group loads the
+// 8-element chunks s, s+LPR, s+2*LPR, ... (NCH of them).
+template <int NCH, int MODE>  // MODE 0 rmsnorm, 1 layernorm
+__global__ __launch_bounds__(256) void rownorm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                      const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
+                                                      long rows, int D, float eps, int lpr,
+                                                      // optional CLIP-embedding gather (MODE 1 only): row = (img, tok)
+                                                      const bf16_t* __restrict__ cls, const bf16_t* __restrict__ pos, int tokens) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (lpr - 1);
+    const int rows_per_wave = 64 / lpr;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave + lane / lpr;
+    const bool row_ok = row < rows;
+    const int nchunk = D >> 3;
+    float v[NCH][8];
+    const bf16_t* xr;
+    const bf16_t* pr = nullptr;
+    if (cls != nullptr) {
+        // CLIP: token 0 is the class embedding, token t>0 is patch-embedding row (img*(tokens-1) + t-1);
+        // the position embedding is added as a bf16 tensor op (one rounding) before the LayerNorm.
+        const long img = row / tokens;
+        const int t = (int)(row - img * tokens);
+        xr = (t == 0) ? cls : x + (img * (tokens - 1) + (t - 1)) * ldx;
+        pr = pos + (long)t * D;
+    } else {
+        xr = x + row * ldx;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = sub + i * lpr;
+        if (row_ok && c < nchunk) {
+            unpack8(*(const uint4*)(xr + c * 8), v[i]);
+            if (pr != nullptr) {
+                float pv[8];
+                unpack8(*(const uint4*)(pr + c * 8), pv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = rbf(v[i][j] + pv[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1 += v[i][j]; s2 += v[i][j] * v[i][j]; }
+    }
+    const float invD = 1.0f / (float)D;
+    float mean = 0.f, rstd;
+    if (MODE == 0) {
+        s2 = group_sum(s2, lpr);
+        rstd = rsqrtf(s2 * invD + eps);
+    } else {
+        s1 = group_sum(s1, lpr);
+        mean = s1 * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = sub + i * lpr;
+            if (c < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+            }
+        }
+        q = group_sum(q, lpr);
+        rstd = 1.0f / sqrtf(q * invD + eps);
+    }
+    if (!row_ok) return;
+    bf16_t* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = sub + i * lpr;
+        if (c < nchunk) {
+            float wv[8], o[8];
+            unpack8(*(const uint4*)(w + c * 8), wv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = wv[j] * rbf(v[i][j] * rstd);
+            } else {
+                float bv[8];
+                unpack8(*(const uint4*)(b + c * 8), bv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = ((v[i][j] - mean) * rstd) * wv[j] + bv[j];
+            }
+            *(uint4*)(yr + c * 8) = pack8(o);
+        }
+    }
+}
+
+template <int MODE>
+int launch_rownorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, long ldy, long rows, int D, float eps,
+                   const bf16_t* cls, const bf16_t* pos, int tokens, hipStream_t st) {
+    if (D <= 0 || (D & 7) || (ldx & 7) || (ldy & 7) || rows <= 0) return ULL_ERR_SHAPE;
+    const int nchunk = D >> 3;
+    int lpr = 1;
+    while (lpr < 64 && lpr < nchunk) lpr <<= 1;
+    const int nch = (nchunk + lpr - 1) / lpr;
+    const long rows_per_block = 4 * (64 / lpr);
+    const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
+#define ULL_RN(N) hipLaunchKernelGGL((rownorm_kernel<N, MODE>), grid, dim3(256), 0, st, x, ldx, w, b, y, ldy, rows, D, eps, lpr, cls, pos, tokens)
+    if (nch <= 1) ULL_RN(1);
+    else if (nch <= 2) ULL_RN(2);
+    else if (nch <= 4) ULL_RN(4);
+    else if (nch <= 8) ULL_RN(8);
+    else if (nch <= 16) ULL_RN(16);
+    else return ULL_ERR_SHAPE;   // D > 8192 never occurs on this path
+#undef ULL_RN
+    return ull_check_launch();
+}
+
+}  // namespace
+
+extern "C" int ull_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps,
+                                void* stream) {
+    if (!x || !w || !y) return ULL_ERR_ARG;
+    return launch_rownorm<0>((const bf16_t*)x, ldx, (const bf16_t*)w, nullptr, (bf16_t*)y, ldy, rows, (int)D, eps, nullptr, nullptr, 0,
+                             (hipStream_t)stream);
+}
+
+extern "C" int ull_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int64_t rows, int64_t D,
+                                  float eps, void* stream) {
+    if (!x || !w || !b || !y) return ULL_ERR_ARG;
+    return launch_rownorm<1>((const bf16_t*)x, ldx, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, rows, (int)D, eps, nullptr, nullptr,
+                             0, (hipStream_t)stream);
+}
+
+// out[(img, t), :] = LayerNorm( (t == 0 ? class_embedding : patch[img, t-1]) + position_embedding[t] )
+extern "C" int ull_clip_embed_ln_bf16(const void* patch, int64_t ldp, const void* cls, const void* pos, const void* w, const void* b,
+                                      void* y, int64_t ldy, int64_t n_img, int64_t tokens, int64_t D, float eps, void* stream) {
+    if (!patch || !cls || !pos || !w || !b || !y || tokens < 2) return ULL_ERR_ARG;
+    return launch_rownorm<1>((const bf16_t*)patch, ldp, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, n_img * tokens, (int)D, eps,
+                             (const bf16_t*)cls, (const bf16_t*)pos, (int)tokens, (hipStream_t)stream);
+}

@@ -1,0 +1,198 @@
+// Gather / scatter / pooling kernels around the GEMMs (all HBM-bound streaming, 16-byte accesses where
+// the layout allows):
+//   * patch im2col            (CLIPVisionEmbeddings.patch_embedding / SAM PatchEmbed: conv k = stride = patch)
+//   * multimodal span finder + token-embedding lookup with visual-token splice
+//                             (reference models/ullava_core.py:182-277 embed_images_videos)
+//   * video spatio-temporal pooling (models/ullava_core.py:160-180 encode_video)
+//   * row gather, bf16 add
+#include "ull_common.h"
+
+namespace {
+
+// out[(img, py, px)][k], k = (c*ps + ky)*ps + kx  (the flattening of conv weight [D, C, ps, ps]); columns
+// [C*ps*ps, Kp) are zero so the GEMM can use K = Kp (multiple of 64).  `skip_rows_per_img` rows are left
+// untouched in front of every image's patches (not used: patches are written densely).
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int C, int Hh, int Ww, int ps,
+                                                     int gh, int gw, int Kp, long total) {
+    const int K = C * ps * ps;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % Kp);
+        const long row = i / Kp;
+        bf16_t v = 0;
+        if (k < K) {
+            const int kx = k % ps, ky = (k / ps) % ps, c = k / (ps * ps);
+            const int px = (int)(row % gw), py = (int)((row / gw) % gh);
+            const long b = row / ((long)gw * gh);
+            v = img[((b * C + c) * Hh + (py * ps + ky)) * (long)Ww + px * ps + kx];
+        }
+        out[i] = v;
+    }
+}
+
+// Per sample: count start/end tokens, first start position, running index into the feature batches.
+// spans[b] = {kind (0 text, 1 image, 2 video), first start pos, feature index, error flag}
+__global__ void mm_spans_kernel(const int64_t* __restrict__ ids, int B, int S, int img_start, int img_end, int vid_start, int vid_end,
+                                int32_t* __restrict__ spans) {
+    // single block; thread b scans sample b, then an in-block prefix count assigns feature indices
+    __shared__ int kind_s[1024];
+    const int b = threadIdx.x;
+    int kind = 0, pos = -1, err = 0;
+    if (b < B) {
+        int nis = 0, nie = 0, nvs = 0, nve = 0, pi = -1, pv = -1;
+        for (int s = 0; s < S; ++s) {
+            const int64_t t = ids[(long)b * S + s];
+            if (t == img_start) { if (pi < 0) pi = s; ++nis; }
+            if (t == img_end) ++nie;
+            if (t == vid_start) { if (pv < 0) pv = s; ++nvs; }
+            if (t == vid_end) ++nve;
+        }
+        if (nis != nie || nvs != nve) err = 1;     // reference asserts (ullava_core.py:209-211)
+        if (nis > 0) { kind = 1; pos = pi; }
+        else if (nvs > 0) { kind = 2; pos = pv; }
+    }
+    kind_s[threadIdx.x] = (b < B) ? kind : 0;
+    __syncthreads();
+    if (b < B) {
+        int idx = 0;
+        for (int j = 0; j < b; ++j) idx += (kind_s[j] == kind);
+        spans[b * 4 + 0] = kind;
+        spans[b * 4 + 1] = pos;
+        spans[b * 4 + 2] = idx;
+        spans[b * 4 + 3] = err;
+    }
+}
+
+// out[b, s, :] = image/video feature row if s lies in the placeholder span of sample b, else table[ids[b, s]]
+__global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table,
+                                                           const bf16_t* __restrict__ img_feat, int n_img_tok, int img_pitch, int img_off,
+                                                           const bf16_t* __restrict__ vid_feat, int n_vid_tok,
+                                                           const int32_t* __restrict__ spans, bf16_t* __restrict__ out, int S, int D,
+                                                           long rows) {
+    const int cpr = D >> 3;                      // 16-byte chunks per row
+    const int rows_per_block = 256 / min(cpr, 256);
+    const int lanes_per_row = min(cpr, 256);
+    const long row = (long)blockIdx.x * rows_per_block + threadIdx.x / lanes_per_row;
+    if (row >= rows || (int)(threadIdx.x / lanes_per_row) >= rows_per_block) return;
+    const int b = (int)(row / S), s = (int)(row % S);
+    const bf16_t* src = table + (long)ids[row] * D;
+    if (spans != nullptr) {
+        const int kind = spans[b * 4], pos = spans[b * 4 + 1], idx = spans[b * 4 + 2];
+        if (kind == 1 && img_feat != nullptr && s > pos && s <= pos + n_img_tok) src = img_feat + ((long)idx * img_pitch + img_off + (s - pos - 1)) * D;
+        if (kind == 2 && vid_feat != nullptr && s > pos && s <= pos + n_vid_tok) src = vid_feat + ((long)idx * n_vid_tok + (s - pos - 1)) * D;
+    }
+    bf16_t* dst = out + row * D;
+    for (int c = threadIdx.x % lanes_per_row; c < cpr; c += lanes_per_row) *(uint4*)(dst + c * 8) = *(const uint4*)(src + c * 8);
+}
+
+// f [b, t, pitch, d] (tokens off..off+n of every frame are the patches) -> out [b, t + n, d]: rows [0, t) = mean over patches (temporal), rows [t, t+n) = mean over
+// frames (spatial); fp32 accumulate, one bf16 rounding (torch.mean on a bf16 tensor).
+__global__ __launch_bounds__(256) void video_pool_kernel(const bf16_t* __restrict__ f, bf16_t* __restrict__ out, int T, int N, int D,
+                                                         int pitch, int off) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x;                    // output row in [0, T + N)
+    const bf16_t* fb = f + ((long)b * T * pitch + off) * D;
+    bf16_t* o = out + ((long)b * (T + N) + r) * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        if (r < T) {
+            for (int n = 0; n < N; ++n) acc += bf2f(fb[((long)r * pitch + n) * D + d]);
+            o[d] = f2bf(acc / (float)N);
+        } else {
+            const int n = r - T;
+            for (int t = 0; t < T; ++t) acc += bf2f(fb[((long)t * pitch + n) * D + d]);
+            o[d] = f2bf(acc / (float)T);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, long lds_, const int64_t* __restrict__ idx,
+                                                          bf16_t* __restrict__ dst, long ldd, int D) {
+    const long r = blockIdx.x;
+    const bf16_t* s = src + idx[r] * lds_;
+    bf16_t* d = dst + r * ldd;
+    for (int c = threadIdx.x; c < (D >> 3); c += 256) *(uint4*)(d + c * 8) = *(const uint4*)(s + c * 8);
+}
+
+// out = bf16(a + b[row % b_rows])   (row-broadcast add: residual adds, + positional tables)
+__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+                                                       long rows, int D, long b_rows) {
+    const int cpr = D >> 3;
+    const long total = rows * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cpr;
+        const int c = (int)(i % cpr);
+        float x[8], y[8];
+        unpack8(*(const uint4*)(a + r * D + c * 8), x);
+        unpack8(*(const uint4*)(b + (r % b_rows) * D + c * 8), y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        *(uint4*)(out + r * D + c * 8) = pack8(x);
+    }
+}
+
+}  // namespace
+
+extern "C" int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp,
+                               void* stream) {
+    if (!img || !out || n_img <= 0 || ps <= 0) return ULL_ERR_ARG;
+    if (H % ps || W % ps || Kp < C * ps * ps) return ULL_ERR_SHAPE;
+    const int gh = (int)(H / ps), gw = (int)(W / ps);
+    const long total = n_img * gh * gw * Kp;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, (int)C, (int)H, (int)W,
+                       (int)ps, gh, gw, (int)Kp, total);
+    return ull_check_launch();
+}
+
+extern "C" int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_start, int64_t img_end, int64_t vid_start, int64_t vid_end,
+                            void* spans, void* stream) {
+    if (!ids || !spans || B <= 0 || S <= 0) return ULL_ERR_ARG;
+    if (B > 1024) return ULL_ERR_SHAPE;
+    const int threads = (int)((B + 63) / 64) * 64;
+    hipLaunchKernelGGL(mm_spans_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, (const int64_t*)ids, (int)B, (int)S, (int)img_start,
+                       (int)img_end, (int)vid_start, (int)vid_end, (int32_t*)spans);
+    return ull_check_launch();
+}
+
+extern "C" int ull_embed_splice_bf16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch,
+                                     int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B,
+                                     int64_t S, int64_t D, void* stream) {
+    if (!ids || !table || !out || B <= 0 || S <= 0) return ULL_ERR_ARG;
+    if (D & 7) return ULL_ERR_SHAPE;
+    const long rows = B * S;
+    const int cpr = (int)(D >> 3);
+    const int rows_per_block = 256 / (cpr < 256 ? cpr : 256);
+    const unsigned blocks = (unsigned)((rows + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(embed_splice_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, (const bf16_t*)table,
+                       (const bf16_t*)img_feat, (int)n_img_tok, (int)img_pitch, (int)img_off, (const bf16_t*)vid_feat, (int)n_vid_tok, (const int32_t*)spans,
+                       (bf16_t*)out, (int)S, (int)D, rows);
+    return ull_check_launch();
+}
+
+extern "C" int ull_video_pool_bf16(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch,
+                                   int64_t tok_off, void* stream) {
+    if (!f || !out || B <= 0 || T <= 0 || N <= 0 || D <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(video_pool_kernel, dim3((unsigned)(T + N), (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)f,
+                       (bf16_t*)out, (int)T, (int)N, (int)D, (int)tok_pitch, (int)tok_off);
+    return ull_check_launch();
+}
+
+extern "C" int ull_gather_rows_bf16(const void* src, int64_t lds_, const void* idx, void* dst, int64_t ldd, int64_t n, int64_t D,
+                                    void* stream) {
+    if (!src || !idx || !dst) return ULL_ERR_ARG;
+    if (n == 0) return ULL_OK;
+    if ((D & 7) || (lds_ & 7) || (ldd & 7)) return ULL_ERR_SHAPE;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, lds_, (const int64_t*)idx,
+                       (bf16_t*)dst, ldd, (int)D);
+    return ull_check_launch();
+}
+
+extern "C" int ull_add_rows_bf16(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream) {
+    if (!a || !b || !out || rows <= 0 || b_rows <= 0) return ULL_ERR_ARG;
+    if (D & 7) return ULL_ERR_SHAPE;
+    const long total = rows * (D >> 3);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, rows,
+                       (int)D, b_rows);
+    return ull_check_launch();
+}

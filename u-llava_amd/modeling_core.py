@@ -1,0 +1,439 @@
+"""UllavaCoreForCausalLM on MI355X: CLIP ViT-L -> vision_projector -> LLaMA -> lm_head.
+
+Host-side mirror of reference `models/ullava_core.py:78-395` (same constructor, attribute names, state-dict keys,
+`forward` / `encode_image` / `encode_video` / `embed_images_videos` / `prepare_inputs_for_generation` / `generate`
+signatures and outputs).  The module tree exists to carry the reference's parameter names; no nn.Module.forward
+of a leaf is ever used: every arithmetic op is a HIP kernel reached through `ops.py` -> C-ABI.
+
+MI355X-specific host design:
+  * weights are re-laid out once (`pack_weights`): q|k|v fused into one [3D, D] matrix (one GEMM, one pass over
+    the activations), gate/up interleaved in 16-row groups so SwiGLU is a register-level GEMM epilogue, the CLIP
+    patch conv flattened and K-padded to a multiple of 64 for the MFMA GEMM;
+  * the residual stream is a flat [B*S, D] bf16 matrix; q/k are consumed in place from the fused QKV buffer by
+    strides, V is written once as V^T (K-contiguous for the P*V MFMA);
+  * the per-sample python splice loop of the reference (with its device->host syncs) is one gather kernel.
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .configuration import UllavaCoreConfig
+
+BF16 = torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------------------------
+# parameter holders (names match transformers' modules; forward intentionally absent)
+# ----------------------------------------------------------------------------------------------------------
+def _param(*shape, device=None, dtype=BF16):
+    return nn.Parameter(torch.empty(*shape, device=device, dtype=dtype), requires_grad=False)
+
+
+class Linear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True, device=None, dtype=BF16):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = _param(out_features, in_features, device=device, dtype=dtype)
+        self.bias = _param(out_features, device=device, dtype=dtype) if bias else None
+
+
+class Embedding(nn.Module):
+    def __init__(self, n, d, device=None, dtype=BF16):
+        super().__init__()
+        self.weight = _param(n, d, device=device, dtype=dtype)
+
+
+class Norm(nn.Module):
+    def __init__(self, d, bias=True, eps=1e-5, device=None, dtype=BF16):
+        super().__init__()
+        self.eps = eps
+        self.weight = _param(d, device=device, dtype=dtype)
+        self.bias = _param(d, device=device, dtype=dtype) if bias else None
+
+
+class Conv2dHolder(nn.Module):
+    def __init__(self, cin, cout, k, bias, device=None, dtype=BF16):
+        super().__init__()
+        self.weight = _param(cout, cin, k, k, device=device, dtype=dtype)
+        self.bias = _param(cout, device=device, dtype=dtype) if bias else None
+
+
+class _Holder(nn.Module):
+    pass
+
+
+def _llama_layer(cfg, device, dtype):
+    m = _Holder()
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    m.self_attn = _Holder()
+    for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+        setattr(m.self_attn, n, Linear(D, D, bias=False, device=device, dtype=dtype))
+    m.mlp = _Holder()
+    m.mlp.gate_proj = Linear(D, I, bias=False, device=device, dtype=dtype)
+    m.mlp.up_proj = Linear(D, I, bias=False, device=device, dtype=dtype)
+    m.mlp.down_proj = Linear(I, D, bias=False, device=device, dtype=dtype)
+    m.input_layernorm = Norm(D, bias=False, eps=cfg.rms_norm_eps, device=device, dtype=dtype)
+    m.post_attention_layernorm = Norm(D, bias=False, eps=cfg.rms_norm_eps, device=device, dtype=dtype)
+    return m
+
+
+def _clip_tower(vc, device, dtype):
+    D, I = vc.hidden_size, vc.intermediate_size
+    m = _Holder()
+    m.embeddings = _Holder()
+    m.embeddings.class_embedding = _param(D, device=device, dtype=dtype)
+    m.embeddings.patch_embedding = Conv2dHolder(vc.num_channels, D, vc.patch_size, bias=False, device=device, dtype=dtype)
+    m.embeddings.position_embedding = Embedding((vc.image_size // vc.patch_size) ** 2 + 1, D, device=device, dtype=dtype)
+    m.pre_layrnorm = Norm(D, eps=vc.layer_norm_eps, device=device, dtype=dtype)
+    m.encoder = _Holder()
+    layers = []
+    for _ in range(vc.num_hidden_layers):
+        l = _Holder()
+        l.self_attn = _Holder()
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            setattr(l.self_attn, n, Linear(D, D, device=device, dtype=dtype))
+        l.layer_norm1 = Norm(D, eps=vc.layer_norm_eps, device=device, dtype=dtype)
+        l.mlp = _Holder()
+        l.mlp.fc1 = Linear(D, I, device=device, dtype=dtype)
+        l.mlp.fc2 = Linear(I, D, device=device, dtype=dtype)
+        l.layer_norm2 = Norm(D, eps=vc.layer_norm_eps, device=device, dtype=dtype)
+        layers.append(l)
+    m.encoder.layers = nn.ModuleList(layers)
+    m.post_layernorm = Norm(D, eps=vc.layer_norm_eps, device=device, dtype=dtype)
+    return m
+
+
+class CausalLMOutputWithPast(dict):
+    """Attribute + key + index access, like transformers.modeling_outputs.CausalLMOutputWithPast."""
+    _order = ("loss", "logits", "past_key_values", "hidden_states", "attentions")
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [self.get(n) for n in self._order if self.get(n) is not None][k]
+        return dict.__getitem__(self, k)
+
+
+class GenerateOutput(dict):
+    __getattr__ = dict.__getitem__
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[I, K] x2 -> [2I, K] with rows [gate 16g..16g+15 | up 16g..16g+15] per group g (ULL_EPI_SWIGLU layout)."""
+    I, K = gate.shape
+    assert I % 16 == 0
+    return torch.stack((gate.view(I // 16, 16, K), up.view(I // 16, 16, K)), dim=1).reshape(2 * I, K).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------
+class UllavaCoreForCausalLM(nn.Module):
+    config_class = UllavaCoreConfig
+
+    def __init__(self, config: UllavaCoreConfig, device=None, dtype=BF16):
+        super().__init__()
+        if dtype != BF16:
+            raise NotImplementedError("the MI355X path computes in bf16 (reference configs: bf16: true)")
+        self.config = config
+        D = config.hidden_size
+        self.model = _Holder()
+        self.model.embed_tokens = Embedding(config.vocab_size, D, device=device, dtype=dtype)
+        self.model.layers = nn.ModuleList([_llama_layer(config, device, dtype) for _ in range(config.num_hidden_layers)])
+        self.model.norm = Norm(D, bias=False, eps=config.rms_norm_eps, device=device, dtype=dtype)
+        self.lm_head = Linear(D, config.vocab_size, bias=False, device=device, dtype=dtype)
+        self.vision_encoder = _clip_tower(config.vision_config, device, dtype)
+        self.vision_projector = self.build_vision_projector(config.vision_config.hidden_size, D, config.projector_type, device, dtype)
+        self.vision_hidden_layer = config.vision_hidden_layer
+        self.projector_from_scratch = config.projector_from_scratch
+        self.mm_token_ids = config.mm_token_ids
+        self.strict_checks = True          # reproduce the reference's start/end-count assert (one tiny D2H read)
+        self._packed = None
+        self._inv_freq = None
+
+    # -- construction helpers ----------------------------------------------------------------------------
+    @staticmethod
+    def build_vision_projector(in_dim, hidden_dim, name="mlp", device=None, dtype=BF16):
+        """reference models/ullava_core.py:117-129."""
+        if name == "mlp":
+            return Linear(in_dim, hidden_dim, device=device, dtype=dtype)
+        if name == "mlp2x":
+            return nn.Sequential(Linear(in_dim, hidden_dim, device=device, dtype=dtype), nn.GELU(),
+                                 Linear(hidden_dim, hidden_dim, device=device, dtype=dtype))
+        raise NotImplementedError
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def init_mm_tokens(self, tokenizer, mm_tokens):
+        ids = {k: tokenizer.convert_tokens_to_ids(v) for k, v in mm_tokens.items()}
+        self.config.mm_token_ids = ids
+        self.mm_token_ids = ids
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        # transformers 4.29.1 checkpoints nest the CLIP tower under `vision_encoder.vision_model.`
+        sd = {k.replace("vision_encoder.vision_model.", "vision_encoder."): v for k, v in state_dict.items()}
+        sd = {k: v for k, v in sd.items() if not k.endswith("position_ids") and "rotary_emb.inv_freq" not in k}
+        self._packed = None
+        return super().load_state_dict(sd, strict=strict, assign=assign)
+
+    # -- weight re-layout ----------------------------------------------------------------------------------
+    def pack_weights(self, free_originals: bool = False):
+        """Build the MI355X layouts.  Call again after changing parameters."""
+        cfg = self.config
+        pk = {"llama": [], "clip": []}
+        for l in self.model.layers:
+            a, m = l.self_attn, l.mlp
+            pk["llama"].append(dict(
+                w_qkv=torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).contiguous(),
+                w_o=a.o_proj.weight, w_gu=interleave_gate_up(m.gate_proj.weight, m.up_proj.weight), w_down=m.down_proj.weight,
+                ln1=l.input_layernorm.weight, ln2=l.post_attention_layernorm.weight))
+        for l in self.vision_encoder.encoder.layers:
+            a = l.self_attn
+            pk["clip"].append(dict(
+                w_qkv=torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).contiguous(),
+                b_qkv=torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0).contiguous(),
+                w_out=a.out_proj.weight, b_out=a.out_proj.bias, fc1=l.mlp.fc1, fc2=l.mlp.fc2, ln1=l.layer_norm1, ln2=l.layer_norm2))
+        vc = cfg.vision_config
+        w = self.vision_encoder.embeddings.patch_embedding.weight
+        K = vc.num_channels * vc.patch_size * vc.patch_size
+        Kp = ((K + 63) // 64) * 64
+        wp = torch.zeros(w.shape[0], Kp, device=w.device, dtype=w.dtype)
+        wp[:, :K] = w.reshape(w.shape[0], K)
+        pk["patch_w"], pk["patch_Kp"] = wp, Kp
+        self._packed = pk
+        if free_originals:
+            for l in self.model.layers:
+                for mod in (l.self_attn.q_proj, l.self_attn.k_proj, l.self_attn.v_proj, l.mlp.gate_proj, l.mlp.up_proj):
+                    mod.weight.data = torch.empty(0, device=mod.weight.device, dtype=mod.weight.dtype)
+        return self
+
+    def _pk(self):
+        if self._packed is None:
+            self.pack_weights()
+        return self._packed
+
+    # -- CLIP ----------------------------------------------------------------------------------------------
+    def _selected_layer_count(self) -> int:
+        L = self.config.vision_config.num_hidden_layers
+        idx = self.vision_hidden_layer if self.vision_hidden_layer >= 0 else L + 1 + self.vision_hidden_layer
+        if not 0 <= idx <= L:
+            raise ValueError("vision_hidden_layer out of range")
+        return idx          # hidden_states[idx] = output after `idx` encoder layers
+
+    def _clip_hidden(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """hidden_states[vision_hidden_layer] of CLIPVisionModel, shape [n, 1 + patches, Dv] (CLS row kept).
+        Layers past the selected one (and post_layernorm) are dead compute in the reference and are not run."""
+        pk = self._pk()
+        vc = self.config.vision_config
+        ve = self.vision_encoder
+        n = pixel_values.shape[0]
+        if pixel_values.shape[-1] != vc.image_size or pixel_values.shape[-2] != vc.image_size:
+            raise ValueError(f"Input image size ({pixel_values.shape[-2]}*{pixel_values.shape[-1]}) doesn't match model "
+                             f"({vc.image_size}*{vc.image_size}).")
+        x = pixel_values.to(BF16).contiguous()
+        P = (vc.image_size // vc.patch_size) ** 2
+        Dv, H = vc.hidden_size, vc.num_attention_heads
+        hd = Dv // H
+        cols = ops.im2col(x, vc.patch_size, pk["patch_Kp"])
+        patches = ops.linear(cols, pk["patch_w"])
+        S = P + 1
+        h = ops.clip_embed_ln(patches, ve.embeddings.class_embedding, ve.embeddings.position_embedding.weight,
+                              ve.pre_layrnorm.weight, ve.pre_layrnorm.bias, n, S, vc.layer_norm_eps).view(n * S, Dv)
+        for li in range(self._selected_layer_count()):
+            w = pk["clip"][li]
+            y = ops.layernorm(h, w["ln1"].weight, w["ln1"].bias, vc.layer_norm_eps)
+            qkv = ops.linear(y, w["w_qkv"], w["b_qkv"])
+            vt = ops.transpose_v(qkv[:, 2 * Dv:], S * 3 * Dv, 3 * Dv, n, S, H, hd)
+            att = torch.empty(n * S, Dv, device=h.device, dtype=BF16)
+            ops.attention(qkv, qkv[:, Dv:], vt, att, n, H, S, S, hd, (S * 3 * Dv, hd, 3 * Dv), (S * 3 * Dv, hd, 3 * Dv),
+                          (S * Dv, hd, Dv), None, causal=False, scale_mode=1, scale=hd ** -0.5)
+            h = ops.linear(att, w["w_out"], w["b_out"], residual=h)
+            y = ops.layernorm(h, w["ln2"].weight, w["ln2"].bias, vc.layer_norm_eps)
+            f = ops.linear(y, w["fc1"].weight, w["fc1"].bias, act="quick_gelu")
+            h = ops.linear(f, w["fc2"].weight, w["fc2"].bias, residual=h)
+        return h.view(n, S, Dv)
+
+    def encode_image(self, image_tensors: torch.Tensor) -> torch.Tensor:
+        """reference :146-158 -> [bs, num_patches, Dv] (CLS removed)."""
+        return self._clip_hidden(image_tensors)[:, 1:]
+
+    def encode_video(self, video_clip_tensors: torch.Tensor) -> torch.Tensor:
+        """reference :160-180 -> [bs, n_frm + num_patches, Dv]."""
+        b, c, t, hh, ww = video_clip_tensors.shape
+        frames = video_clip_tensors.permute(0, 2, 1, 3, 4).reshape(b * t, c, hh, ww)
+        h = self._clip_hidden(frames)                       # [b*t, P+1, Dv]
+        return ops.video_pool(h, b, t, h.shape[1] - 1, tok_pitch=h.shape[1], tok_off=1)
+
+    def _project(self, x: torch.Tensor) -> torch.Tensor:
+        vp = self.vision_projector
+        if isinstance(vp, Linear):
+            return ops.linear(x, vp.weight, vp.bias)
+        return ops.linear(ops.linear(x, vp[0].weight, vp[0].bias, act="gelu"), vp[2].weight, vp[2].bias)
+
+    # -- embedding + splice ----------------------------------------------------------------------------------
+    def embed_images_videos(self, input_ids=None, images=None, videos=None):
+        """reference :182-277.  Returns (input_ids, None) when S == 1, else (None, inputs_embeds [B,S,D])."""
+        if input_ids.shape[1] == 1:
+            return input_ids, None
+        ids = input_ids.contiguous()
+        mm = self.mm_token_ids
+        img_feat = vid_feat = None
+        img_tokens = img_pitch = img_off = 0
+        if images is not None:
+            h = self._clip_hidden(images)                   # [n, P+1, Dv]; the projector also runs on the CLS row,
+            img_feat = self._project(h.view(-1, h.shape[-1])).view(h.shape[0], h.shape[1], -1)   # which the splice skips
+            img_pitch, img_off, img_tokens = h.shape[1], 1, h.shape[1] - 1
+        if videos is not None:
+            v = self.encode_video(videos)
+            vid_feat = self._project(v.view(-1, v.shape[-1])).view(v.shape[0], v.shape[1], -1)
+        spans = None
+        if mm is not None:
+            spans = ops.mm_spans(ids, mm["IMG_START"], mm["IMG_END"], mm["VID_START"], mm["VID_END"])
+            if self.strict_checks:
+                sp = spans.cpu()
+                assert int(sp[:, 3].sum()) == 0, "Number of image/video start and end tokens should be the same."
+                if int((sp[:, 0] == 1).sum()) > (0 if img_feat is None else img_feat.shape[0]) or \
+                        int((sp[:, 0] == 2).sum()) > (0 if vid_feat is None else vid_feat.shape[0]):
+                    raise IndexError("fewer images/videos than samples that reference one")
+        emb = ops.embed_splice(ids, self.model.embed_tokens.weight, img_feat, vid_feat, spans, img_tokens, img_pitch, img_off)
+        return None, emb
+
+    # -- LLaMA ---------------------------------------------------------------------------------------------
+    def _rope_inv_freq(self, device):
+        if self._inv_freq is None or self._inv_freq.device != device:
+            hd = self.config.hidden_size // self.config.num_attention_heads
+            inv = 1.0 / (self.config.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))   # LlamaRotaryEmbedding
+            self._inv_freq = inv.to(device)
+        return self._inv_freq
+
+    def _llama(self, inputs_embeds, attention_mask, position_ids, output_hidden_states):
+        cfg = self.config
+        pk = self._pk()
+        B, S, D = inputs_embeds.shape
+        H = cfg.num_attention_heads
+        hd = D // H
+        dev = inputs_embeds.device
+        if position_ids is None:
+            pos = torch.arange(S, device=dev, dtype=torch.int64).repeat(B)
+        else:
+            pos = position_ids.to(torch.int64).expand(B, S).reshape(-1).contiguous()
+        key_mask = None if attention_mask is None else attention_mask.to(torch.int32).contiguous()
+        inv_freq = self._rope_inv_freq(dev)
+        x = inputs_embeds.reshape(B * S, D)
+        T = B * S
+        all_h = []
+        for w in pk["llama"]:
+            if output_hidden_states:
+                all_h.append(x.view(B, S, D))
+            y = ops.rmsnorm(x, w["ln1"], cfg.rms_norm_eps)
+            qkv = ops.linear(y, w["w_qkv"])
+            ops.rope_inplace(qkv, 3 * D, pos, inv_freq, T, 2 * H, hd)
+            vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
+            att = torch.empty(T, D, device=dev, dtype=BF16)
+            ops.attention(qkv, qkv[:, D:], vt, att, B, H, S, S, hd, (S * 3 * D, hd, 3 * D), (S * 3 * D, hd, 3 * D), (S * D, hd, D),
+                          key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
+            x = ops.linear(att, w["w_o"], residual=x)
+            y = ops.rmsnorm(x, w["ln2"], cfg.rms_norm_eps)
+            a = ops.linear(y, w["w_gu"], swiglu=True)
+            x = ops.linear(a, w["w_down"], residual=x)
+        x = ops.rmsnorm(x, self.model.norm.weight, cfg.rms_norm_eps)
+        last = x.view(B, S, D)
+        if output_hidden_states:
+            all_h.append(last)
+        return last, (tuple(all_h) if output_hidden_states else None)
+
+    def forward(self, input_ids: torch.LongTensor = None, attention_mask: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.LongTensor] = None, past_key_values: Optional[List[torch.FloatTensor]] = None,
+                inputs_embeds: Optional[torch.FloatTensor] = None, labels: Optional[torch.LongTensor] = None,
+                use_cache: Optional[bool] = None, output_attentions: Optional[bool] = None,
+                output_hidden_states: Optional[bool] = None, images: Optional[torch.FloatTensor] = None,
+                videos: Optional[torch.FloatTensor] = None, return_dict: Optional[bool] = None):
+        """reference :279-355 (same argument list)."""
+        if output_attentions:
+            raise NotImplementedError("attention probabilities never leave LDS on this path")
+        if past_key_values is not None:
+            raise NotImplementedError("incremental decoding is handled by generate(); forward() always runs a full prefill")
+        output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        if inputs_embeds is None:
+            ids, inputs_embeds = self.embed_images_videos(input_ids, images, videos)
+            if inputs_embeds is None:
+                inputs_embeds = ops.embed_splice(ids.contiguous(), self.model.embed_tokens.weight, None, None, None)
+        last, all_h = self._llama(inputs_embeds, attention_mask, position_ids, output_hidden_states)
+        logits = ops.linear(last, self.lm_head.weight)
+        loss = None
+        if labels is not None:
+            raise NotImplementedError("training loss is outside the forward hot path (SURVEY 8(a) row a16)")
+        if not return_dict:
+            out = (logits,) + ((all_h,) if all_h is not None else ())
+            return out
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=all_h, attentions=None)
+
+    __call__ = forward
+
+    def prepare_inputs_for_generation(self, input_ids=None, inputs_embeds=None, attention_mask=None, images=None, videos=None,
+                                      labels=None, past_key_values=None, **kwargs):
+        """reference :357-395."""
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        position_ids = kwargs.get("position_ids", None)
+        if attention_mask is not None and position_ids is None:
+            position_ids = attention_mask.long().cumsum(-1) - 1
+            position_ids.masked_fill_(attention_mask == 0, 1)
+            if past_key_values:
+                position_ids = position_ids[:, -1].unsqueeze(-1)
+        model_inputs = {"inputs_embeds": inputs_embeds} if inputs_embeds is not None and past_key_values is None else {"input_ids": input_ids}
+        model_inputs.update({"position_ids": position_ids, "past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"),
+                             "attention_mask": attention_mask, "images": images, "videos": videos})
+        return model_inputs
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, images=None, videos=None, attention_mask=None, max_new_tokens=32, do_sample=False,
+                 temperature=1.0, top_p=None, num_beams=1, no_repeat_ngram_size=None, stopping_criteria=None, eos_token_id=None,
+                 output_hidden_states=False, return_dict_in_generate=False, use_cache=None, **kwargs):
+        """Token-by-token decoding with the reference's no-KV-cache semantics (every step re-runs the multimodal prefill,
+        which is what the released checkpoints do: SURVEY 3.2).  Greedy (`do_sample=False`) is bit-reproducible; sampling
+        draws from torch's RNG on the softmax of logits/temperature with optional nucleus filtering."""
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not used by the reference callers (num_beams=1)")
+        seq = input_ids
+        steps_hidden = []
+        eos = eos_token_id
+        for _ in range(max_new_tokens):
+            mask = torch.ones_like(seq) if attention_mask is None else torch.cat(
+                [attention_mask, attention_mask.new_ones(seq.shape[0], seq.shape[1] - attention_mask.shape[1])], dim=1)
+            out = self.forward(input_ids=seq, attention_mask=mask, images=images, videos=videos,
+                               output_hidden_states=output_hidden_states)
+            if output_hidden_states:
+                steps_hidden.append(out.hidden_states)
+            logits = out.logits[:, -1].float()
+            if do_sample and temperature and temperature > 0:
+                probs = torch.softmax(logits / temperature, dim=-1)
+                if top_p is not None and top_p < 1.0:
+                    sp, si = probs.sort(dim=-1, descending=True)
+                    keep = (sp.cumsum(-1) - sp) < top_p
+                    sp = sp * keep
+                    probs = torch.zeros_like(probs).scatter_(-1, si, sp)
+                    probs = probs / probs.sum(-1, keepdim=True)
+                nxt = torch.multinomial(probs, 1)
+            else:
+                nxt = logits.argmax(-1, keepdim=True)
+            seq = torch.cat([seq, nxt], dim=1)
+            if eos is not None and bool((nxt == eos).all()):
+                break
+            if stopping_criteria is not None:
+                crit = stopping_criteria if isinstance(stopping_criteria, (list, tuple)) else [stopping_criteria]
+                if any(bool(c(seq, None)) for c in crit):
+                    break
+        if return_dict_in_generate:
+            return GenerateOutput(sequences=seq, hidden_states=tuple(steps_hidden) if output_hidden_states else None)
+        return seq

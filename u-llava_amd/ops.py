@@ -1,0 +1,200 @@
+"""Thin torch-tensor wrappers over the C-ABI (device pointers + sizes + current HIP stream).
+
+torch is used for device memory and streams only; every arithmetic op on the path is a HIP kernel from
+libullava_hip.so.  All activations are bf16, row-major, last dim contiguous.
+"""
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_RELU, EPI_RESID, EPI_SWIGLU, EPI_F32 = 1, 1 << 1, 2 << 1, 3 << 1, 8, 16, 32
+ACTS = {None: 0, "quick_gelu": EPI_QGELU, "gelu": EPI_GELU, "relu": EPI_RELU}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=BF16):
+    if not t.is_cuda:
+        raise RuntimeError(f"u-llava_amd: `{name}` must live on the GPU (no CPU path exists)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"u-llava_amd: `{name}` must be {dtype}, got {t.dtype}")
+    if t.dim() and t.stride(-1) != 1:
+        raise RuntimeError(f"u-llava_amd: `{name}` must be contiguous in its last dim")
+
+
+def _rows(t: torch.Tensor):
+    """View [*, D] as rows with one row stride; returns (rows, ld)."""
+    if t.dim() == 1:
+        return 1, t.shape[0]
+    if t.dim() == 2:
+        return t.shape[0], t.stride(0)
+    if not t.is_contiguous():
+        raise RuntimeError("u-llava_amd: >2-D operands must be contiguous")
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
+           residual: Optional[torch.Tensor] = None, swiglu: bool = False, out: Optional[torch.Tensor] = None,
+           out_f32: bool = False) -> torch.Tensor:
+    """y = epilogue(x @ w.T).  x [..., K]; w [N, K] (nn.Linear layout).  swiglu: w is the 16-row interleaved gate/up pack."""
+    _chk(x, "x"); _chk(w, "w")
+    M, ldx = _rows(x)
+    N, K = w.shape
+    lead = tuple(x.shape[:-1])
+    if x.shape[-1] != K:
+        raise RuntimeError(f"u-llava_amd.linear: K mismatch {x.shape[-1]} vs {K}")
+    if K % 64:
+        # The MFMA kernel consumes K in 64-wide DMA tiles.  Every real width on the path (1024, 1280, 4096, 5120,
+        # 11008, 256, 128, 2048, 64, patch K padded by im2col) is a multiple of 64; only the tiny test models are not.
+        # Zero-padding K is exact (adds 0*0 terms).
+        Kp = ((K + 63) // 64) * 64
+        x = torch.nn.functional.pad(x.reshape(M, K) if x.dim() != 2 else x, (0, Kp - K))
+        w = torch.nn.functional.pad(w, (0, Kp - K))
+        K, ldx = Kp, Kp
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else BF16)
+    flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | \
+        (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0)
+    if bias is not None:
+        _chk(bias, "bias")
+    ldr = 0
+    if residual is not None:
+        _chk(residual, "residual")
+        _, ldr = _rows(residual)
+    _, ldc = _rows(out)
+    _lib.call("ull_gemm_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags, _stream())
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, "x"); _chk(w, "w")
+    rows, ldx = _rows(x)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    _, ldy = _rows(out)
+    _lib.call("ull_rmsnorm_bf16", _p(x), ldx, _p(w), _p(out), ldy, rows, x.shape[-1], float(eps), _stream())
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, "x"); _chk(w, "w"); _chk(b, "b")
+    rows, ldx = _rows(x)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    _, ldy = _rows(out)
+    _lib.call("ull_layernorm_bf16", _p(x), ldx, _p(w), _p(b), _p(out), ldy, rows, x.shape[-1], float(eps), _stream())
+    return out
+
+
+def clip_embed_ln(patch: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, w: torch.Tensor, b: torch.Tensor, n_img: int, tokens: int,
+                  eps: float) -> torch.Tensor:
+    """patch [n_img*(tokens-1), D] -> pre-LN hidden states [n_img, tokens, D]."""
+    for t, n in ((patch, "patch"), (cls, "cls"), (pos, "pos"), (w, "w"), (b, "b")):
+        _chk(t, n)
+    D = patch.shape[-1]
+    out = torch.empty(n_img, tokens, D, device=patch.device, dtype=BF16)
+    _lib.call("ull_clip_embed_ln_bf16", _p(patch), patch.stride(0), _p(cls), _p(pos), _p(w), _p(b), _p(out), D, n_img, tokens, D,
+              float(eps), _stream())
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Sq: int, Sk: int, hd: int,
+              q_strides, k_strides, o_strides, key_mask: Optional[torch.Tensor] = None, causal: bool = False, scale_mode: int = 1,
+              scale: float = 1.0):
+    """q/k/out are views into larger buffers: strides = (batch, head, seq) in elements.  vt [B, H, hd, pitch] contiguous."""
+    _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt"); _chk(out, "out")
+    if key_mask is not None:
+        _chk(key_mask, "key_mask", torch.int32)
+    pitch = vt.shape[-1]
+    _lib.call("ull_attention_bf16", _p(q), *q_strides, _p(k), *k_strides, _p(vt), H * hd * pitch, hd * pitch, pitch, pitch, _p(out),
+              *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), _stream())
+    return out
+
+
+def rope_inplace(x: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_freq: torch.Tensor, tokens: int, n_heads: int, hd: int):
+    _chk(x, "x"); _chk(positions, "positions", torch.int64); _chk(inv_freq, "inv_freq", torch.float32)
+    _lib.call("ull_rope_inplace_bf16", _p(x), row_stride, _p(positions), _p(inv_freq), tokens, n_heads, hd, _stream())
+
+
+def transpose_v(v: torch.Tensor, v_bs: int, v_ss: int, B: int, S: int, H: int, hd: int, pitch: Optional[int] = None) -> torch.Tensor:
+    _chk(v, "v")
+    pitch = pitch or ((S + 63) // 64) * 64
+    vt = torch.empty(B, H, hd, pitch, device=v.device, dtype=BF16)
+    _lib.call("ull_transpose_v_bf16", _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, _stream())
+    return vt
+
+
+def im2col(img: torch.Tensor, ps: int, Kp: int) -> torch.Tensor:
+    _chk(img, "img")
+    if not img.is_contiguous():
+        raise RuntimeError("u-llava_amd.im2col: image batch must be contiguous NCHW")
+    n, C, H, W = img.shape
+    out = torch.empty(n * (H // ps) * (W // ps), Kp, device=img.device, dtype=BF16)
+    _lib.call("ull_im2col_bf16", _p(img), _p(out), n, C, H, W, ps, Kp, _stream())
+    return out
+
+
+def mm_spans(ids: torch.Tensor, img_start: int, img_end: int, vid_start: int, vid_end: int) -> torch.Tensor:
+    _chk(ids, "input_ids", torch.int64)
+    B, S = ids.shape
+    spans = torch.empty(B, 4, device=ids.device, dtype=torch.int32)
+    _lib.call("ull_mm_spans", _p(ids), B, S, img_start, img_end, vid_start, vid_end, _p(spans), _stream())
+    return spans
+
+
+def embed_splice(ids: torch.Tensor, table: torch.Tensor, img_feat: Optional[torch.Tensor], vid_feat: Optional[torch.Tensor],
+                 spans: Optional[torch.Tensor], img_tokens: int = 0, img_pitch: int = 0, img_off: int = 0) -> torch.Tensor:
+    """img_feat [n_img, img_pitch, D] (rows img_off..img_off+img_tokens of each image are spliced); vid_feat [n_vid, n_tok, D]."""
+    _chk(ids, "input_ids", torch.int64); _chk(table, "embed_tokens")
+    B, S = ids.shape
+    D = table.shape[1]
+    out = torch.empty(B, S, D, device=ids.device, dtype=BF16)
+    if img_feat is not None:
+        _chk(img_feat, "img_feat")
+        img_pitch = img_pitch or img_feat.shape[-2]
+        img_tokens = img_tokens or img_pitch - img_off
+    n_vid = 0
+    if vid_feat is not None:
+        _chk(vid_feat, "vid_feat")
+        n_vid = vid_feat.shape[-2]
+    _lib.call("ull_embed_splice_bf16", _p(ids), _p(table), _p(img_feat), img_tokens, img_pitch, img_off, _p(vid_feat), n_vid, _p(spans),
+              _p(out), B, S, D, _stream())
+    return out
+
+
+def video_pool(f: torch.Tensor, B: int, T: int, N: int, tok_pitch: Optional[int] = None, tok_off: int = 0) -> torch.Tensor:
+    """f [B*T, tok_pitch, D]; patches are tokens tok_off..tok_off+N of every frame."""
+    _chk(f, "f")
+    D = f.shape[-1]
+    out = torch.empty(B, T + N, D, device=f.device, dtype=BF16)
+    _lib.call("ull_video_pool_bf16", _p(f), _p(out), B, T, N, D, tok_pitch or N, tok_off, _stream())
+    return out
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    _chk(src, "src"); _chk(idx, "idx", torch.int64)
+    n, D = idx.numel(), src.shape[-1]
+    out = torch.empty(n, D, device=src.device, dtype=BF16)
+    if n:
+        _lib.call("ull_gather_rows_bf16", _p(src), src.stride(-2), _p(idx), _p(out), D, n, D, _stream())
+    return out
+
+
+def add_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """bf16(a + b) with b broadcast over leading rows (b has b_rows rows, a has k*b_rows)."""
+    _chk(a, "a"); _chk(b, "b")
+    D = a.shape[-1]
+    rows, b_rows = a.numel() // D, b.numel() // D
+    out = torch.empty_like(a)
+    _lib.call("ull_add_rows_bf16", _p(a), _p(b), _p(out), rows, D, b_rows, _stream())
+    return out
