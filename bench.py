@@ -108,11 +108,22 @@ def cpu_baseline(image_size, prompt_tokens):
     through 2 of 23 CLIP layers and 2 of 32 LLaMA layers + lm_head, extrapolated linearly in layer count."""
     from oracle import ullava_oracle as O
     W = importlib.import_module("u-llava_amd.weights")
-    torch.set_num_threads(os.cpu_count())
+    # pick the thread count on a probe matmul: 256-thread hosts are often slower with every hardware thread in use
+    probe_x, probe_w = torch.randn(643, 4096).to(torch.bfloat16), torch.randn(4096, 4096).to(torch.bfloat16)
+    best_n, best_t = 1, float("inf")
+    for n in sorted({min(os.cpu_count(), c) for c in (8, 32, 64, 128, os.cpu_count())}):
+        torch.set_num_threads(n)
+        torch.nn.functional.linear(probe_x, probe_w)
+        t0 = time.perf_counter()
+        torch.nn.functional.linear(probe_x, probe_w)
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best_n, best_t = n, dt
+    torch.set_num_threads(best_n)
     P = (image_size // 14) ** 2
     S = 2 + P + 1 + prompt_tokens
     D, I, V, Dv, Iv = 4096, 11008, 32011, 1024, 4096
-    nl, nv = 2, 2
+    nl, nv = 1, 1
     shapes = {"model.embed_tokens.weight": (V, D), "model.norm.weight": (D,), "lm_head.weight": (V, D),
               "vision_projector.weight": (D, Dv), "vision_projector.bias": (D,)}
     for l in range(nl):
@@ -140,7 +151,7 @@ def cpu_baseline(image_size, prompt_tokens):
     img = torch.randn(1, 3, image_size, image_size).to(torch.bfloat16)
     emb = torch.randn(1, S, D).to(torch.bfloat16)
 
-    def t(fn, n=2):
+    def t(fn, n=1):
         fn()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -155,10 +166,10 @@ def cpu_baseline(image_size, prompt_tokens):
         hs = O.llama_model(sd, lcfg0, emb)[0][-1]
         t_head = t(lambda: torch.nn.functional.linear(hs, sd["lm_head.weight"]))
     per_img = t_clip0 + (t_clip - t_clip0) / nv * 23 + t_llm0 + (t_llm - t_llm0) / nl * 32 + t_head
-    return dict(value=round(1.0 / per_img, 4), unit="images/sec", cores=os.cpu_count(), kind="port",
+    return dict(value=round(1.0 / per_img, 4), unit="images/sec", cores=best_n, kind="port",
                 sample=f"oracle (torch-CPU bf16 restatement of the reference path), 1 image {image_size}x{image_size} S={S}: "
                        f"{nv}/23 CLIP layers + {nl}/32 LLaMA-7B layers + lm_head timed, extrapolated linearly in layer count "
-                       f"({per_img:.2f} s/image)")
+                       f"({per_img:.2f} s/image; {best_n} of {os.cpu_count()} host threads, fastest on a probe matmul)")
 
 
 def main():

@@ -50,21 +50,22 @@ int ull_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b,
 int ull_clip_embed_ln_bf16(const void* patch, int64_t ldp, const void* cls, const void* pos, const void* w, const void* b, void* y,
                            int64_t ldy, int64_t n_img, int64_t tokens, int64_t D, float eps, void* stream);
 
-/* Attention with the score strip in LDS.  hf: llama eager_attention_forward (causal + key padding mask),
+/* Attention with the score rows in registers (Sk <= 1024).  hf: llama eager_attention_forward (causal + key padding mask),
  * clip eager_attention_forward (no mask); scale_mode 1 multiplies after the matmul like both.
- * Q/K: [B,H,S,hd] by strides, hd contiguous.  Vt: [B,H,hd,vt_len] key-contiguous, zero for keys >= Sk.
- * key_mask: int32 [B,Sk] (nonzero = attend) or NULL. */
+ * Q/K: [B,H,S,hd] by strides, hd contiguous.  Vt: [B,H,hd,vt_len] as written by ull_transpose_v_bf16 (vt_len % 64 == 0).
+ * key_mask: int32 [B,Sk] (nonzero = attend) or NULL.  zeros: >= 16 readable zero bytes (head-dim padding source). */
 int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs, int64_t k_ss,
                        const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O, int64_t o_bs, int64_t o_hs,
                        int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal,
-                       int scale_mode, float scale, void* stream);
+                       int scale_mode, float scale, const void* zeros, void* stream);
 
 /* hf: apply_rotary_pos_emb on n_heads consecutive heads (q heads then k heads of a fused QKV row), in place.
  * positions int64 [tokens]; inv_freq float32 [hd/2] computed by the host exactly as LlamaRotaryEmbedding does. */
 int ull_rope_inplace_bf16(void* x, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads,
                           int64_t hd, void* stream);
 
-/* V [B,S,H,hd] -> Vt [B,H,hd,pitch] with zeros for s in [S,pitch): the K-contiguous B-operand layout of P*V. */
+/* V [B,S,H,hd] -> Vt [B,H,hd,pitch] (pitch % 64 == 0), zeros for keys >= S, keys permuted inside each 32-key block
+ * (slot 8g+4a+r <- key 16a+4g+r): the K-contiguous A-operand layout of P*V matching the P register layout. */
 int ull_transpose_v_bf16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch,
                          void* stream);
 

@@ -31,11 +31,21 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def assert_close_bf16(a, b, ulps=2.0, floor=None, what=""):
-    """|a-b| <= ulps * 2^-8 * max(|b|, floor): agreement to a couple of bf16 ulps; `floor` defaults to 1% of max|b|."""
+def assert_close_bf16(a, b, ulps=2.0, floor=None, what="", outlier_frac=0.0, outlier_floor=None):
+    """See below; with `outlier_frac` > 0 that fraction of elements may miss the tight bound as long as ALL elements meet the
+    same bound evaluated with `outlier_floor` as the absolute floor (e.g. attention: one bf16 flip of a dominant probability
+    p ~ 0.5 moves the output by 2^-9 * max|v| whatever the output's own magnitude)."""
+    if outlier_frac > 0.0:
+        a_, b_ = a.detach().float().cpu(), b.detach().float().cpu()
+        fl = float(b_.abs().max()) * 0.02 if floor is None else floor
+        bad = (a_ - b_).abs() > ulps * 2.0 ** -7 * torch.maximum(b_.abs(), torch.full_like(b_, fl))
+        assert float(bad.float().mean()) <= outlier_frac, f"{what}: {int(bad.sum())}/{bad.numel()} elements beyond the tight bound"
+        return assert_close_bf16(a, b, ulps, outlier_floor, what)
+    """|a-b| <= ulps * 2^-7 * max(|b|, floor).  One bf16 ulp is between 2^-8 and 2^-7 of the value, so `ulps=1` admits a
+    single rounding flip anywhere; `floor` (default 2% of max|b|) sets the absolute tolerance for near-zero entries."""
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    fl = float(b.abs().max()) * 0.01 if floor is None else floor
-    tol = ulps * 2.0 ** -8 * torch.maximum(b.abs(), torch.full_like(b, fl))
+    fl = float(b.abs().max()) * 0.02 if floor is None else floor
+    tol = ulps * 2.0 ** -7 * torch.maximum(b.abs(), torch.full_like(b, fl))
     bad = (a - b).abs() > tol
     assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max|d|={float((a - b).abs().max()):.4g} " \
                                 f"max|ref|={float(b.abs().max()):.4g}"

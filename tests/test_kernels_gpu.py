@@ -90,9 +90,9 @@ def test_rmsnorm_layernorm(rows, D):
     ops = pkg("ops")
     x, w, b = _rand(rows, D, seed=20, scale=3.0), (1 + 0.1 * torch.randn(D)).to(BF), (0.1 * torch.randn(D)).to(BF)
     y = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6)
-    assert_close_bf16(y, O.rms_norm(x, w, 1e-6), ulps=1.01, what="rmsnorm")
+    assert_close_bf16(y, O.rms_norm(x, w, 1e-6), ulps=1.0, what="rmsnorm")
     y = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
-    assert_close_bf16(y, F.layer_norm(x, (D,), w, b, 1e-5), ulps=1.01, what="layernorm")
+    assert_close_bf16(y, F.layer_norm(x, (D,), w, b, 1e-5), ulps=1.0, what="layernorm")
 
 
 @pytest.mark.parametrize("hd,H", [(128, 4), (16, 4)])
@@ -110,8 +110,8 @@ def test_rope(hd, H):
     inv = (1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(DEV)
     ops.rope_inplace(g, 3 * D, pos.reshape(-1).to(DEV), inv, B * S, 2 * H, hd)
     out = g.cpu()
-    assert_close_bf16(out[:, :D].view(B, S, H, hd).transpose(1, 2), qr, ulps=1.01, what="rope q")
-    assert_close_bf16(out[:, D:2 * D].view(B, S, H, hd).transpose(1, 2), kr, ulps=1.01, what="rope k")
+    assert_close_bf16(out[:, :D].view(B, S, H, hd).transpose(1, 2), qr, ulps=1.0, what="rope q")
+    assert_close_bf16(out[:, D:2 * D].view(B, S, H, hd).transpose(1, 2), kr, ulps=1.0, what="rope k")
     assert torch.equal(out[:, 2 * D:], qkv[:, 2 * D:]), "v must be untouched"
 
 
@@ -147,8 +147,9 @@ def test_attention(B, H, S, hd, causal, masked):
     ref = _attn_ref(q, k, v, hd ** -0.5, causal, km).transpose(1, 2).reshape(B * S, D)
     g = qkv.to(DEV)
     vt = ops.transpose_v(g[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
-    assert torch.equal(vt[..., :S].cpu(), v.transpose(2, 3)), "V^T"
-    assert float(vt[..., S:].abs().sum()) == 0.0, "V^T padding must be zero"
+    vt_nat = vt.cpu()[..., ops.vt_unpermute_index(vt.shape[-1])]       # undo the 32-key block permutation
+    assert torch.equal(vt_nat[..., :S], v.transpose(2, 3)), "V^T"
+    assert float(vt_nat[..., S:].abs().sum()) == 0.0, "V^T padding must be zero"
     out = torch.empty(B * S, D, device=DEV, dtype=BF)
     ops.attention(g, g[:, D:], vt, out, B, H, S, S, hd, (S * 3 * D, hd, 3 * D), (S * 3 * D, hd, 3 * D), (S * D, hd, D),
                   None if km is None else km.to(DEV), causal=causal, scale_mode=1, scale=hd ** -0.5)
@@ -156,7 +157,7 @@ def test_attention(B, H, S, hd, causal, masked):
     if masked:      # rows of padded queries are don't-care in the reference's callers too; compare the valid ones
         valid = km.bool().reshape(-1)
         got, ref = got[valid], ref[valid]
-    assert_close_bf16(got, ref, ulps=3.0, what=f"attention S={S} hd={hd}")
+    assert_close_bf16(got, ref, ulps=2.0, what=f"attention S={S} hd={hd}", outlier_frac=1e-3, outlier_floor=float(v.float().abs().max()))
 
 
 def test_patch_embed_and_clip_pre_ln():
@@ -179,7 +180,7 @@ def test_patch_embed_and_clip_pre_ln():
     T = pe.shape[1] + 1
     h = ops.clip_embed_ln(patches, cls.to(DEV), pos.to(DEV), lw.to(DEV), lb.to(DEV), n, T, 1e-5)
     ref = F.layer_norm(torch.cat([cls.expand(n, 1, -1), patches.cpu().view(n, -1, Dv)], 1) + pos[None], (Dv,), lw, lb, 1e-5)
-    assert_close_bf16(h, ref, ulps=1.01, what="clip embeddings + pre-LN")
+    assert_close_bf16(h, ref, ulps=1.0, what="clip embeddings + pre-LN")
 
 
 def test_embed_splice_and_spans():
@@ -211,7 +212,7 @@ def test_video_pool():
     out = ops.video_pool(f.to(DEV), B, T, N, tok_pitch=N + 1, tok_off=1).cpu()
     ff = f[:, 1:].reshape(B, T, N, D)
     ref = torch.concat([ff.mean(dim=2), ff.mean(dim=1)], dim=1)
-    assert_close_bf16(out, ref, ulps=1.01, what="video pool")
+    assert_close_bf16(out, ref, ulps=1.0, what="video pool")
 
 
 def test_gather_and_add():

@@ -1,17 +1,19 @@
-// Attention for gfx950 with the score strip resident in LDS.
+// Attention for gfx950 with the whole score row resident in registers.
 //
 // The reference's attention (transformers eager path used by LlamaAttention / CLIPAttention, and SAM's
 // Attention modules) materialises   S = bf16(Q K^T) -> bf16(S * scale) -> (+mask) -> fp32 softmax -> bf16 P
-// -> bf16(P V)   as separate bf16 tensors in HBM.  On MI355X a 64-query strip of that matrix
-// (64 x 1024 bf16 = 128 KiB) fits in the CU's 160 KiB LDS, so this kernel keeps the *same rounding points*
-// as the reference but never writes S or P to HBM:
-//   phase 1  S strip  = K-tile x Q^T on MFMA (operands swapped so a lane owns 4 consecutive keys of one
-//            query -> one 8-byte LDS store), rounded/scaled/masked exactly like the eager graph;
-//   phase 2  exact row softmax in fp32 over the bf16 strip (true row max, no online rescaling), P
-//            written back over S as bf16;
-//   phase 3  O^T = V^T-tile x P^T on MFMA (V^T is produced K-contiguous by ull_transpose_v_bf16 so both
-//            operands are plain 16-byte LDS reads), 8-byte stores into [token, head*hd] row-major O.
-// Causal tiles beyond the diagonal are skipped in all three phases.
+// -> bf16(P V)   as separate bf16 tensors in HBM.  Sequences on this path are <= 1024 tokens, so one wave can
+// keep its 16 queries' complete score rows in VGPRs as packed bf16 (8 registers per 64 keys, 128 for 1024 keys;
+// gfx950 gives a wave 256 at two waves/SIMD).  The kernel therefore keeps the *same rounding points* as the
+// reference but S and P never leave the register file:
+//   phase 1  S = K-tile x Q^T on MFMA (operands swapped so a lane owns 4 consecutive keys of one query),
+//            rounded / scaled / masked exactly like the eager graph, packed to bf16 in registers;
+//   phase 2  exact row softmax in fp32 (true row max, no online rescaling), two shuffles per reduction;
+//   phase 3  O^T = V^T-tile x P^T on MFMA: the P registers ARE the B operand (V^T is stored with the matching
+//            key permutation by ull_transpose_v_bf16), 8-byte stores into [token, head*hd] row-major O.
+// K and V^T tiles stream HBM/L2 -> LDS by LDS-DMA, double-buffered through all three phases (the first V^T tile
+// lands while the softmax runs).  Causal tiles beyond a wave's diagonal are skipped.  All query tiles of one head are
+// placed on the same XCD so K/V are fetched into one L2 only.
 //
 // Also here: the QKV post-processing kernels (RoPE in place on q|k, V -> V^T with zero padding).
 #include "ull_common.h"
@@ -29,144 +31,216 @@ struct AttnArgs {
     int B, H, Sq, Sk, hd, vt_len;
     int causal, scale_mode;
     float scale;
-    int pitch;                          // strip row pitch in bytes (multiple of 16)
+    const bf16_t* zeros;                // >= 16 readable zero bytes (source of the head-dim padding chunks)
 };
 
-template <int HDP, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_strip_kernel(AttnArgs p) {
+// LDS-DMA of 64 x 16 B (see gemm_bf16.hip: issued via inline asm so hipcc does not drain it before the next ds_read).
+ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+// XOR swizzle of the 16-byte chunk index inside an LDS tile row (CPR chunks per row): chosen so that the 16 rows a
+// ds_read_b128 lane group touches land on 16 different bank slots.
+template <int CPR>
+ULL_DEV int swz(int row) { return CPR >= 16 ? (row & 15) : CPR == 8 ? (row & 7) : ((row >> 2) & 3); }
+
+// Block = 8 waves = 128 queries of one (batch, head); wave w owns queries q0+16w .. +16 against ALL keys.
+//   HDP : head dim padded to 32/64/128 (K-tile row = HDP bf16);  NT : max number of 64-key tiles held in registers.
+// Per lane the whole score/probability row segment lives in registers as packed bf16 (8 VGPRs per 64 keys).
+template <int HDP, int NT>
+__global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BQ = 16 * NW;
-    constexpr int KP = HDP * 2 + 16;     // K-tile row pitch (bytes): +16 breaks the power-of-two stride
-    constexpr int VP = KT * 2 + 16;      // V^T-tile row pitch (bytes)
-    constexpr int NKS = HDP / 32;        // MFMA k-steps over the head dim
-    constexpr int NDS = HDP / 16;        // 16-wide d sub-tiles of the output
+    constexpr int NWV = 8, BQ = 16 * NWV;
+    constexpr int CPR = HDP / 8;          // 16-byte chunks per K-tile row
+    constexpr int KROW = HDP * 2;         // K-tile row bytes
+    constexpr int NKS = HDP / 32, NDS = HDP / 16;
+    constexpr int TILE = 64 * KROW > HDP * 128 ? 64 * KROW : HDP * 128;   // bytes per tile buffer (K: 64 x HDP, V^T: HDP x 64)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * BQ;
-    char* strip = smem;
-    char* tile = smem + BQ * p.pitch;
-    const int koff = p.Sk - p.Sq;        // query i sees key j <= i + koff when causal
 
-    // ---- Q fragments (B operand: lane -> query fr, dims 8*fg.. of k-step ks) --------------------
+    // ---- block -> (head, query tile): all query tiles of a head run on ONE XCD (K/V stay in that L2) ----
+    const int nq = (p.Sq + BQ - 1) / BQ;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int head = (slot / nq) * 8 + xcd;
+    if (head >= p.B * p.H) return;
+    const int qt = nq - 1 - slot % nq;    // longest (most keys under the causal mask) first
+    const int b = head / p.H, h = head % p.H;
+    const int q0 = qt * BQ;
+    const int koff = p.Sk - p.Sq;
+
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    char* maskb = smem + 2 * TILE;        // one byte per key: 1 attend, 0 masked (finfo.min), 2 out of range (-inf)
+
+    int kend = p.Sk;
+    if (p.causal) kend = min(p.Sk, q0 + BQ + koff);
+    if (kend < 1) kend = 1;
+    const int nkt = (kend + KT - 1) / KT;                       // tiles this block streams
+    int kend_w = p.Sk;
+    if (p.causal) kend_w = min(p.Sk, q0 + wave * 16 + 16 + koff);
+    const int nkt_w = (q0 + wave * 16 < p.Sq) ? max(1, (kend_w + KT - 1) / KT) : 0;   // tiles this wave computes on
+
+    // ---- Q fragments + key-mask bytes (ordinary loads; drained before any DMA is issued) ---------------
     uint4 qf[NKS];
+    const int qi = q0 + wave * 16 + fr;
     {
-        const int qi = q0 + wave * 16 + fr;
         const bf16_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
             qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
         }
+        for (int j = tid; j < nkt * KT; j += 512) {
+            unsigned char m = 2;
+            if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
+            maskb[j] = m;
+        }
     }
-    int kend = p.Sk;
-    if (p.causal) kend = min(p.Sk, q0 + BQ + koff);
-    if (kend < 1) kend = 1;
-    const int nkt = (kend + KT - 1) / KT;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- phase 1: score strip -------------------------------------------------------------
     const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        for (int i = tid; i < KT * (HDP / 8); i += NW * 64) {
-            const int row = i / (HDP / 8), ch = i % (HDP / 8);
-            const int key = kt * KT + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (key < p.Sk && ch * 8 < p.hd) v = *(const uint4*)(kbase + (long)key * p.k_ss + ch * 8);
-            *(uint4*)(tile + row * KP + ch * 16) = v;
-        }
-        __syncthreads();
-        const int qi = q0 + wave * 16 + fr;
-#pragma unroll
-        for (int ns = 0; ns < 4; ++ns) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const uint4 kf = *(const uint4*)(tile + (ns * 16 + fr) * KP + (ks * 4 + fg) * 16);
-                acc = mfma16(kf, qf[ks], acc);
-            }
-            // acc[r] = S[key = kt*64 + ns*16 + 4*fg + r][query = fr]
-            uint16_t o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = kt * KT + ns * 16 + fg * 4 + r;
-                float s = rbf(acc[r]);
-                if (p.scale_mode == 1) s = rbf(s * p.scale);
-                else if (p.scale_mode == 2) s = rbf(s / p.scale);
-                bool allowed = true;
-                if (p.causal) allowed = j <= qi + koff;
-                if (allowed && p.key_mask != nullptr && j < p.Sk) allowed = p.key_mask[(long)b * p.Sk + j] != 0;
-                o[r] = (j >= p.Sk) ? BF16_NEG_INF : (allowed ? f2bf(s) : BF16_MIN);
-            }
-            uint2 pk;
-            pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-            pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-            *(uint2*)(strip + (wave * 16 + fr) * p.pitch + (kt * KT + ns * 16 + fg * 4) * 2) = pk;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 2: row softmax (4 lanes per row, this wave's 16 rows) ------------------------------
-    {
-        const int row = lane >> 2, sub = lane & 3;
-        char* rp = strip + (wave * 16 + row) * p.pitch;
-        const int nch = nkt * (KT / 8);
-        float m = -INFINITY;
-        for (int c = sub; c < nch; c += 4) {
-            float f[8];
-            unpack8(*(const uint4*)(rp + c * 16), f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) m = fmaxf(m, f[j]);
-        }
-        m = group_max(m, 4);
-        float sum = 0.f;
-        for (int c = sub; c < nch; c += 4) {
-            float f[8];
-            unpack8(*(const uint4*)(rp + c * 16), f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum += __expf(f[j] - m);
-        }
-        sum = group_sum(sum, 4);
-        const float inv = 1.0f / sum;
-        for (int c = sub; c < nch; c += 4) {
-            float f[8];
-            unpack8(*(const uint4*)(rp + c * 16), f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = __expf(f[j] - m) * inv;
-            *(uint4*)(rp + c * 16) = pack8(f);
-        }
-    }
-
-    // ---- phase 3: O^T = V^T P^T --------------------------------------------------------------
-    f32x4_t oacc[NDS];
-#pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        for (int i = tid; i < p.hd * (KT / 8); i += NW * 64) {
-            const int d = i >> 3, ch = i & 7;
-            const int key0 = kt * KT + ch * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (key0 + 8 <= p.vt_len) v = *(const uint4*)(vbase + (long)d * p.vt_ds + key0);
-            *(uint4*)(tile + d * VP + ch * 16) = v;
+    // stream step s: s < nkt -> K tile s ; else V^T tile s - nkt.   Buffer = s & 1.
+    auto issue = [&](int s) {
+        const uint32_t dst = lds_base + (s & 1) * TILE;
+        if (s < nkt) {
+            const int kt = s;
+#pragma unroll
+            for (int i0 = 0; i0 < CPR; i0 += NWV) {
+                const int i = i0 + wave;                        // one 1-KiB piece = 64/CPR rows
+                if (i < CPR) {
+                    const int row = i * (64 / CPR) + lane / CPR;
+                    const int c = (lane % CPR) ^ swz<CPR>(row);
+                    const int key = min(kt * KT + row, p.Sk - 1);
+                    const bf16_t* src = (c * 8 < p.hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                    glds16(src, dst + i * 1024);
+                }
+            }
+        } else {
+            const int kt = s - nkt;
+            const int npieces = p.hd >> 3;                      // 8 V^T rows (head dims) per 1-KiB piece
+#pragma unroll
+            for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
+                const int i = i0 + wave;
+                if (i < npieces) {
+                    const int row = i * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ (row & 7);
+                    glds16(vbase + (long)row * p.vt_ds + kt * KT + c * 8, dst + i * 1024);
+                }
+            }
         }
-        __syncthreads();
+    };
+
+    uint32_t sp[NT][8];                   // [tile][2*ns + half]: bf16 pairs for keys kt*64 + ns*16 + 4*fg + {0,1 | 2,3}
+    issue(0);
+
+    // ---- phase 1: S = bf16(K Q^T) (+scale, +mask), kept in registers -----------------------------------
+#pragma clang loop unroll(full)
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < nkt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(kt + 1);                                       // next K tile, or V^T tile 0
+            if (kt < nkt_w) {
+                const char* tb = smem + (kt & 1) * TILE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint4 pf = *(const uint4*)(strip + (wave * 16 + fr) * p.pitch + (kt * KT + kk * 32 + fg * 8) * 2);
+                for (int ns = 0; ns < 4; ++ns) {
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                    const int row = ns * 16 + fr;
 #pragma unroll
-            for (int ds = 0; ds < NDS; ++ds) {
-                if (ds * 16 < p.hd) {
-                    const uint4 vf = *(const uint4*)(tile + (ds * 16 + fr) * VP + (kk * 4 + fg) * 16);
-                    oacc[ds] = mfma16(vf, pf, oacc[ds]);
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
+                        acc = mfma16(kf, qf[ks], acc);
+                    }
+                    const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
+                    uint16_t o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = kt * KT + ns * 16 + fg * 4 + r;
+                        float sv = rbf(acc[r]);
+                        if (p.scale_mode == 1) sv = rbf(sv * p.scale);
+                        else if (p.scale_mode == 2) sv = rbf(sv / p.scale);
+                        const uint32_t mb = (mk >> (8 * r)) & 0xff;
+                        const bool allowed = (mb == 1) && (!p.causal || j <= qi + koff);
+                        o[r] = (mb == 2) ? BF16_NEG_INF : (allowed ? f2bf(sv) : BF16_MIN);
+                    }
+                    sp[kt][ns * 2] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+                    sp[kt][ns * 2 + 1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
                 }
             }
         }
     }
-    // oacc[ds][r] = O[d = ds*16 + 4*fg + r][query = fr]
-    const int qi = q0 + wave * 16 + fr;
+
+    // ---- phase 2: exact fp32 row softmax over the bf16 scores, P = bf16(softmax) (registers only) --------
+    {
+        float m = -INFINITY;
+#pragma clang loop unroll(full)
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < nkt_w) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    m = fmaxf(m, __uint_as_float(sp[kt][i] << 16));
+                    m = fmaxf(m, __uint_as_float(sp[kt][i] & 0xffff0000u));
+                }
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma clang loop unroll(full)
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < nkt_w) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    sum += __expf(__uint_as_float(sp[kt][i] << 16) - m);
+                    sum += __expf(__uint_as_float(sp[kt][i] & 0xffff0000u) - m);
+                }
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma clang loop unroll(full)
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < nkt_w) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float lo = __expf(__uint_as_float(sp[kt][i] << 16) - m) * inv;
+                    const float hi = __expf(__uint_as_float(sp[kt][i] & 0xffff0000u) - m) * inv;
+                    sp[kt][i] = pack2bf(lo, hi);
+                }
+            }
+    }
+
+    // ---- phase 3: O^T = V^T P^T; P feeds the MFMA B operand straight from registers ---------------------
+    // V^T tiles are stored with keys permuted inside every 32-key block (slot 8g+4a+r <- key 16a+4g+r, see
+    // transpose_v_kernel) so that the k-slot <-> key map of the A operand equals the one the P registers already have.
+    f32x4_t oacc[NDS];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma clang loop unroll(full)
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt < nkt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nkt) issue(nkt + kt + 1);
+            if (kt < nkt_w) {
+                const char* tb = smem + ((nkt + kt) & 1) * TILE;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
+#pragma unroll
+                    for (int ds = 0; ds < NDS; ++ds) {
+                        if (ds * 16 < p.hd) {
+                            const int row = ds * 16 + fr;
+                            const uint4 vf = *(const uint4*)(tb + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                            oacc[ds] = mfma16(vf, pf, oacc[ds]);
+                        }
+                    }
+                }
+            }
+        }
+    }
     if (qi < p.Sq) {
         bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
@@ -216,8 +290,10 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(bf16_t* __restrict__ 
     }
 }
 
-// V [B, S, H, hd] (token stride row_stride, heads contiguous) -> Vt [B, H, hd, pitch], zero-filled for
-// s in [S, pitch).  64(s) x 64(d) tiles through LDS.
+// V [B, S, H, hd] (token stride v_ss, heads contiguous) -> Vt [B, H, hd, pitch], zero-filled for keys >= S.
+// Inside every 32-key block the keys are stored permuted: slot 8g + 4a + r holds key 16a + 4g + r (a<2, g<4, r<4),
+// which is the (lane group g, element j = 4a + r) <-> key map that the attention kernel's probability registers
+// have after the swapped QK^T MFMA -- so P*V needs no cross-lane movement.  64(s) x 64(d) tiles through LDS.
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, long v_bs, long v_ss, bf16_t* __restrict__ vt, int S,
                                                           int H, int hd, int pitch) {
     __shared__ bf16_t t[64][66];
@@ -234,25 +310,32 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
     bf16_t* op = vt + ((long)b * H + h) * hd * pitch;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int d = i >> 6, s = i & 63;
-        if (d0 + d < hd && s0 + s < pitch) op[(long)(d0 + d) * pitch + s0 + s] = t[s][d];
+        // output slot s (within this 64-wide tile) takes the key at the permuted position
+        const int w = s & 31, key = (s & 32) + 16 * ((w >> 2) & 1) + 4 * (w >> 3) + (w & 3);
+        if (d0 + d < hd && s0 + s < pitch) op[(long)(d0 + d) * pitch + s0 + s] = t[key][d];
     }
 }
 
-template <int HDP>
+template <int HDP, int NT>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
-    constexpr int NW = 4;
-    constexpr int BQ = 16 * NW;
-    constexpr int tile_bytes = (KT * (HDP * 2 + 16) > HDP * (KT * 2 + 16)) ? KT * (HDP * 2 + 16) : HDP * (KT * 2 + 16);
-    const int lds = BQ * a.pitch + tile_bytes;
-    if (lds > 160 * 1024) return ULL_ERR_LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_strip_kernel<HDP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    const dim3 grid((a.Sq + BQ - 1) / BQ, a.H, a.B);
-    hipLaunchKernelGGL((attn_strip_kernel<HDP, NW>), grid, dim3(NW * 64), lds, st, a);
+    constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
+    const int lds = 2 * TILE + NT * KT;
+    const int nq = (a.Sq + 127) / 128;
+    const int nheads = a.B * a.H;
+    const dim3 grid(((nheads + 7) / 8) * 8 * nq);
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT>), grid, dim3(512), lds, st, a);
     return ull_check_launch();
+}
+
+template <int HDP>
+int dispatch_nt(const AttnArgs& a, hipStream_t st) {
+    const int nt = (a.Sk + KT - 1) / KT;
+    if constexpr (HDP < 128) {          // (the <128, 5> instantiation spills; hd=128 starts at the 11-tile variant)
+        if (nt <= 5) return launch_attn<HDP, 5>(a, st);
+    }
+    if (nt <= 11) return launch_attn<HDP, 11>(a, st);
+    if (nt <= 16) return launch_attn<HDP, 16>(a, st);
+    return ULL_ERR_LDS;      // > 1024 keys do not fit the register-resident score row
 }
 
 }  // namespace
@@ -263,9 +346,9 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs,
                                   int64_t k_ss, const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O,
                                   int64_t o_bs, int64_t o_hs, int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq,
-                                  int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, void* stream) {
-    if (!Q || !K || !Vt || !O || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return ULL_ERR_ARG;
-    if (hd <= 0 || hd > 128 || (hd & 15) || (vt_len & 7) || vt_len < ((Sk + 7) & ~7)) return ULL_ERR_SHAPE;
+                                  int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, const void* zeros, void* stream) {
+    if (!Q || !K || !Vt || !O || !zeros || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return ULL_ERR_ARG;
+    if (hd <= 0 || hd > 128 || (hd & 15) || (vt_len & 63) || vt_len < ((Sk + 63) & ~63)) return ULL_ERR_SHAPE;
     if ((q_ss & 7) || (k_ss & 7) || (vt_ds & 7) || (q_hs & 7) || (k_hs & 7) || (q_bs & 7) || (k_bs & 7) || (vt_hs & 7) || (vt_bs & 7) ||
         (o_ss & 3) || (o_hs & 3) || (o_bs & 3))
         return ULL_ERR_SHAPE;
@@ -276,13 +359,11 @@ extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int
     a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_hs = o_hs; a.o_ss = o_ss;
     a.B = (int)B; a.H = (int)H; a.Sq = (int)Sq; a.Sk = (int)Sk; a.hd = (int)hd; a.vt_len = (int)vt_len;
     a.causal = causal; a.scale_mode = scale_mode; a.scale = scale;
-    const int lmax = (int)((Sk + KT - 1) / KT) * KT;
-    a.pitch = lmax * 2 + 16;
+    a.zeros = (const bf16_t*)zeros;
     hipStream_t st = (hipStream_t)stream;
-    if (hd <= 32) return launch_attn<32>(a, st);
-    if (hd <= 64) return launch_attn<64>(a, st);
-    if (hd <= 96) return launch_attn<96>(a, st);
-    return launch_attn<128>(a, st);
+    if (hd <= 32) return dispatch_nt<32>(a, st);
+    if (hd <= 64) return dispatch_nt<64>(a, st);
+    return dispatch_nt<128>(a, st);
 }
 
 // x: first of `n_heads` consecutive heads (q heads then k heads of a fused QKV row); positions int64 [tokens];
@@ -300,7 +381,7 @@ extern "C" int ull_rope_inplace_bf16(void* x, int64_t row_stride, const void* po
 extern "C" int ull_transpose_v_bf16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd,
                                     int64_t pitch, void* stream) {
     if (!v || !vt || B <= 0 || S <= 0) return ULL_ERR_ARG;
-    if (pitch < S || (pitch & 7)) return ULL_ERR_SHAPE;
+    if (pitch < S || (pitch & 63)) return ULL_ERR_SHAPE;
     const dim3 grid((unsigned)((pitch + 63) / 64), (unsigned)((hd + 63) / 64), (unsigned)(B * H));
     hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v, v_bs, v_ss, (bf16_t*)vt, (int)S, (int)H,
                        (int)hd, (int)pitch);

@@ -14,6 +14,24 @@ EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_RELU, EPI_RESID, EPI_SWIGLU, EPI_F32 = 1, 1 <
 ACTS = {None: 0, "quick_gelu": EPI_QGELU, "gelu": EPI_GELU, "relu": EPI_RELU}
 
 
+_ZEROS = {}
+
+
+def _zeros(device):
+    z = _ZEROS.get(device)
+    if z is None:
+        z = _ZEROS[device] = torch.zeros(256, device=device, dtype=BF16)
+    return z
+
+
+def vt_unpermute_index(pitch: int) -> torch.Tensor:
+    """index so that vt[..., idx] is in natural key order (inverse of the 32-key block permutation of transpose_v)."""
+    key = torch.arange(pitch)
+    w = key % 32
+    a, g, r = w // 16, (w % 16) // 4, w % 4
+    return (key // 32) * 32 + 8 * g + 4 * a + r
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -117,7 +135,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
         _chk(key_mask, "key_mask", torch.int32)
     pitch = vt.shape[-1]
     _lib.call("ull_attention_bf16", _p(q), *q_strides, _p(k), *k_strides, _p(vt), H * hd * pitch, hd * pitch, pitch, pitch, _p(out),
-              *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), _stream())
+              *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), _zeros(q.device).data_ptr(), _stream())
     return out
 
 
