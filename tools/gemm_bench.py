@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""GEMM microbench on the LLaMA-7B / CLIP shapes of the C4 workload (M = 32 x 643 tokens). Random operands."""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ops = importlib.import_module("u-llava_amd.ops")
+dev = "cuda:0"
+T = int(os.environ.get("TOKENS", 20576))
+shapes = [("qkv", T, 12288, 4096, False), ("o", T, 4096, 4096, False), ("gateup", T, 22016, 4096, True), ("down", T, 4096, 11008, False),
+          ("lm_head", T, 32011, 4096, False), ("clip_qkv", 32 * 577, 3072, 1024, False), ("clip_fc1", 32 * 577, 4096, 1024, False),
+          ("clip_fc2", 32 * 577, 1024, 4096, False), ("sq4096", 4096, 4096, 4096, False), ("sq8192", 8192, 8192, 8192, False)]
+g = torch.Generator(device=dev).manual_seed(0)
+tot_f = tot_t = 0
+for name, M, N, K, sw in shapes:
+    x = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)
+    out = torch.empty(M, N // 2 if sw else N, device=dev, dtype=torch.bfloat16)
+    for _ in range(2):
+        ops.linear(x, w, swiglu=sw, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    it = 10
+    for _ in range(it):
+        ops.linear(x, w, swiglu=sw, out=out)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / it
+    fl = 2.0 * M * N * K
+    if name in ("qkv", "o", "gateup", "down"):
+        tot_f += fl
+        tot_t += ms
+    print(f"{name:10s} M={M:6d} N={N:6d} K={K:6d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s")
+print(f"llama layer GEMMs: {tot_t:.3f} ms  {tot_f / tot_t / 1e9:.1f} TF/s")

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libullava_hip.so")
+LIB_PATH = os.environ.get("ULL_LIB_PATH", os.path.join(_HERE, "csrc", "libullava_hip.so"))   # override: kernel A/B experiments only
 
 _i64, _i32, _f32, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 

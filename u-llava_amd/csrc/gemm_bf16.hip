@@ -21,6 +21,7 @@
 //   * 1-D grid with XCD-aware remap (block b runs on XCD b%8; each XCD gets a contiguous chunk of the
 //     tile space, walked in GROUP_M-row groups so co-resident blocks share X / W panels in that L2).
 #include "ull_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -231,6 +232,230 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
     }
 }
 
+
+// =============================================================================================================
+// Large-shape kernel: 256x256 block tile, BK = 64, two 64-KiB LDS slots (128 KiB), 512 threads = 8 waves (2 x 4),
+// 128(m) x 64(n) per wave = 32 accumulators (128 VGPR).  Measured motivation (profiles/r01_gemm_notes.md): ablating the
+// MFMAs out of either kernel leaves the run time almost unchanged -- the GEMM is bound by the HBM/L2 -> LDS staging path
+// (~85 GB/s per CU peak through the vector L1, ~0.2 us L2-hit and ~1-2 us first-touch latency), so this kernel doubles
+// the FLOPs per staged byte (128 vs 64 FLOP/B) and keeps a whole K-step of DMA in flight behind the MFMAs.
+//   * MFMA fragments are double-buffered in REGISTERS at half-K-step granularity: while the MFMAs of (tile k, half h)
+//     issue, the fragments of the next half are read from LDS.  Tile k therefore lives in registers while tile k+1 is
+//     being read from one LDS slot and tile k+2 is being DMA'd into the other: two slots give a prefetch distance of 2.
+//   * one barrier per BK=64 step; the DMA of tile k+2 is issued right after it and is waited for a full step later.
+//   * the steady-state loop is branch-free (a conditional ds_read block makes hipcc join paths with lgkmcnt(0) in front
+//     of the MFMAs), and sched_group_barrier pins the 1-read : 2-MFMA software pipeline hipcc would otherwise collapse.
+namespace big {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int OP_BYTES = BM * BK * 2;             // 32 KiB per operand per slot
+constexpr int SLOT_BYTES = 2 * OP_BYTES;          // 64 KiB
+constexpr int LDS_BYTES = 2 * SLOT_BYTES;         // 128 KiB -> one block (8 waves) per CU
+
+struct Frags { uint4 w[4]; uint4 x[8]; };
+
+template <bool SWIGLU>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+    const int nwg = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int per_group = GROUP_M * p.nbn;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(p.nbm - first_m, GROUP_M);
+    const int bm = first_m + (bid % per_group) % gsz;
+    const int bn = (bid % per_group) / gsz;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // DMA: a 1-KiB piece = 8 rows x 128 B; wave w stages pieces 4w..4w+3 of X and of W.
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const bf16_t* xsrc[4];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + srow;
+        xsrc[i] = p.X + (long)min(m0 + r, p.M - 1) * p.ldx + schunk * 8;
+        wsrc[i] = p.W + (long)min(n0 + r, p.N - 1) * p.ldw + schunk * 8;
+    }
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    const uint32_t piece_off = wave * 4 * 1024;
+    auto stage = [&](int kt) {
+        const uint32_t bx = lds_base + (kt & 1) * SLOT_BYTES + piece_off;
+        const long ko = (long)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(xsrc[i] + ko, bx + i * 1024);
+            glds16(wsrc[i] + ko, bx + OP_BYTES + i * 1024);
+        }
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int swz[2];
+    swz[0] = ((0 + fg) ^ (lane & 7)) << 4;
+    swz[1] = ((4 + fg) ^ (lane & 7)) << 4;
+    const int xoff = (wm * 128 + fr) * (BK * 2);
+    const int woff = OP_BYTES + (wn * 64 + fr) * (BK * 2);
+    auto read_frags = [&](int kt, int kk, Frags& f) {
+        const char* base = smem + (kt & 1) * SLOT_BYTES + swz[kk];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.w[i] = *(const uint4*)(base + woff + i * 16 * (BK * 2));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.x[j] = *(const uint4*)(base + xoff + j * 16 * (BK * 2));
+    };
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const Frags& f) {
+#if !defined(ULL_ABL_NOMMA)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(f.w[i], f.x[j], acc[i][j]);
+#else
+        for (int i_ = 0; i_ < 4; ++i_) asm volatile("" :: "v"(f.w[i_].x), "v"(f.w[i_].w));
+        for (int j_ = 0; j_ < 8; ++j_) asm volatile("" :: "v"(f.x[j_].x), "v"(f.x[j_].w));
+#endif
+    };
+    // the 12 fragment reads of the NEXT half step are issued up front, one per two MFMAs of the current half (left alone,
+    // hipcc sinks them behind ~22 MFMAs to save registers and then stalls on them)
+    auto pipeline_hint = [&]() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    };
+
+    const int nk = p.K / BK;                          // >= 2 (host dispatch)
+    stage(0);
+    stage(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed, tile 1 in flight
+    __builtin_amdgcn_s_barrier();
+    Frags fa, fb;                                     // fa: half 0 of the current tile, fb: half 1
+    read_frags(0, 0, fa);
+    for (int kt = 0; kt < nk - 2; ++kt) {
+        read_frags(kt, 1, fb);
+        mma(fa);
+        pipeline_hint();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed (issued a full step ago); my reads of tile kt done
+        __builtin_amdgcn_s_barrier();                 // tile kt+1 visible to all; slot of tile kt free
+#if !defined(ULL_ABL_NODMA)
+        stage(kt + 2);
+#endif
+        read_frags(kt + 1, 0, fa);
+        mma(fb);
+        pipeline_hint();
+    }
+    {   // kt = nk - 2: nothing left to prefetch
+        const int kt = nk - 2;
+        read_frags(kt, 1, fb);
+        mma(fa);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(kt + 1, 0, fa);
+        mma(fb);
+        read_frags(kt + 1, 1, fb);
+        mma(fa);
+        mma(fb);
+    }
+
+    // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
+    const int flags = p.flags;
+    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+    const bool out_f32 = flags & EPI_OUT_F32;
+    const int n_out_total = SWIGLU ? p.N / 2 : p.N;
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((n_out_total & 3) == 0) && (!(flags & EPI_RESID) || (p.ldr & 3) == 0);
+    auto emit = [&](int m, int n, float (&v)[4]) {
+        if (n >= n_out_total) return;
+        if (flags & EPI_RESID) {
+            const bf16_t* rp = p.R + (long)m * p.ldr + n;
+            if (vec_ok) {
+                const uint2 rv = *(const uint2*)rp;
+                v[0] = rbf(bf2f((bf16_t)(rv.x & 0xffff)) + v[0]);
+                v[1] = rbf(bf2f((bf16_t)(rv.x >> 16)) + v[1]);
+                v[2] = rbf(bf2f((bf16_t)(rv.y & 0xffff)) + v[2]);
+                v[3] = rbf(bf2f((bf16_t)(rv.y >> 16)) + v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out_total) v[r] = rbf(bf2f(rp[r]) + v[r]);
+            }
+        }
+        if (out_f32) {
+            float* cp = (float*)p.C + (long)m * p.ldc + n;
+            if (vec_ok) *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out_total) cp[r] = v[r];
+            }
+        } else {
+            bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
+            if (vec_ok) {
+                uint2 o;
+                o.x = pack2bf(v[0], v[1]);
+                o.y = pack2bf(v[2], v[3]);
+                *(uint2*)cp = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out_total) cp[r] = f2bf(v[r]);
+            }
+        }
+    };
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 8; ++j) {
+        const int m = m0 + wm * 128 + j * 16 + fr;
+        if (m < p.M) {
+            if constexpr (SWIGLU) {
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    const int n = (n0 + wn * 64) / 2 + ip * 16 + fg * 4;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = rbf(acc[2 * ip][j][r]);
+                        const float u = rbf(acc[2 * ip + 1][j][r]);
+                        v[r] = rbf(rbf(act_silu(g)) * u);
+                    }
+                    emit(m, n, v);
+                }
+            } else {
+#pragma clang loop unroll(full)
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + wn * 64 + i * 16 + fg * 4;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = acc[i][j][r];
+                        if ((flags & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
+                        if (!out_f32 || act || (flags & EPI_RESID)) t = rbf(t);
+                        if (act == 1) t = act_quick_gelu_bf16(t);
+                        else if (act == 2) t = rbf(act_gelu_erf(t));
+                        else if (act == 3) t = fmaxf(t, 0.f);
+                        v[r] = t;
+                    }
+                    emit(m, n, v);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace big
+
 }  // namespace
 
 extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -247,8 +472,21 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
     a.bias = (const bf16_t*)bias; a.R = (const bf16_t*)R;
     a.ldx = ldx; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags;
-    a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     static bool attr_set = false;
+    static const bool force_small = getenv("ULL_GEMM_SMALL") != nullptr;
+    if (!force_small && M >= 1024 && N >= 512 && K >= 128) {   // nk >= 2
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+        }
+        a.nbm = (int)((M + big::BM - 1) / big::BM); a.nbn = (int)((N + big::BN - 1) / big::BN);
+        if (flags & EPI_SWIGLU)
+            hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(a.nbm * a.nbn), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(a.nbm * a.nbn), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+        return ull_check_launch();
+    }
+    a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
