@@ -50,14 +50,18 @@ int ull_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b,
 int ull_clip_embed_ln_bf16(const void* patch, int64_t ldp, const void* cls, const void* pos, const void* w, const void* b, void* y,
                            int64_t ldy, int64_t n_img, int64_t tokens, int64_t D, float eps, void* stream);
 
-/* Attention with the score rows in registers (Sk <= 1024).  hf: llama eager_attention_forward (causal + key padding mask),
- * clip eager_attention_forward (no mask); scale_mode 1 multiplies after the matmul like both.
+/* Attention.  Sk <= 1024: score rows stay in registers; larger Sk: two-pass streaming kernel with the same rounding points.
+ * hf: llama eager_attention_forward (causal + key padding mask), clip eager_attention_forward (no mask): scale_mode 1
+ * multiplies after the matmul like both.  SAM encoder (image_encoder.py:235-260,354-392): q_scale = hd^-0.5 applied to Q
+ * as a bf16 tensor op, scale_mode 0, rel_h [B*H,Sq,rel_kh] / rel_w [B*H,Sq,rel_kw] added to the bf16 scores one after the
+ * other.  SAM decoder (transformer.py:220-242): scale_mode 2 divides by sqrt(hd).
  * Q/K: [B,H,S,hd] by strides, hd contiguous.  Vt: [B,H,hd,vt_len] as written by ull_transpose_v_bf16 (vt_len % 64 == 0).
  * key_mask: int32 [B,Sk] (nonzero = attend) or NULL.  zeros: >= 16 readable zero bytes (head-dim padding source). */
 int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs, int64_t k_ss,
                        const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O, int64_t o_bs, int64_t o_hs,
                        int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal,
-                       int scale_mode, float scale, const void* zeros, void* stream);
+                       int scale_mode, float scale, float q_scale, const void* rel_h, const void* rel_w, int64_t rel_kh,
+                       int64_t rel_kw, const void* zeros, void* stream);
 
 /* hf: apply_rotary_pos_emb on n_heads consecutive heads (q heads then k heads of a fused QKV row), in place.
  * positions int64 [tokens]; inv_freq float32 [hd/2] computed by the host exactly as LlamaRotaryEmbedding does. */
@@ -94,6 +98,35 @@ int ull_gather_rows_bf16(const void* src, int64_t lds, const void* idx, void* ds
 
 /* out = bf16(a + b[row % b_rows])  (bf16 tensor adds: queries + query_pe, keys + key_pe, x + pos_embed). */
 int ull_add_rows_bf16(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream);
+
+/* ---- SAM (models/segment_anything/modeling) -- token-major / channels-last layouts ---------------------------------- */
+
+/* image_encoder.py:263-289 window_partition: x [B,H,W,C] -> [B*nW, ws*ws, C], zero rows for the F.pad region. */
+int ull_window_partition_bf16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
+
+/* image_encoder.py:292-318 window_unpartition fused with the residual add of Block.forward (:190): out = shortcut + unpart(win). */
+int ull_window_unpartition_add_bf16(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws,
+                                    void* stream);
+
+/* image_encoder.py:321-392 get_rel_pos + einsum("bhwc,hkc->bhwk") / ("bhwc,wkc->bhwk"): q [NB,nH,KH*KW,hd] by strides ->
+ * out_h [NB*nH, KH*KW, KH], out_w [NB*nH, KH*KW, KW].  rel_pos_h [2*KH-1, hd], rel_pos_w [2*KW-1, hd] (no interpolation case). */
+int ull_sam_relpos_bf16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w, void* out_h,
+                        void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
+
+/* common.py:31-43 LayerNorm2d on channels-last rows [rows, C] with the reference's bf16 op chain; gelu != 0 fuses the
+ * nn.GELU that follows it in mask_decoder.py:53-64 output_upscaling. */
+int ull_layernorm2d_cl_bf16(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu, void* stream);
+
+/* image_encoder.py:100-106 neck Conv2d(k=3, padding=1): x [B,H,W,C] -> cols [B*H*W, 9*C] in (ky,kx,ci) order. */
+int ull_im2col3x3_bf16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+
+/* mask_decoder.py:150-158: masks[n,t,Y,X] = hyper_in[n,t,:] . upscaled[n,:,Y,X]; `up` is the blocked output of the two
+ * ConvTranspose2d(k=2,s=2) GEMMs: [n][G*G cells][d1][d2][C].  masks bf16 [n,T,4G,4G]. */
+int ull_mask_matmul_bf16(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
+
+/* sam.py:137-172 postprocess_masks: F.interpolate(bilinear, align_corners=False) in fp32 of n images (bf16 or fp32, strided crop). */
+int ull_bilinear_f32(const void* in, int in_is_bf16, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w, void* out,
+                     int64_t n, int64_t out_h, int64_t out_w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,212 @@
+"""GPU parity of the SAM kernels / sub-models against the CPU oracle and the committed reference fixtures (G7, G8)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import pkg, load_fixture, fixture_sd, assert_close_bf16, rel_err
+from oracle import ullava_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def test_window_partition_roundtrip_and_zero_pad():
+    ops = pkg("ops")
+    B, H, W, C, ws = 2, 10, 10, 64, 4
+    x = _rand(B, H, W, C, seed=1)
+    win = ops.window_partition(x.view(-1, C).to(DEV), B, H, W, ws).cpu()
+    ref, pad_hw = O.window_partition(x, ws)
+    assert torch.equal(win.view(ref.shape), ref)
+    sc = _rand(B, H, W, C, seed=2)
+    out = ops.window_unpartition_add(win.to(DEV), sc.view(-1, C).to(DEV), B, H, W, ws).cpu()
+    assert torch.equal(out.view(B, H, W, C), sc + O.window_unpartition(ref, ws, pad_hw, (H, W)))
+
+
+@pytest.mark.parametrize("side,hd,nH,NB", [(14, 80, 2, 3), (8, 16, 2, 1)])
+def test_relpos_tables(side, hd, nH, NB):
+    ops = pkg("ops")
+    S, C = side * side, nH * hd
+    qkv = _rand(NB * S, 3 * C, seed=3)
+    rph, rpw = _rand(2 * side - 1, hd, seed=4), _rand(2 * side - 1, hd, seed=5)
+    oh, ow = ops.sam_relpos(qkv.to(DEV), (S * 3 * C, hd, 3 * C), rph.to(DEV), rpw.to(DEV), NB, nH, side, side, hd)
+    q = qkv[:, :C].view(NB, S, nH, hd).permute(0, 2, 1, 3).reshape(NB * nH, S, hd)
+    r_q = q.reshape(NB * nH, side, side, hd)
+    rel_h = torch.einsum("bhwc,hkc->bhwk", r_q, O.get_rel_pos(side, side, rph))
+    rel_w = torch.einsum("bhwc,wkc->bhwk", r_q, O.get_rel_pos(side, side, rpw))
+    assert_close_bf16(oh.view(rel_h.shape), rel_h, ulps=1.0, what="rel_h")
+    assert_close_bf16(ow.view(rel_w.shape), rel_w, ulps=1.0, what="rel_w")
+
+
+@pytest.mark.parametrize("side,hd,nH,NB", [(14, 80, 2, 3), (64, 80, 2, 1), (64, 32, 2, 1)])
+def test_sam_encoder_attention(side, hd, nH, NB):
+    """windowed (196 keys, register kernel + bias) and global (4096 keys, two-pass kernel + bias) SAM attention."""
+    ops = pkg("ops")
+    S, C = side * side, nH * hd
+    x = _rand(NB, side, side, C, seed=6)
+    sd = {"qkv.weight": _rand(3 * C, C, seed=7, scale=C ** -0.5), "qkv.bias": _rand(3 * C, seed=8, scale=0.1),
+          "proj.weight": torch.eye(C).to(BF), "proj.bias": torch.zeros(C).to(BF),
+          "rel_pos_h": _rand(2 * side - 1, hd, seed=9, scale=0.3), "rel_pos_w": _rand(2 * side - 1, hd, seed=10, scale=0.3)}
+    ref = O.sam_attention(sd, "", x, nH).reshape(NB * S, C)           # proj = identity -> the attention output itself
+    qkv = F.linear(x.reshape(-1, C), sd["qkv.weight"], sd["qkv.bias"]).to(DEV)
+    strides = (S * 3 * C, hd, 3 * C)
+    rel_h, rel_w = ops.sam_relpos(qkv, strides, sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), NB, nH, side, side, hd)
+    vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
+    att = torch.empty(NB * S, C, device=DEV, dtype=BF)
+    ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
+                  q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
+    vmax = float(qkv[:, 2 * C:].float().abs().max())
+    assert_close_bf16(att, ref, ulps=2.0, what=f"sam attention side={side}", outlier_frac=2e-3, outlier_floor=vmax)
+
+
+@pytest.mark.parametrize("Sq,Sk,hd", [(6, 4096, 16), (4096, 6, 16), (6, 6, 32), (130, 1500, 64)])
+def test_decoder_style_attention(Sq, Sk, hd):
+    """SAM decoder attention (scores / sqrt(hd), softmax in bf16) incl. the 4096-key two-pass kernel."""
+    ops = pkg("ops")
+    n, H = 2, 8 if hd <= 32 else 2
+    Di = H * hd
+    q, k, v = _rand(n * Sq, Di, seed=11), _rand(n * Sk, Di, seed=12), _rand(n * Sk, Di, seed=13)
+    qh = q.view(n, Sq, H, hd).transpose(1, 2)
+    kh = k.view(n, Sk, H, hd).transpose(1, 2)
+    vh = v.view(n, Sk, H, hd).transpose(1, 2)
+    a = torch.softmax((qh @ kh.permute(0, 1, 3, 2)) / math.sqrt(hd), dim=-1)
+    ref = (a @ vh).transpose(1, 2).reshape(n * Sq, Di)
+    vt = ops.transpose_v(v.to(DEV), Sk * Di, Di, n, Sk, H, hd)
+    out = torch.empty(n * Sq, Di, device=DEV, dtype=BF)
+    ops.attention(q.to(DEV), k.to(DEV), vt, out, n, H, Sq, Sk, hd, (Sq * Di, hd, Di), (Sk * Di, hd, Di), (Sq * Di, hd, Di), None,
+                  causal=False, scale_mode=2, scale=math.sqrt(hd))
+    assert_close_bf16(out, ref, ulps=2.0, what=f"decoder attention {Sq}x{Sk}", outlier_frac=2e-3, outlier_floor=float(v.float().abs().max()))
+
+
+@pytest.mark.parametrize("C,gelu", [(64, True), (256, False)])
+def test_layernorm2d_channels_last(C, gelu):
+    ops = pkg("ops")
+    x = _rand(3, C, 5, 7, seed=14, scale=2.0)
+    w, b = (1 + 0.1 * torch.randn(C)).to(BF), (0.1 * torch.randn(C)).to(BF)
+    ref = O.layer_norm_2d(x, w, b)
+    if gelu:
+        ref = F.gelu(ref)
+    out = ops.layernorm2d_cl(x.permute(0, 2, 3, 1).contiguous().view(-1, C).to(DEV), w.to(DEV), b.to(DEV), 1e-6, gelu)
+    assert_close_bf16(out.view(3, 5, 7, C).permute(0, 3, 1, 2), ref, ulps=1.0, what="LayerNorm2d")
+
+
+def test_neck_conv3x3_as_gemm():
+    ops = pkg("ops")
+    B, g, D = 2, 8, 64
+    x = _rand(B, D, g, g, seed=15)
+    w = _rand(D, D, 3, 3, seed=16, scale=(9 * D) ** -0.5)
+    ref = F.conv2d(x, w, padding=1)
+    xt = x.permute(0, 2, 3, 1).contiguous().view(-1, D).to(DEV)
+    wp = w.permute(0, 2, 3, 1).reshape(D, 9 * D).contiguous().to(DEV)
+    out = ops.linear(ops.im2col3x3(xt, B, g, g), wp)
+    assert_close_bf16(out.view(B, g, g, D).permute(0, 3, 1, 2), ref, what="conv3x3")
+
+
+def test_bilinear_matches_interpolate():
+    ops = pkg("ops")
+    m = _rand(3, 256, 256, seed=17)
+    ref = O.postprocess_masks(m[:, None], (768, 1024), (480, 640))[:, 0]
+    up = ops.bilinear(m.to(DEV), 256, 256, 1024, 1024)
+    out = ops.bilinear(up, 768, 1024, 480, 640).cpu()
+    assert out.dtype == torch.float32 and tuple(out.shape) == (3, 480, 640)
+    assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def _decoder_engine(fx):
+    C, S = pkg("configuration"), pkg("sam")
+    cfg = C.SamConfig(depth=0)
+    holder = S.build_sam_holder(cfg, device=DEV)
+    sd = {k[len("visual_model."):]: v for k, v in fixture_sd(fx, BF).items()}
+    missing = holder.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    return S.SamEngine(holder, cfg), fixture_sd(fx, BF)
+
+
+def test_mask_decoder_fixture_g7():
+    fx = load_fixture("g7_sam_decoder_bf16.pt")
+    eng, sd = _decoder_engine(fx)
+    pe = eng.dense_pe().cpu()                                     # token-major [4096, 256]
+    ref_pe = O.dense_pe(sd, (64, 64))[0].permute(1, 2, 0).reshape(4096, 256)
+    assert torch.equal(pe, ref_pe), "dense PE must be bit-exact (constant folded with the reference's bf16 recipe)"
+    g = torch.Generator().manual_seed(fx["image_embedding_seed"])
+    emb = torch.randn(1, 256, 64, 64, generator=g).to(BF)
+    emb_tm = emb[0].permute(1, 2, 0).reshape(4096, 256).contiguous().to(DEV)
+    sd32 = {k: v.float() for k, v in sd.items()}
+    for case in fx["cases"]:
+        text = case["text_embeds"][:, 0].to(DEV)
+        masks, iou = eng.decode(emb_tm, text)
+        low = masks[:, 0:1].float().cpu()
+        sp, de = O.prompt_encoder_text(sd32, case["text_embeds"].float(), (64, 64))
+        truth, truth_iou = O.mask_decoder(sd32, emb.float(), O.dense_pe(sd32, (64, 64)), sp, de, False)
+        e_ref, e_hip = rel_err(case["low_res_masks"], truth), rel_err(low, truth)
+        print(f"n={case['n']}: mask-logit err vs fp32 truth: reference bf16 {e_ref:.4f}, HIP {e_hip:.4f}; HIP vs reference {rel_err(low, case['low_res_masks']):.4f};"
+              f" iou err {rel_err(iou[:, 0:1], case['iou']):.4f}")
+        assert e_hip <= max(2.0 * e_ref, 0.02)
+        post = eng.postprocess(masks[:, 0].contiguous(), (768, 1024), (480, 640)).cpu()
+        assert post.dtype == torch.float32 and tuple(post.shape) == (case["n"], 480, 640)
+        ref_post = O.postprocess_masks(masks[:, 0:1].cpu(), (768, 1024), (480, 640))[:, 0]
+        assert float((post - ref_post).abs().max()) <= 1e-5 * float(ref_post.abs().max())
+
+
+def _full_model(fx):
+    C, M = pkg("configuration"), pkg("modeling_ullava")
+    cfg, cd = fx["cfg"], fx["cfg"]["llm"]
+    ucfg = C.UllavaConfig(llm_config=dict(vision_config=cd["vision_config"], vision_hidden_layer=cd["vision_hidden_layer"],
+                                          projector_type="mlp", mm_token_ids=cd["mm_token_ids"], vocab_size=cd["vocab_size"],
+                                          hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
+                                          num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"]),
+                            seg_token_idx=cfg["seg_token_idx"], loc_token_idx=cfg["loc_token_idx"], sam_config=dict(cfg["sam"]))
+    model = M.UllavaForCausalLM(ucfg, device=DEV)
+    sd = fixture_sd(fx, BF)
+    model.load_state_dict(sd, strict=True)
+    return model, sd
+
+
+def test_full_forward_fixture_g8():
+    fx = load_fixture("g8_full_tiny_bf16.pt")
+    model, sd = _full_model(fx)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(BF)
+    out = model(images_sam=images_sam.to(DEV), images=fx["images"].to(DEV), input_ids=fx["input_ids"].to(DEV), labels=None,
+                attention_mask=fx["attention_mask"].to(DEV), mask_list=[None, None], size_list=fx["size_list"],
+                resize_list=fx["resize_list"], bbox_list=[None, None], inference=True)
+    assert sorted(out.keys()) == fx["dict_keys"]
+    assert [m.shape[0] for m in out["pred_masks"]] == [2, 1] and [b.shape[0] for b in out["pred_boxes"]] == [1, 2]   # [SEG]/[LOC] shift
+    valid = fx["attention_mask"].bool()
+    print("logits err", rel_err(out["logits"].cpu()[valid], fx["logits"][valid]))
+    assert rel_err(out["logits"].cpu()[valid], fx["logits"][valid]) < 0.03
+    emb = model.get_visual_embs(images_sam.to(DEV)).cpu()
+    e = rel_err(emb[:, ::16, ::4, ::4], fx["image_embeddings_sample"])
+    print("SAM encoder embedding err vs reference", e)
+    assert e < 0.05
+    for i in range(2):
+        assert out["pred_masks"][i].dtype == torch.float32 and tuple(out["pred_masks"][i].shape) == tuple(fx["pred_mask_shapes"][i])
+        em = rel_err(out["pred_masks"][i].cpu()[:, ::8, ::8], fx["pred_mask_samples"][i])
+        eb = rel_err(out["pred_boxes"][i], fx["pred_boxes"][i])
+        print(f"sample {i}: mask err {em:.4f} box err {eb:.4f}")
+        assert em < 0.08 and eb < 0.05
+
+
+def test_evaluate_greedy_tiny():
+    """evaluate(temperature=0): ids identical to the oracle's greedy loop, masks produced for generated [SEG] tokens."""
+    fx = load_fixture("g8_full_tiny_bf16.pt")
+    model, sd = _full_model(fx)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(BF)[:1]
+    ids = fx["input_ids"][:1]
+    seq, masks, boxes = model.evaluate(images_sam.to(DEV), fx["images"][:1].to(DEV), ids.to(DEV), [fx["size_list"][0]], [fx["resize_list"][0]],
+                                       max_new_tokens=6, temperature=0)
+    llm_sd = {k[4:]: v for k, v in sd.items() if k.startswith("llm.")}
+    ref_seq, _ = O.greedy_generate(llm_sd, fx["cfg"]["llm"], ids, fx["images"][:1], None, 6)
+    assert torch.equal(seq.cpu(), ref_seq), (seq.cpu().tolist(), ref_seq.tolist())
+    n_seg = int((ref_seq[0, 1:] == fx["cfg"]["seg_token_idx"]).sum())
+    assert masks[0].shape[0] == n_seg and tuple(masks[0].shape[1:]) == tuple(fx["size_list"][0])

@@ -19,7 +19,7 @@ SIGNATURES = {
     "ull_layernorm_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "ull_clip_embed_ln_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
     "ull_attention_bf16": [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64,
-                           _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _ptr, _ptr],
+                           _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _ptr, _ptr, _i64, _i64, _ptr, _ptr],
     "ull_rope_inplace_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "ull_transpose_v_bf16": [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_im2col_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
@@ -28,6 +28,13 @@ SIGNATURES = {
     "ull_video_pool_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_gather_rows_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "ull_add_rows_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "ull_window_partition_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "ull_window_unpartition_add_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "ull_sam_relpos_bf16": [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "ull_layernorm2d_cl_bf16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _i32, _ptr],
+    "ull_im2col3x3_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
+    "ull_mask_matmul_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
+    "ull_bilinear_f32": [_ptr, _i32, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr],
 }
 
 ERRORS = {-1: "ULL_ERR_ARG (null pointer / bad size)", -2: "ULL_ERR_SHAPE (alignment or shape constraint)",

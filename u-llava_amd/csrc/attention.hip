@@ -32,13 +32,50 @@ struct AttnArgs {
     int causal, scale_mode;
     float scale;
     const bf16_t* zeros;                // >= 16 readable zero bytes (source of the head-dim padding chunks)
+    // SAM decomposed relative-position bias (image_encoder.py:354-392): S += rel_h[q, key / KW]; S += rel_w[q, key % KW]
+    const bf16_t* rel_h; const bf16_t* rel_w;   // [B*H, Sq, KH] / [B*H, Sq, KW] or null
+    int KH, KW;
+    float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
 };
+
+// One lane's 4 consecutive scores of one query -> the reference's rounding chain -> two packed bf16 pairs.
+//   acc[r] = raw fp32 dot product for key j0 + r;  mk = 4 mask bytes (1 attend, 0 masked, 2 out of range)
+//   brow   = this query's bias row in LDS: [KH rel_h values | KW rel_w values], or null
+ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t mk, int qi, int koff, const bf16_t* brow,
+                        uint32_t& lo, uint32_t& hi) {
+    uint16_t o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + r;
+        float sv = rbf(acc[r]);
+        if (p.scale_mode == 1) sv = rbf(sv * p.scale);
+        else if (p.scale_mode == 2) sv = rbf(sv / p.scale);
+        if (brow != nullptr) {
+            const int kh = min(j / p.KW, p.KH - 1), kw = j % p.KW;
+            sv = rbf(rbf(sv + bf2f(brow[kh])) + bf2f(brow[p.KH + kw]));
+        }
+        const uint32_t mb = (mk >> (8 * r)) & 0xff;
+        const bool allowed = (mb == 1) && (!p.causal || j <= qi + koff);
+        o[r] = (mb == 2) ? BF16_NEG_INF : (allowed ? f2bf(sv) : BF16_MIN);
+    }
+    lo = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+    hi = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+}
+
+ULL_DEV uint4 scale_q8(const uint4& v, float sc) {
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= sc;
+    return pack8(f);
+}
 
 // LDS-DMA of 64 x 16 B (see gemm_bf16.hip: issued via inline asm so hipcc does not drain it before the next ds_read).
 ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */) {
     uint32_t keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);   // make uniformity provable to the compiler
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
 // XOR swizzle of the 16-byte chunk index inside an LDS tile row (CPR chunks per row): chosen so that the 16 rows a
@@ -73,6 +110,7 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     char* maskb = smem + 2 * TILE;        // one byte per key: 1 attend, 0 masked (finfo.min), 2 out of range (-inf)
+    bf16_t* biasb = (bf16_t*)(smem + 2 * TILE + NT * KT);
 
     int kend = p.Sk;
     if (p.causal) kend = min(p.Sk, q0 + BQ + koff);
@@ -91,14 +129,26 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
             qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+            if (p.q_scale != 1.0f) qf[ks] = scale_q8(qf[ks], p.q_scale);
         }
         for (int j = tid; j < nkt * KT; j += 512) {
             unsigned char m = 2;
             if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
             maskb[j] = m;
         }
+        if (p.rel_h != nullptr) {           // this wave's 16 bias rows -> LDS (read back by the lanes that own each query)
+            const int bw = p.KH + p.KW;
+            bf16_t* dst = biasb + wave * 16 * bw;
+            for (int i = lane; i < 16 * bw; i += 64) {
+                const int r = i / bw, c = i % bw;
+                const int q = min(q0 + wave * 16 + r, p.Sq - 1);
+                const long row = (long)head * p.Sq + q;
+                dst[i] = (c < p.KH) ? p.rel_h[row * p.KH + c] : p.rel_w[row * p.KW + (c - p.KH)];
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bf16_t* brow = (p.rel_h != nullptr) ? biasb + (wave * 16 + fr) * (p.KH + p.KW) : nullptr;
 
     const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
     const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
@@ -155,19 +205,7 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
                         acc = mfma16(kf, qf[ks], acc);
                     }
                     const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
-                    uint16_t o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = kt * KT + ns * 16 + fg * 4 + r;
-                        float sv = rbf(acc[r]);
-                        if (p.scale_mode == 1) sv = rbf(sv * p.scale);
-                        else if (p.scale_mode == 2) sv = rbf(sv / p.scale);
-                        const uint32_t mb = (mk >> (8 * r)) & 0xff;
-                        const bool allowed = (mb == 1) && (!p.causal || j <= qi + koff);
-                        o[r] = (mb == 2) ? BF16_NEG_INF : (allowed ? f2bf(sv) : BF16_MIN);
-                    }
-                    sp[kt][ns * 2] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-                    sp[kt][ns * 2 + 1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+                    score_quad(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
                 }
             }
         }
@@ -256,6 +294,192 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Any number of keys (SAM global attention: 4096 keys; mask-decoder token->image cross attention: 4096 keys).
+// Same rounding points as above, but the score row no longer fits in registers, so the kernel streams the keys TWICE:
+//   pass 1  S tiles -> running row max and sum of exp (fp32; combined across the 4 lanes of a query at the end);
+//   pass 2  the same S tiles again (bit-identical), P = bf16(exp(S - max) / sum) straight into the P*V MFMA.
+// Nothing but O is written; K is read twice from L2 instead of S/P being materialised in HBM like the reference does.
+template <int HDP>
+__global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NWV = 8, BQ = 16 * NWV;
+    constexpr int CPR = HDP / 8, KROW = HDP * 2;
+    constexpr int NKS = HDP / 32, NDS = HDP / 16;
+    constexpr int TILE = 64 * KROW;       // == HDP * 128: a K tile (64 x HDP) and a V^T tile (HDP x 64) have the same size
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nq = (p.Sq + BQ - 1) / BQ;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int head = (slot / nq) * 8 + xcd;
+    if (head >= p.B * p.H) return;
+    const int qt = nq - 1 - slot % nq;
+    const int b = head / p.H, h = head % p.H;
+    const int q0 = qt * BQ;
+    const int koff = p.Sk - p.Sq;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    int kend = p.Sk;
+    if (p.causal) kend = min(p.Sk, q0 + BQ + koff);
+    if (kend < 1) kend = 1;
+    const int nkt = (kend + KT - 1) / KT;
+    char* maskb = smem + 4 * TILE;
+    bf16_t* biasb = (bf16_t*)(smem + 4 * TILE + ((nkt * KT + 15) & ~15));
+
+    uint4 qf[NKS];
+    const int qi = q0 + wave * 16 + fr;
+    {
+        const bf16_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 32 + fg * 8;
+            qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+            if (p.q_scale != 1.0f) qf[ks] = scale_q8(qf[ks], p.q_scale);
+        }
+        for (int j = tid; j < nkt * KT; j += 512) {
+            unsigned char m = 2;
+            if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
+            maskb[j] = m;
+        }
+        if (p.rel_h != nullptr) {
+            const int bw = p.KH + p.KW;
+            bf16_t* dst = biasb + wave * 16 * bw;
+            for (int i = lane; i < 16 * bw; i += 64) {
+                const int r = i / bw, c = i % bw;
+                const int q = min(q0 + wave * 16 + r, p.Sq - 1);
+                const long row = (long)head * p.Sq + q;
+                dst[i] = (c < p.KH) ? p.rel_h[row * p.KH + c] : p.rel_w[row * p.KW + (c - p.KH)];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bf16_t* brow = (p.rel_h != nullptr) ? biasb + (wave * 16 + fr) * (p.KH + p.KW) : nullptr;
+
+    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    // stream step s: s < nkt -> K tile s (pass 1); else K tile + V^T tile s - nkt (pass 2).  Slot = s & 1, [K | V^T].
+    auto issue = [&](int s) {
+        if (s >= 2 * nkt) return;
+        const uint32_t dst = lds_base + (s & 1) * (2 * TILE);
+        const int kt = s < nkt ? s : s - nkt;
+#pragma unroll
+        for (int i0 = 0; i0 < CPR; i0 += NWV) {
+            const int i = i0 + wave;
+            if (i < CPR) {
+                const int row = i * (64 / CPR) + lane / CPR;
+                const int c = (lane % CPR) ^ swz<CPR>(row);
+                const int key = min(kt * KT + row, p.Sk - 1);
+                const bf16_t* src = (c * 8 < p.hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                glds16(src, dst + i * 1024);
+            }
+        }
+        if (s >= nkt) {
+            const int npieces = p.hd >> 3;
+#pragma unroll
+            for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
+                const int i = i0 + wave;
+                if (i < npieces) {
+                    const int row = i * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ (row & 7);
+                    glds16(vbase + (long)row * p.vt_ds + kt * KT + c * 8, dst + TILE + i * 1024);
+                }
+            }
+        }
+    };
+    // scores of one 64-key tile for this lane's query: sq[2*ns + half]
+    auto scores = [&](const char* tb, int kt, uint32_t (&sq)[8]) {
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const int row = ns * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
+                acc = mfma16(kf, qf[ks], acc);
+            }
+            const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
+            score_quad(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sq[ns * 2], sq[ns * 2 + 1]);
+        }
+    };
+
+    issue(0);
+    float m = -INFINITY, l = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {                       // ---- pass 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(kt + 1);
+        uint32_t sq[8];
+        scores(smem + (kt & 1) * (2 * TILE), kt, sq);
+        float tm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            tm = fmaxf(tm, __uint_as_float(sq[i] << 16));
+            tm = fmaxf(tm, __uint_as_float(sq[i] & 0xffff0000u));
+        }
+        if (tm > m) { l *= __expf(m - tm); m = tm; }
+        if (m > -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                l += __expf(__uint_as_float(sq[i] << 16) - m);
+                l += __expf(__uint_as_float(sq[i] & 0xffff0000u) - m);
+            }
+        }
+    }
+    {   // combine the 4 lanes (fg = 0..3) that share a query
+        float mo = __shfl_xor(m, 16, 64), lo = __shfl_xor(l, 16, 64);
+        float mn = fmaxf(m, mo);
+        l = (m > -INFINITY ? l * __expf(m - mn) : 0.f) + (mo > -INFINITY ? lo * __expf(mo - mn) : 0.f);
+        m = mn;
+        mo = __shfl_xor(m, 32, 64); lo = __shfl_xor(l, 32, 64);
+        mn = fmaxf(m, mo);
+        l = (m > -INFINITY ? l * __expf(m - mn) : 0.f) + (mo > -INFINITY ? lo * __expf(mo - mn) : 0.f);
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+
+    f32x4_t oacc[NDS];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nkt; ++kt) {                       // ---- pass 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(nkt + kt + 1);
+        const char* tb = smem + ((nkt + kt) & 1) * (2 * TILE);
+        uint32_t sq[8];
+        scores(tb, kt, sq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float lo = __expf(__uint_as_float(sq[i] << 16) - m) * inv;
+            const float hi = __expf(__uint_as_float(sq[i] & 0xffff0000u) - m) * inv;
+            sq[i] = pack2bf(lo, hi);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint4 pf = make_uint4(sq[4 * kk], sq[4 * kk + 1], sq[4 * kk + 2], sq[4 * kk + 3]);
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                if (ds * 16 < p.hd) {
+                    const int row = ds * 16 + fr;
+                    const uint4 vf = *(const uint4*)(tb + TILE + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                    oacc[ds] = mfma16(vf, pf, oacc[ds]);
+                }
+            }
+        }
+    }
+    if (qi < p.Sq) {
+        bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            if (ds * 16 < p.hd) {
+                uint2 pk;
+                pk.x = pack2bf(oacc[ds][0], oacc[ds][1]);
+                pk.y = pack2bf(oacc[ds][2], oacc[ds][3]);
+                *(uint2*)(op + ds * 16 + fg * 4) = pk;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // RoPE in place on the q|k part of a fused QKV buffer (transformers apply_rotary_pos_emb on bf16
 // tensors: q*cos -> bf16, rotate_half(q)*sin -> bf16, sum -> bf16; cos/sin are fp32 values cast to bf16).
 // One block per token; thread t owns the 8-wide dim chunk (t % (hd/16)) of head-instances t / (hd/16), ...
@@ -319,7 +543,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 template <int HDP, int NT>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
-    const int lds = 2 * TILE + NT * KT;
+    const int lds = 2 * TILE + NT * KT + (a.rel_h ? 8 * 16 * (a.KH + a.KW) * 2 : 0);
     const int nq = (a.Sq + 127) / 128;
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
@@ -335,7 +559,19 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     }
     if (nt <= 11) return launch_attn<HDP, 11>(a, st);
     if (nt <= 16) return launch_attn<HDP, 16>(a, st);
-    return ULL_ERR_LDS;      // > 1024 keys do not fit the register-resident score row
+    // > 1024 keys do not fit the register-resident score row: two-pass streaming kernel
+    constexpr int TILE = 64 * HDP * 2;
+    const int lds = 4 * TILE + ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (a.KH + a.KW) * 2 : 0);
+    if (lds > 160 * 1024) return ULL_ERR_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_long_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int nq = (a.Sq + 127) / 128;
+    const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
+    hipLaunchKernelGGL((attn_long_kernel<HDP>), grid, dim3(512), lds, st, a);
+    return ull_check_launch();
 }
 
 }  // namespace
@@ -346,7 +582,8 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
 extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs,
                                   int64_t k_ss, const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O,
                                   int64_t o_bs, int64_t o_hs, int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq,
-                                  int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, const void* zeros, void* stream) {
+                                  int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, float q_scale, const void* rel_h,
+                                  const void* rel_w, int64_t rel_kh, int64_t rel_kw, const void* zeros, void* stream) {
     if (!Q || !K || !Vt || !O || !zeros || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return ULL_ERR_ARG;
     if (hd <= 0 || hd > 128 || (hd & 15) || (vt_len & 63) || vt_len < ((Sk + 63) & ~63)) return ULL_ERR_SHAPE;
     if ((q_ss & 7) || (k_ss & 7) || (vt_ds & 7) || (q_hs & 7) || (k_hs & 7) || (q_bs & 7) || (k_bs & 7) || (vt_hs & 7) || (vt_bs & 7) ||
@@ -360,6 +597,9 @@ extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int
     a.B = (int)B; a.H = (int)H; a.Sq = (int)Sq; a.Sk = (int)Sk; a.hd = (int)hd; a.vt_len = (int)vt_len;
     a.causal = causal; a.scale_mode = scale_mode; a.scale = scale;
     a.zeros = (const bf16_t*)zeros;
+    a.rel_h = (const bf16_t*)rel_h; a.rel_w = (const bf16_t*)rel_w; a.KH = (int)rel_kh; a.KW = (int)rel_kw; a.q_scale = q_scale;
+    if ((rel_h == nullptr) != (rel_w == nullptr)) return ULL_ERR_ARG;
+    if (rel_h && (rel_kh <= 0 || rel_kw <= 0 || rel_kh + rel_kw > 256 || rel_kh * rel_kw < Sk)) return ULL_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (hd <= 32) return dispatch_nt<32>(a, st);
     if (hd <= 64) return dispatch_nt<64>(a, st);

@@ -399,7 +399,7 @@ class UllavaCoreForCausalLM(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids=None, images=None, videos=None, attention_mask=None, max_new_tokens=32, do_sample=False,
                  temperature=1.0, top_p=None, num_beams=1, no_repeat_ngram_size=None, stopping_criteria=None, eos_token_id=None,
-                 output_hidden_states=False, return_dict_in_generate=False, use_cache=None, **kwargs):
+                 output_hidden_states=False, return_dict_in_generate=False, use_cache=None, keep_last_step_only=False, **kwargs):
         """Token-by-token decoding with the reference's no-KV-cache semantics (every step re-runs the multimodal prefill,
         which is what the released checkpoints do: SURVEY 3.2).  Greedy (`do_sample=False`) is bit-reproducible; sampling
         draws from torch's RNG on the softmax of logits/temperature with optional nucleus filtering."""
@@ -414,7 +414,10 @@ class UllavaCoreForCausalLM(nn.Module):
             out = self.forward(input_ids=seq, attention_mask=mask, images=images, videos=videos,
                                output_hidden_states=output_hidden_states)
             if output_hidden_states:
-                steps_hidden.append(out.hidden_states)
+                if keep_last_step_only:
+                    steps_hidden = [out.hidden_states]      # evaluate() only reads hidden_states[-1] (the last step)
+                else:
+                    steps_hidden.append(out.hidden_states)
             logits = out.logits[:, -1].float()
             if do_sample and temperature and temperature > 0:
                 probs = torch.softmax(logits / temperature, dim=-1)

@@ -1,0 +1,146 @@
+"""UllavaForCausalLM on MI355X: u-LLaVA core + [SEG]/[LOC] projectors + SAM prompt-encoder / mask-decoder / postprocess.
+
+Host-side mirror of reference `models/ullava.py:69-434` (same constructor, attribute names `.llm .seg_projector
+.visual_model .det_projector .det_decoder`, state-dict keys, `forward(..., inference=True)` dict keys and `evaluate()`
+tuple).  Differences that are deliberate and output-preserving:
+  * the [SEG]/[LOC] rows are gathered BEFORE the projector MLPs (the reference projects all B*S rows and then masks);
+  * the SAM image encoder runs batched instead of one image per python iteration with empty_cache();
+  * the dense positional encoding is evaluated once (the reference recomputes it per image).
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .configuration import UllavaConfig
+from .modeling_core import BF16, Linear, UllavaCoreForCausalLM, _Holder
+from .sam import SamEngine, build_sam_holder
+
+
+def _mlp_seq(dims, device, dtype, dropout_tail=False):
+    """nn.Sequential(Linear, ReLU, Linear, ...) with the reference's child indices (ReLU / Dropout hold no parameters)."""
+    mods = []
+    for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        mods.append(Linear(a, b, device=device, dtype=dtype))
+        if i < len(dims) - 2:
+            mods.append(nn.ReLU(inplace=True))
+    if dropout_tail:
+        mods.append(nn.Dropout(0.0))
+    return nn.Sequential(*mods)
+
+
+class UllavaForCausalLM(nn.Module):
+    config_class = UllavaConfig
+
+    def __init__(self, config: UllavaConfig, device=None, dtype=BF16):
+        super().__init__()
+        self.config = config
+        llm_config = config.llm_config
+        self.llm = UllavaCoreForCausalLM(llm_config, device=device, dtype=dtype)
+        D, O = llm_config.hidden_size, config.out_dim
+        self.seg_projector = _mlp_seq([D, D, O], device, dtype, dropout_tail=True)            # ullava.py:113-118
+        self.visual_model = build_sam_holder(config.sam_config, device=device, dtype=dtype)   # ullava.py:124 (build_sam_vit_h)
+        self.det_projector = _mlp_seq([D, D, O], device, dtype, dropout_tail=True)            # ullava.py:86-91
+        self.det_decoder = _mlp_seq([O, O, O // 2, 4], device, dtype)                         # ullava.py:96-102
+        self._sam = SamEngine(self.visual_model, config.sam_config)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        sd = {k.replace("llm.vision_encoder.vision_model.", "llm.vision_encoder."): v for k, v in state_dict.items()}
+        sd = {k: v for k, v in sd.items() if not k.endswith("position_ids") and "rotary_emb.inv_freq" not in k}
+        self.llm._packed = None
+        self._sam.invalidate()
+        return super().load_state_dict(sd, strict=strict, assign=assign)
+
+    def load_visual_checkpoint(self, checkpoint):
+        """reference ullava.py:134-137."""
+        with open(checkpoint, "rb") as f:
+            sd = torch.load(f, map_location="cpu")
+        self._sam.invalidate()
+        return self.visual_model.load_state_dict(sd, strict=False)
+
+    # -- SAM image encoder -------------------------------------------------------------------------------------------
+    def _visual_embs_tm(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        return self._sam.encode(pixel_values)                       # [B, g*g, 256] token-major
+
+    def get_visual_embs(self, pixel_values: torch.FloatTensor) -> torch.Tensor:
+        """reference ullava.py:139-150 -> [B, 256, g, g] (NCHW, as the reference returns it)."""
+        tm = self._visual_embs_tm(pixel_values)
+        B, P, C = tm.shape
+        g = int(P ** 0.5)
+        return tm.view(B, g, g, C).permute(0, 3, 1, 2).contiguous()
+
+    # -- shared tail of forward / evaluate -----------------------------------------------------------------------------
+    def _run_mlp(self, seq, x):
+        lin = [m for m in seq if isinstance(m, Linear)]
+        for i, l in enumerate(lin):
+            x = ops.linear(x, l.weight, l.bias, act="relu" if i < len(lin) - 1 else None)
+        return x
+
+    def _select(self, last_hidden: torch.Tensor, token_mask: torch.Tensor, projector) -> List[torch.Tensor]:
+        """rows of last_hidden [B, L, D] where token_mask [B, L] is set -> per-sample [n_i, out_dim] after the projector."""
+        B, L, D = last_hidden.shape
+        counts = token_mask.sum(-1).tolist()                       # host sync (the reference indexes device offsets too)
+        idx = token_mask.reshape(-1).nonzero().squeeze(-1)
+        rows = ops.gather_rows(last_hidden.reshape(B * L, D), idx)
+        emb = self._run_mlp(projector, rows) if rows.shape[0] else rows.new_empty(0, self.config.out_dim)
+        out, o = [], 0
+        for c in counts:
+            out.append(emb[o:o + c])
+            o += c
+        return out
+
+    def _decode(self, image_embeddings_tm, pred_embeddings, resize_list, size_list):
+        pred_masks = []
+        for i, e in enumerate(pred_embeddings):
+            n = e.shape[0]
+            H, W = int(size_list[i][0]), int(size_list[i][1])
+            if n == 0:
+                pred_masks.append(torch.empty(0, H, W, device=e.device, dtype=torch.float32))
+                continue
+            masks, _iou = self._sam.decode(image_embeddings_tm[i], e.contiguous())
+            low = masks[:, 0].contiguous()                          # multimask_output=False -> mask 0
+            pred_masks.append(self._sam.postprocess(low, resize_list[i], (H, W)))
+        return pred_masks
+
+    def forward(self, images_sam: torch.FloatTensor, images: torch.FloatTensor, input_ids: torch.LongTensor, labels: torch.LongTensor,
+                attention_mask: torch.LongTensor, mask_list: List[torch.FloatTensor], size_list: List[torch.Tensor],
+                resize_list: List[tuple], bbox_list: List[torch.FloatTensor], inference: bool = False):
+        """reference ullava.py:152-333."""
+        if not inference:
+            raise NotImplementedError("training losses are outside the forward hot path (SURVEY 8(a) row a16); pass inference=True")
+        B = input_ids.shape[0]
+        image_embeddings = self._visual_embs_tm(images_sam)
+        pad = torch.zeros((B, 1), dtype=torch.bool, device=input_ids.device)
+        seg_token_mask = torch.cat([input_ids[:, 1:] == self.config.seg_token_idx, pad], dim=1)    # row t selected iff ids[t+1]==[SEG]
+        loc_token_mask = torch.cat([input_ids[:, 1:] == self.config.loc_token_idx, pad], dim=1)
+        output = self.llm.forward(images=images, attention_mask=attention_mask, input_ids=input_ids, labels=None,
+                                  output_hidden_states=True)
+        last = output.hidden_states[-1]
+        pred_embeddings = self._select(last, seg_token_mask, self.seg_projector)
+        pred_loc_embeddings = self._select(last, loc_token_mask, self.det_projector)
+        pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, size_list)
+        pred_boxes = [self._run_mlp(self.det_decoder, e) if e.shape[0] else e.new_empty(0, 4) for e in pred_loc_embeddings]
+        return {"pred_masks": pred_masks, "pred_boxes": pred_boxes, "gt_masks": mask_list, "gt_boxes": bbox_list, "logits": output.logits}
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def evaluate(self, images_sam, images, input_ids, raw_size_list, resize_list, max_new_tokens=32, temperature=0.2, top_p=None,
+                 num_beams=1, no_repeat_ngram_size=None, stopping_criteria=None):
+        """reference ullava.py:335-434 -> (output_ids, pred_masks, pred_boxes)."""
+        outputs = self.llm.generate(input_ids=input_ids, images=images, max_new_tokens=max_new_tokens, num_beams=num_beams, top_p=top_p,
+                                    do_sample=True if temperature > 0 else False, temperature=temperature, output_hidden_states=True,
+                                    return_dict_in_generate=True, no_repeat_ngram_size=no_repeat_ngram_size,
+                                    stopping_criteria=stopping_criteria, keep_last_step_only=True)
+        output_ids = outputs.sequences
+        last = outputs.hidden_states[-1][-1]                          # last step, last layer: [B, L-1, D]
+        seg_token_mask = output_ids[:, 1:] == self.config.seg_token_idx
+        loc_token_mask = output_ids[:, 1:] == self.config.loc_token_idx
+        L1 = last.shape[1]
+        pred_embeddings = self._select(last, seg_token_mask[:, :L1], self.seg_projector)
+        pred_loc_embeddings = self._select(last, loc_token_mask[:, :L1], self.det_projector)
+        image_embeddings = self._visual_embs_tm(images_sam)
+        pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, raw_size_list)
+        pred_boxes = [self._run_mlp(self.det_decoder, e) if e.shape[0] else e.new_empty(0, 4) for e in pred_loc_embeddings]
+        return output_ids, pred_masks, pred_boxes

@@ -128,14 +128,15 @@ def clip_embed_ln(patch: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, w: 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Sq: int, Sk: int, hd: int,
               q_strides, k_strides, o_strides, key_mask: Optional[torch.Tensor] = None, causal: bool = False, scale_mode: int = 1,
-              scale: float = 1.0):
+              scale: float = 1.0, q_scale: float = 1.0, rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None):
     """q/k/out are views into larger buffers: strides = (batch, head, seq) in elements.  vt [B, H, hd, pitch] contiguous."""
     _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt"); _chk(out, "out")
     if key_mask is not None:
         _chk(key_mask, "key_mask", torch.int32)
     pitch = vt.shape[-1]
     _lib.call("ull_attention_bf16", _p(q), *q_strides, _p(k), *k_strides, _p(vt), H * hd * pitch, hd * pitch, pitch, pitch, _p(out),
-              *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), _zeros(q.device).data_ptr(), _stream())
+              *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), float(q_scale), _p(rel_h), _p(rel_w),
+              0 if rel_h is None else rel_h.shape[-1], 0 if rel_w is None else rel_w.shape[-1], _zeros(q.device).data_ptr(), _stream())
     return out
 
 
@@ -215,4 +216,67 @@ def add_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     rows, b_rows = a.numel() // D, b.numel() // D
     out = torch.empty_like(a)
     _lib.call("ull_add_rows_bf16", _p(a), _p(b), _p(out), rows, D, b_rows, _stream())
+    return out
+
+
+# ---- SAM --------------------------------------------------------------------------------------------------------------
+def window_partition(x: torch.Tensor, B: int, H: int, W: int, ws: int) -> torch.Tensor:
+    """x [B*H*W, C] token-major -> [B*nW*ws*ws, C]."""
+    _chk(x, "x")
+    C = x.shape[-1]
+    nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
+    out = torch.empty(B * nW * ws * ws, C, device=x.device, dtype=BF16)
+    _lib.call("ull_window_partition_bf16", _p(x), _p(out), B, H, W, C, ws, _stream())
+    return out
+
+
+def window_unpartition_add(win: torch.Tensor, shortcut: torch.Tensor, B: int, H: int, W: int, ws: int) -> torch.Tensor:
+    _chk(win, "win"); _chk(shortcut, "shortcut")
+    out = torch.empty_like(shortcut)
+    _lib.call("ull_window_unpartition_add_bf16", _p(win), _p(shortcut), _p(out), B, H, W, shortcut.shape[-1], ws, _stream())
+    return out
+
+
+def sam_relpos(q: torch.Tensor, q_strides, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, NB: int, nH: int, KH: int, KW: int, hd: int):
+    _chk(q, "q"); _chk(rel_pos_h, "rel_pos_h"); _chk(rel_pos_w, "rel_pos_w")
+    if rel_pos_h.shape[0] != 2 * KH - 1 or rel_pos_w.shape[0] != 2 * KW - 1:
+        raise NotImplementedError("rel_pos interpolation (image_encoder.py:336-343) is not needed for 1024x1024 SAM inputs")
+    oh = torch.empty(NB * nH, KH * KW, KH, device=q.device, dtype=BF16)
+    ow = torch.empty(NB * nH, KH * KW, KW, device=q.device, dtype=BF16)
+    _lib.call("ull_sam_relpos_bf16", _p(q), *q_strides, _p(rel_pos_h), _p(rel_pos_w), _p(oh), _p(ow), NB, nH, KH, KW, hd, _stream())
+    return oh, ow
+
+
+def layernorm2d_cl(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6, gelu: bool = False) -> torch.Tensor:
+    _chk(x, "x"); _chk(w, "w"); _chk(b, "b")
+    if not x.is_contiguous():
+        raise RuntimeError("u-llava_amd.layernorm2d_cl: x must be contiguous channels-last rows")
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.call("ull_layernorm2d_cl_bf16", _p(x), _p(w), _p(b), _p(out), x.numel() // C, C, float(eps), int(gelu), _stream())
+    return out
+
+
+def im2col3x3(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    _chk(x, "x")
+    C = x.shape[-1]
+    out = torch.empty(B * H * W, 9 * C, device=x.device, dtype=BF16)
+    _lib.call("ull_im2col3x3_bf16", _p(x), _p(out), B, H, W, C, _stream())
+    return out
+
+
+def mask_matmul(hyper: torch.Tensor, up: torch.Tensor, n: int, T: int, C: int, G: int) -> torch.Tensor:
+    _chk(hyper, "hyper"); _chk(up, "up")
+    out = torch.empty(n, T, 4 * G, 4 * G, device=up.device, dtype=BF16)
+    _lib.call("ull_mask_matmul_bf16", _p(hyper), _p(up), _p(out), n, T, C, G, _stream())
+    return out
+
+
+def bilinear(x: torch.Tensor, in_h: int, in_w: int, out_h: int, out_w: int) -> torch.Tensor:
+    """x [n, Hfull, Wfull] (bf16 or fp32, contiguous); the top-left in_h x in_w crop of every image is resized -> fp32 [n, out_h, out_w]."""
+    if not x.is_cuda or x.dtype not in (BF16, torch.float32) or not x.is_contiguous():
+        raise RuntimeError("u-llava_amd.bilinear: contiguous bf16/fp32 GPU tensor required")
+    n, Hf, Wf = x.shape
+    out = torch.empty(n, out_h, out_w, device=x.device, dtype=torch.float32)
+    _lib.call("ull_bilinear_f32", _p(x), int(x.dtype == BF16), Hf * Wf, Wf, in_h, in_w, _p(out), n, out_h, out_w, _stream())
     return out

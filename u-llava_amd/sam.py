@@ -1,0 +1,281 @@
+"""SAM (ViT-H image encoder, prompt encoder, two-way mask decoder, postprocess) on the HIP path.
+
+Host-side mirror of reference `models/segment_anything/modeling/{image_encoder,prompt_encoder,mask_decoder,transformer,
+common,sam}.py` + `build_sam.py`: the module tree reproduces the reference's state-dict key names; the arithmetic is
+HIP kernels (ops.py).  Internal activation layout is token-major / channels-last ([tokens, C] rows) everywhere, so
+every conv on the path is a GEMM: patch embed (im2col), neck 1x1 (plain), neck 3x3 (9-tap im2col), the two
+ConvTranspose2d(k=2,s=2) of the mask decoder (GEMM whose 4 column blocks are the 2x2 output pixels -- the result is kept
+in that blocked order and only un-blocked by the final mask product kernel).
+"""
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .configuration import SamConfig
+from .modeling_core import BF16, Conv2dHolder, Embedding, Linear, Norm, _Holder, _param
+
+
+def _attn_holder(dim, internal, device, dtype):
+    m = _Holder()
+    m.q_proj = Linear(dim, internal, device=device, dtype=dtype)
+    m.k_proj = Linear(dim, internal, device=device, dtype=dtype)
+    m.v_proj = Linear(dim, internal, device=device, dtype=dtype)
+    m.out_proj = Linear(internal, dim, device=device, dtype=dtype)
+    return m
+
+
+def _mlp_holder(i, h, o, n, device, dtype):
+    m = _Holder()
+    dims = [i] + [h] * (n - 1) + [o]
+    m.layers = nn.ModuleList([Linear(a, b, device=device, dtype=dtype) for a, b in zip(dims[:-1], dims[1:])])
+    return m
+
+
+def build_sam_holder(cfg: SamConfig, device=None, dtype=BF16) -> nn.Module:
+    """Parameter tree with the key names of reference build_sam._build_sam (build_sam.py:56-102)."""
+    sam = _Holder()
+    C, D = cfg.embed_dim, cfg.out_chans
+    g = cfg.img_size // cfg.patch_size
+    enc = _Holder()
+    enc.patch_embed = _Holder()
+    enc.patch_embed.proj = Conv2dHolder(3, C, cfg.patch_size, bias=True, device=device, dtype=dtype)
+    enc.pos_embed = _param(1, g, g, C, device=device, dtype=dtype)
+    blocks = []
+    for i in range(cfg.depth):
+        b = _Holder()
+        size = g if i in cfg.global_attn_indexes else cfg.window_size
+        b.norm1 = Norm(C, eps=1e-6, device=device, dtype=dtype)
+        b.attn = _Holder()
+        b.attn.qkv = Linear(C, 3 * C, device=device, dtype=dtype)
+        b.attn.proj = Linear(C, C, device=device, dtype=dtype)
+        b.attn.rel_pos_h = _param(2 * size - 1, C // cfg.num_heads, device=device, dtype=dtype)
+        b.attn.rel_pos_w = _param(2 * size - 1, C // cfg.num_heads, device=device, dtype=dtype)
+        b.norm2 = Norm(C, eps=1e-6, device=device, dtype=dtype)
+        b.mlp = _Holder()
+        b.mlp.lin1 = Linear(C, int(C * cfg.mlp_ratio), device=device, dtype=dtype)
+        b.mlp.lin2 = Linear(int(C * cfg.mlp_ratio), C, device=device, dtype=dtype)
+        blocks.append(b)
+    enc.blocks = nn.ModuleList(blocks)
+    enc.neck = nn.ModuleList([Conv2dHolder(C, D, 1, bias=False, device=device, dtype=dtype), Norm(D, eps=1e-6, device=device, dtype=dtype),
+                              Conv2dHolder(D, D, 3, bias=False, device=device, dtype=dtype), Norm(D, eps=1e-6, device=device, dtype=dtype)])
+    sam.image_encoder = enc
+
+    pe = _Holder()
+    pe.pe_layer = _Holder()
+    pe.pe_layer.register_buffer("positional_encoding_gaussian_matrix", torch.empty(2, D // 2, device=device, dtype=dtype))
+    pe.point_embeddings = nn.ModuleList([Embedding(1, D, device=device, dtype=dtype) for _ in range(4)])
+    pe.not_a_point_embed = Embedding(1, D, device=device, dtype=dtype)
+    mic = cfg.mask_in_chans
+    pe.mask_downscaling = nn.ModuleList([Conv2dHolder(1, mic // 4, 2, True, device, dtype), Norm(mic // 4, eps=1e-6, device=device, dtype=dtype),
+                                         nn.Identity(), Conv2dHolder(mic // 4, mic, 2, True, device, dtype),
+                                         Norm(mic, eps=1e-6, device=device, dtype=dtype), nn.Identity(),
+                                         Conv2dHolder(mic, D, 1, True, device, dtype)])
+    pe.no_mask_embed = Embedding(1, D, device=device, dtype=dtype)
+    sam.prompt_encoder = pe
+
+    md = _Holder()
+    tr = _Holder()
+    layers = []
+    for _ in range(cfg.decoder_depth):
+        l = _Holder()
+        l.self_attn = _attn_holder(D, D, device, dtype)
+        l.norm1 = Norm(D, device=device, dtype=dtype)
+        l.cross_attn_token_to_image = _attn_holder(D, D // 2, device, dtype)
+        l.norm2 = Norm(D, device=device, dtype=dtype)
+        l.mlp = _Holder()
+        l.mlp.lin1 = Linear(D, cfg.decoder_mlp_dim, device=device, dtype=dtype)
+        l.mlp.lin2 = Linear(cfg.decoder_mlp_dim, D, device=device, dtype=dtype)
+        l.norm3 = Norm(D, device=device, dtype=dtype)
+        l.norm4 = Norm(D, device=device, dtype=dtype)
+        l.cross_attn_image_to_token = _attn_holder(D, D // 2, device, dtype)
+        layers.append(l)
+    tr.layers = nn.ModuleList(layers)
+    tr.final_attn_token_to_image = _attn_holder(D, D // 2, device, dtype)
+    tr.norm_final_attn = Norm(D, device=device, dtype=dtype)
+    md.transformer = tr
+    nm = cfg.num_multimask_outputs + 1
+    md.iou_token = Embedding(1, D, device=device, dtype=dtype)
+    md.mask_tokens = Embedding(nm, D, device=device, dtype=dtype)
+    up0, up3 = _Holder(), _Holder()           # ConvTranspose2d weights are [in, out, kh, kw]
+    up0.weight, up0.bias = _param(D, D // 4, 2, 2, device=device, dtype=dtype), _param(D // 4, device=device, dtype=dtype)
+    up3.weight, up3.bias = _param(D // 4, D // 8, 2, 2, device=device, dtype=dtype), _param(D // 8, device=device, dtype=dtype)
+    md.output_upscaling = nn.ModuleList([up0, Norm(D // 4, eps=1e-6, device=device, dtype=dtype), nn.Identity(), up3, nn.Identity()])
+    md.output_hypernetworks_mlps = nn.ModuleList([_mlp_holder(D, D, D // 8, 3, device, dtype) for _ in range(nm)])
+    md.iou_prediction_head = _mlp_holder(D, cfg.iou_head_hidden_dim, nm, cfg.iou_head_depth, device, dtype)
+    sam.mask_decoder = md
+    return sam
+
+
+class SamEngine:
+    """Runs the SAM sub-models of a `build_sam_holder` tree on the HIP path (weights re-laid out once)."""
+
+    def __init__(self, sam: nn.Module, cfg: SamConfig):
+        self.sam, self.cfg = sam, cfg
+        self._pk = None
+        self._dense_pe = None
+
+    def invalidate(self):
+        self._pk = None
+        self._dense_pe = None
+
+    # -- weight re-layout ------------------------------------------------------------------------------------------
+    def pack(self):
+        cfg, enc, md = self.cfg, self.sam.image_encoder, self.sam.mask_decoder
+        C, D = cfg.embed_dim, cfg.out_chans
+        pk = {}
+        w = enc.patch_embed.proj.weight
+        pk["patch_w"] = w.reshape(C, -1).contiguous()                        # K = 3*16*16 = 768 (multiple of 64)
+        pk["pos"] = enc.pos_embed.reshape(-1, C).contiguous()
+        pk["neck0"] = enc.neck[0].weight.reshape(D, C).contiguous()
+        pk["neck2"] = enc.neck[2].weight.permute(0, 2, 3, 1).reshape(D, 9 * D).contiguous()   # (ky,kx,ci) columns
+        u0, u3 = md.output_upscaling[0], md.output_upscaling[3]
+        # ConvTranspose2d(k=2,s=2) as a GEMM: row (dy*2+dx)*Cout + co of W^T holds W[:, co, dy, dx]
+        pk["up0_w"] = u0.weight.permute(2, 3, 1, 0).reshape(-1, u0.weight.shape[0]).contiguous()
+        pk["up0_b"] = u0.bias.repeat(4).contiguous()
+        pk["up3_w"] = u3.weight.permute(2, 3, 1, 0).reshape(-1, u3.weight.shape[0]).contiguous()
+        pk["up3_b"] = u3.bias.repeat(4).contiguous()
+        self._pk = pk
+        return pk
+
+    def pk(self):
+        return self._pk if self._pk is not None else self.pack()
+
+    # -- image encoder (image_encoder.py:110-125) ------------------------------------------------------------------
+    def encode(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """[B,3,S,S] -> token-major embeddings [B, g*g, out_chans]."""
+        cfg, enc, pk = self.cfg, self.sam.image_encoder, self.pk()
+        B = pixel_values.shape[0]
+        C, nH = cfg.embed_dim, cfg.num_heads
+        hd = C // nH
+        g = cfg.img_size // cfg.patch_size
+        cols = ops.im2col(pixel_values.to(BF16).contiguous(), cfg.patch_size, pk["patch_w"].shape[1])
+        x = ops.linear(cols, pk["patch_w"], enc.patch_embed.proj.bias)           # [B*g*g, C]
+        x = ops.add_rows(x, pk["pos"])
+        for i, blk in enumerate(enc.blocks):
+            glob = i in cfg.global_attn_indexes
+            ws = 0 if glob else cfg.window_size
+            y = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, 1e-6)
+            if ws:
+                y = ops.window_partition(y, B, g, g, ws)
+                side = ws
+                NB = B * ((g + ws - 1) // ws) ** 2
+            else:
+                side, NB = g, B
+            S = side * side
+            qkv = ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)          # [NB*S, 3C]: q | k | v, heads contiguous
+            strides = (S * 3 * C, hd, 3 * C)
+            rel_h, rel_w = ops.sam_relpos(qkv, strides, blk.attn.rel_pos_h, blk.attn.rel_pos_w, NB, nH, side, side, hd)
+            vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
+            att = torch.empty(NB * S, C, device=x.device, dtype=BF16)
+            ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
+                          scale_mode=0, q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
+            if ws:
+                o = ops.linear(att, blk.attn.proj.weight, blk.attn.proj.bias)
+                x = ops.window_unpartition_add(o, x, B, g, g, ws)
+            else:
+                x = ops.linear(att, blk.attn.proj.weight, blk.attn.proj.bias, residual=x)
+            y = ops.layernorm(x, blk.norm2.weight, blk.norm2.bias, 1e-6)
+            f = ops.linear(y, blk.mlp.lin1.weight, blk.mlp.lin1.bias, act="gelu")
+            x = ops.linear(f, blk.mlp.lin2.weight, blk.mlp.lin2.bias, residual=x)
+        x = ops.linear(x, pk["neck0"])
+        x = ops.layernorm2d_cl(x, enc.neck[1].weight, enc.neck[1].bias, 1e-6)
+        x = ops.linear(ops.im2col3x3(x, B, g, g), pk["neck2"])
+        x = ops.layernorm2d_cl(x, enc.neck[3].weight, enc.neck[3].bias, 1e-6)
+        return x.view(B, g * g, cfg.out_chans)
+
+    # -- prompt encoder (prompt_encoder.py:67-76,216-229) ----------------------------------------------------------
+    def dense_pe(self) -> torch.Tensor:
+        """Token-major [g*g, D] dense positional encoding.  A constant of the weights: evaluated once on the host with the
+        reference's exact bf16 op sequence (the Gaussian buffer is cast with the model, so the PE is computed in bf16)."""
+        if self._dense_pe is None:
+            gm = self.sam.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix
+            g = self.cfg.img_size // self.cfg.patch_size
+            m = gm.detach().cpu()
+            grid = torch.ones((g, g), dtype=m.dtype)
+            y = (grid.cumsum(dim=0) - 0.5) / g
+            x = (grid.cumsum(dim=1) - 0.5) / g
+            c = torch.stack([x, y], dim=-1)
+            c = 2 * c - 1
+            c = c @ m
+            c = 2 * math.pi * c
+            pe = torch.cat([torch.sin(c), torch.cos(c)], dim=-1)           # [g, g, D]
+            self._dense_pe = pe.reshape(g * g, -1).contiguous().to(gm.device)
+        return self._dense_pe
+
+    # -- mask decoder (mask_decoder.py:75-164, transformer.py) -----------------------------------------------------
+    def _attn(self, a, q_in, k_in, v_in, n, Sq, Sk, residual=None):
+        H = self.cfg.decoder_heads
+        Di = a.q_proj.weight.shape[0]
+        hd = Di // H
+        q = ops.linear(q_in, a.q_proj.weight, a.q_proj.bias)
+        k = ops.linear(k_in, a.k_proj.weight, a.k_proj.bias)
+        v = ops.linear(v_in, a.v_proj.weight, a.v_proj.bias)
+        vt = ops.transpose_v(v, Sk * Di, Di, n, Sk, H, hd)
+        att = torch.empty(n * Sq, Di, device=q.device, dtype=BF16)
+        ops.attention(q, k, vt, att, n, H, Sq, Sk, hd, (Sq * Di, hd, Di), (Sk * Di, hd, Di), (Sq * Di, hd, Di), None, causal=False,
+                      scale_mode=2, scale=math.sqrt(hd))
+        return ops.linear(att, a.out_proj.weight, a.out_proj.bias, residual=residual)
+
+    def _mlp3(self, m, x):
+        nl = len(m.layers)
+        for i, l in enumerate(m.layers):
+            x = ops.linear(x, l.weight, l.bias, act="relu" if i < nl - 1 else None)
+        return x
+
+    def decode(self, image_embedding_tm: torch.Tensor, text_embeds: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """image_embedding_tm [g*g, D] (one image), text_embeds [n, D] -> (masks [n, nm, 4g, 4g] bf16, iou [n, nm]).
+        Covers PromptEncoder.forward with text_embeds only (sparse = text, dense = no_mask_embed) + MaskDecoder.predict_masks."""
+        md, tr, pk = self.sam.mask_decoder, self.sam.mask_decoder.transformer, self.pk()
+        n, D = text_embeds.shape
+        P = image_embedding_tm.shape[0]
+        g = int(math.isqrt(P))
+        nm = md.mask_tokens.weight.shape[0]
+        out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], dim=0)                  # [1+nm, D]
+        tokens = torch.cat([out_tok.unsqueeze(0).expand(n, -1, -1), text_embeds.unsqueeze(1)], dim=1).contiguous()   # [n, T, D]
+        T = tokens.shape[1]
+        src = ops.add_rows(image_embedding_tm, self.sam.prompt_encoder.no_mask_embed.weight)     # + dense (no-mask) embedding
+        keys = src.unsqueeze(0).expand(n, -1, -1).contiguous().view(n * P, D)                    # repeat_interleave over prompts
+        pos = self.dense_pe()
+        qpe = tokens.view(n * T, D)
+        queries = qpe
+        for i, l in enumerate(tr.layers):
+            if i == 0:
+                queries = self._attn(l.self_attn, queries, queries, queries, n, T, T)
+            else:
+                q = ops.add_rows(queries, qpe)
+                queries = self._attn(l.self_attn, q, q, queries, n, T, T, residual=queries)
+            queries = ops.layernorm(queries, l.norm1.weight, l.norm1.bias, 1e-5)
+            q = ops.add_rows(queries, qpe)
+            k = ops.add_rows(keys, pos)
+            queries = self._attn(l.cross_attn_token_to_image, q, k, keys, n, T, P, residual=queries)
+            queries = ops.layernorm(queries, l.norm2.weight, l.norm2.bias, 1e-5)
+            m = ops.linear(queries, l.mlp.lin1.weight, l.mlp.lin1.bias, act="relu")
+            queries = ops.linear(m, l.mlp.lin2.weight, l.mlp.lin2.bias, residual=queries)
+            queries = ops.layernorm(queries, l.norm3.weight, l.norm3.bias, 1e-5)
+            q = ops.add_rows(queries, qpe)
+            k = ops.add_rows(keys, pos)
+            keys = self._attn(l.cross_attn_image_to_token, k, q, queries, n, P, T, residual=keys)
+            keys = ops.layernorm(keys, l.norm4.weight, l.norm4.bias, 1e-5)
+        q = ops.add_rows(queries, qpe)
+        k = ops.add_rows(keys, pos)
+        queries = self._attn(tr.final_attn_token_to_image, q, k, keys, n, T, P, residual=queries)
+        hs = ops.layernorm(queries, tr.norm_final_attn.weight, tr.norm_final_attn.bias, 1e-5).view(n, T, D)
+        # upscaling: ConvT(k2,s2) -> LN2d -> GELU -> ConvT(k2,s2) -> GELU, kept in blocked [cell][d1][d2][c] order
+        ln = md.output_upscaling[1]
+        y1 = ops.linear(keys, pk["up0_w"], pk["up0_b"])                                         # [n*P, 4*D/4]
+        y1 = ops.layernorm2d_cl(y1.view(-1, D // 4), ln.weight, ln.bias, 1e-6, gelu=True)        # [n*P*4, D/4]
+        y2 = ops.linear(y1, pk["up3_w"], pk["up3_b"], act="gelu")                                # [n*P*4, 4*D/8]
+        hyper = torch.stack([self._mlp3(md.output_hypernetworks_mlps[t], hs[:, 1 + t, :]) for t in range(nm)], dim=1).contiguous()
+        masks = ops.mask_matmul(hyper, y2, n, nm, D // 8, g)
+        iou = self._mlp3(md.iou_prediction_head, hs[:, 0, :])
+        return masks, iou
+
+    # -- Sam.postprocess_masks (sam.py:137-172) --------------------------------------------------------------------
+    def postprocess(self, masks: torch.Tensor, input_size, original_size) -> torch.Tensor:
+        """masks [n, H, W] (bf16/fp32, contiguous) -> fp32 [n, orig_h, orig_w]."""
+        s = self.cfg.img_size
+        up = ops.bilinear(masks, masks.shape[-2], masks.shape[-1], s, s)
+        return ops.bilinear(up, int(input_size[0]), int(input_size[1]), int(original_size[0]), int(original_size[1]))
