@@ -144,7 +144,8 @@ def test_mask_decoder_fixture_g7():
         masks, iou = eng.decode(emb_tm, text)
         low = masks[:, 0:1].float().cpu()
         sp, de = O.prompt_encoder_text(sd32, case["text_embeds"].float(), (64, 64))
-        truth, truth_iou = O.mask_decoder(sd32, emb.float(), O.dense_pe(sd32, (64, 64)), sp, de, False)
+        # fp32 "truth": same bf16-rounded weights/inputs and the same bf16-computed dense PE (part of the reference's semantics)
+        truth, truth_iou = O.mask_decoder(sd32, emb.float(), O.dense_pe(sd, (64, 64)).float(), sp, de, False)
         e_ref, e_hip = rel_err(case["low_res_masks"], truth), rel_err(low, truth)
         print(f"n={case['n']}: mask-logit err vs fp32 truth: reference bf16 {e_ref:.4f}, HIP {e_hip:.4f}; HIP vs reference {rel_err(low, case['low_res_masks']):.4f};"
               f" iou err {rel_err(iou[:, 0:1], case['iou']):.4f}")

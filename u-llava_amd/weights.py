@@ -10,7 +10,7 @@ Scale rules keep activations O(1) at any width so that tiny test models are as
 sensitive to kernel bugs as full-size ones:
   * norm weights            1 + 0.1 N(0,1)
   * biases (1-D "*.bias")   0.1 N(0,1)
-  * tables / tokens         0.5 N(0,1)   (embed_tokens, position/pos embeddings, *_token, class_embedding, rel_pos)
+  * tables / tokens         0.5 N(0,1)   (embed_tokens, position/pos embeddings, iou_token/mask_tokens, class_embedding, rel_pos)
   * Gaussian PE buffer      N(0,1)       (SAM positional_encoding_gaussian_matrix)
   * everything else (>=2-D) N(0,1) / sqrt(fan_in)
 `hf_init=True` switches to the reference's initializer_range recipe (N(0,0.02) weights,
@@ -22,7 +22,7 @@ from typing import Dict, Iterable, Tuple
 import torch
 
 _NORM_KEYS = ("norm", "layrnorm", "layer_norm", "neck.1.", "neck.3.", "output_upscaling.1.")
-_TABLE_KEYS = ("embed_tokens", "position_embedding", "pos_embed", "_token", "class_embedding", "rel_pos",
+_TABLE_KEYS = ("embed_tokens", "position_embedding", "pos_embed", "iou_token", "mask_tokens", "class_embedding", "rel_pos",
                "no_mask_embed", "point_embeddings", "not_a_point_embed")
 
 
