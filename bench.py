@@ -25,6 +25,8 @@ WORKLOADS = {
     # name: (image_size, prompt_tokens, per_gpu_batch, description)
     "c4": (336, 64, 32, "C4: ViT-L/14-336 + LLaMA-7B instruct forward, 336x336 image + 64-token prompt (S=643), batch 32/GPU"),
     "c2": (224, 64, 16, "C2: ViT-L/14-224 + LLaMA-7B VQA forward, 224x224 image + 64-token prompt (S=323), batch 16"),
+    # full RES path: + SAM ViT-H encoder on 1024x1024, 3 [SEG]+[LOC] rounds per sample, prompt-encoder + mask decoder + postprocess
+    "res": (224, 120, 8, "C3: full RES forward (ViT-L/14-224 + LLaMA-7B + SAM ViT-H 1024x1024 + MaskDecoder, 3 [SEG]/[LOC] per image), batch 8"),
 }
 PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 
@@ -51,15 +53,27 @@ def init_random_(model, seed):
             p.data.normal_(0.0, 0.02, generator=g)
 
 
-def build_model(image_size, device, seed=0):
+SEG, LOC = 32007, 32008
+
+
+def build_model(image_size, device, seed=0, with_sam=False):
     C = importlib.import_module("u-llava_amd.configuration")
-    M = importlib.import_module("u-llava_amd.modeling_core")
-    cfg = C.UllavaCoreConfig(vision_config=dict(image_size=image_size, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
-                             mm_token_ids=dict(MM), vocab_size=32011)
-    model = M.UllavaCoreForCausalLM(cfg, device=device)
-    init_random_(model, seed)
-    model.strict_checks = False        # no host sync inside the timed region (the check itself is covered by tests)
-    model.pack_weights()
+    llm = dict(vision_config=dict(image_size=image_size, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
+               mm_token_ids=dict(MM), vocab_size=32011)
+    if with_sam:
+        M = importlib.import_module("u-llava_amd.modeling_ullava")
+        model = M.UllavaForCausalLM(C.UllavaConfig(llm_config=llm, seg_token_idx=SEG, loc_token_idx=LOC), device=device)
+        init_random_(model, seed)
+        g = torch.Generator(device="cuda").manual_seed(seed + 1)
+        model.visual_model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.normal_(0.0, 1.0, generator=g)
+        core, cfg = model.llm, model.config.llm_config
+    else:
+        M = importlib.import_module("u-llava_amd.modeling_core")
+        cfg = C.UllavaCoreConfig(**llm)
+        model = core = M.UllavaCoreForCausalLM(cfg, device=device)
+        init_random_(model, seed)
+    core.strict_checks = False        # no host sync inside the timed region (the check itself is covered by tests)
+    core.pack_weights()
     return model, cfg
 
 
@@ -197,12 +211,25 @@ def main():
     image_size, prompt, batch, desc = WORKLOADS[a.workload]
     batch = a.batch or batch
 
-    model, cfg = build_model(image_size, dev, seed=rank)
+    res = a.workload == "res"
+    model, cfg = build_model(image_size, dev, seed=rank, with_sam=res)
     images, ids, mask = make_inputs(cfg, batch, prompt, dev, rank)
     S = ids.shape[1]
+    if res:
+        # three rounds per sample, each ending "... [SEG] ... [LOC]" (RefCOCO-shaped: valid region 768x1024 -> original 480x640)
+        for r in range(3):
+            ids[:, S - 10 - 40 * r] = SEG
+            ids[:, S - 5 - 40 * r] = LOC
+        g = torch.Generator(device="cuda").manual_seed(2000 + rank)
+        images_sam = torch.randn(batch, 3, 1024, 1024, device=dev, generator=g).to(torch.bfloat16)
+        sizes, resizes = [(480, 640)] * batch, [(768, 1024)] * batch
 
-    def step():
-        return model.forward(input_ids=ids, attention_mask=mask, images=images)
+        def step():
+            return model.forward(images_sam=images_sam, images=images, input_ids=ids, labels=None, attention_mask=mask,
+                                 mask_list=[None] * batch, size_list=sizes, resize_list=resizes, bbox_list=[None] * batch, inference=True)
+    else:
+        def step():
+            return model.forward(input_ids=ids, attention_mask=mask, images=images)
 
     with torch.no_grad():
         for _ in range(a.warmup):
@@ -219,17 +246,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # the path's only collective: a scalar over xGMI
-    elapsed = float(t.item())
-    total_images = batch * world * a.steps
-    value = total_images / elapsed
+    D = importlib.import_module("u-llava_amd.dist")
+    # the path's only collective: scalar MAX(elapsed) / SUM(images) over RCCL/xGMI
+    value, total_images, elapsed = D.global_rate(float(batch * a.steps), elapsed, device=dev)
 
     if rank == 0:
         P = (image_size // 14) ** 2
         flops_img = llama_flops(S, cfg.vocab_size) + clip_flops(P) + 2 * (P + 1) * 1024 * 4096
-        line = {"metric": "images/sec (ViT-L/14 + projector + LLaMA-7B multimodal forward)", "value": round(value, 3), "unit": "images/sec",
+        if res:
+            flops_img += 5.96e12 + 3 * 3.61e9          # SAM ViT-H encoder + 3 mask-decoder passes
+        line = {"metric": "images/sec (ViT-L/14 + projector + LLaMA-7B" + (" + SAM ViT-H RES" if res else "") + " multimodal forward)", "value": round(value, 3), "unit": "images/sec",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": desc, "per_gpu_batch": batch, "global_batch": batch * world, "seq_len": S, "image": image_size,

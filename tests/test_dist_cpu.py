@@ -1,0 +1,57 @@
+"""CPU, gloo, world_size 2: the N>1 aggregation used by bench.py (units summed, elapsed maxed) and the image sharding."""
+import importlib
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D = importlib.import_module("u-llava_amd.dist")
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = D.shard_range(257, r, w)                 # 257 images over 2 ranks: 129 + 128, contiguous, disjoint
+    units = float(hi - lo)
+    elapsed = 1.0 + 0.5 * rank                        # rank 1 is the slow one
+    rate, total, tmax = D.global_rate(units, elapsed)
+    dist.barrier()
+    q.put((rank, lo, hi, rate, total, tmax))
+    dist.destroy_process_group()
+
+
+def test_global_rate_and_sharding_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, lo0, hi0, rate0, tot0, t0), (_, lo1, hi1, rate1, tot1, t1) = out
+    assert (lo0, hi0, lo1, hi1) == (0, 129, 129, 257)
+    assert tot0 == tot1 == 257.0 and t0 == t1 == 1.5
+    assert abs(rate0 - 257.0 / 1.5) < 1e-9 and rate0 == rate1
+
+
+def test_single_process_rate_needs_no_group():
+    D = importlib.import_module("u-llava_amd.dist")
+    assert D.global_rate(64.0, 2.0) == (32.0, 64.0, 2.0)
+    assert [D.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
