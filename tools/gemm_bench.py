@@ -16,8 +16,9 @@ shapes = [("qkv", T, 12288, 4096, False), ("o", T, 4096, 4096, False), ("gateup"
 g = torch.Generator(device=dev).manual_seed(0)
 tot_f = tot_t = 0
 for name, M, N, K, sw in shapes:
-    x = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
-    w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)
+    PAD = int(os.environ.get("PADK", 0))          # row-stride experiment: operands become views of [rows, K + PAD] buffers
+    x = torch.randn(M, K + PAD, device=dev, generator=g).to(torch.bfloat16)[:, :K]
+    w = (torch.randn(N, K + PAD, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)[:, :K]
     out = torch.empty(M, N // 2 if sw else N, device=dev, dtype=torch.bfloat16)
     for _ in range(2):
         ops.linear(x, w, swiglu=sw, out=out)

@@ -35,6 +35,7 @@ struct AttnArgs {
     // SAM decomposed relative-position bias (image_encoder.py:354-392): S += rel_h[q, key / KW]; S += rel_w[q, key % KW]
     const bf16_t* rel_h; const bf16_t* rel_w;   // [B*H, Sq, KH] / [B*H, Sq, KW] or null
     int KH, KW;
+    float inv_kw;                       // 1 / KW
     float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
 };
 
@@ -51,7 +52,8 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
         if (p.scale_mode == 1) sv = rbf(sv * p.scale);
         else if (p.scale_mode == 2) sv = rbf(sv / p.scale);
         if (brow != nullptr) {
-            const int kh = min(j / p.KW, p.KH - 1), kw = j % p.KW;
+            // j / KW without the integer-division sequence: exact for j < 2^16, KW <= 256 (|err| << 0.5 / KW)
+            const int kh = min((int)(((float)j + 0.5f) * p.inv_kw), p.KH - 1), kw = j - kh * p.KW;
             sv = rbf(rbf(sv + bf2f(brow[kh])) + bf2f(brow[p.KH + kw]));
         }
         const uint32_t mb = (mk >> (8 * r)) & 0xff;
@@ -201,8 +203,10 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
                     const int row = ns * 16 + fr;
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
-                        acc = mfma16(kf, qf[ks], acc);
+                        if (ks * 32 < p.hd) {                    // k-steps that are pure head-dim padding are skipped
+                            const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
+                            acc = mfma16(kf, qf[ks], acc);
+                        }
                     }
                     const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
                     score_quad(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
@@ -393,8 +397,10 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
             const int row = ns * 16 + fr;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
-                acc = mfma16(kf, qf[ks], acc);
+                if (ks * 32 < p.hd) {
+                    const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
+                    acc = mfma16(kf, qf[ks], acc);
+                }
             }
             const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
             score_quad(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sq[ns * 2], sq[ns * 2 + 1]);
@@ -598,6 +604,7 @@ extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int
     a.causal = causal; a.scale_mode = scale_mode; a.scale = scale;
     a.zeros = (const bf16_t*)zeros;
     a.rel_h = (const bf16_t*)rel_h; a.rel_w = (const bf16_t*)rel_w; a.KH = (int)rel_kh; a.KW = (int)rel_kw; a.q_scale = q_scale;
+    a.inv_kw = rel_kw > 0 ? 1.0f / (float)rel_kw : 0.f;
     if ((rel_h == nullptr) != (rel_w == nullptr)) return ULL_ERR_ARG;
     if (rel_h && (rel_kh <= 0 || rel_kw <= 0 || rel_kh + rel_kw > 256 || rel_kh * rel_kw < Sk)) return ULL_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;

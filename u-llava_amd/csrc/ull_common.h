@@ -14,17 +14,18 @@ using f32x16_t = __attribute__((ext_vector_type(16))) float;  // 32x32 MFMA accu
 
 // ---- bf16 <-> f32 (round-to-nearest-even, identical to torch's c10::BFloat16) -------------
 ULL_DEV float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-ULL_DEV bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// f32 -> bf16 goes through the native __bf16 type so hipcc emits gfx950's v_cvt_pk_bf16_f32 (IEEE round-to-nearest-even,
+// two values per instruction) instead of a ~8-instruction integer sequence; bf16 -> f32 is a 16-bit shift.
+typedef __bf16 bf16x2_native_t __attribute__((ext_vector_type(2)));
+ULL_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 // Round an fp32 value through bf16: this is how the kernels reproduce the rounding points of the
 // reference's bf16 PyTorch graph (every torch op boundary stores bf16) inside fused epilogues.
-ULL_DEV float rbf(float f) { return bf2f(f2bf(f)); }
+ULL_DEV float rbf(float f) { return (float)(__bf16)f; }
 
-ULL_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+ULL_DEV uint32_t pack2bf(float lo, float hi) {
+    const bf16x2_native_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
 ULL_DEV void unpack8(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
