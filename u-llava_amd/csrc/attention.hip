@@ -39,29 +39,43 @@ struct AttnArgs {
     float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
 };
 
+// Compile-time "flavors" of the score epilogue.  The runtime-flag version (FL_RUNTIME) costs ~6 wave-uniform branches per
+// score element, which fragments the schedule (measured: SAM global attention 12 ms -> see profiles/); the hot callers
+// get straight-line code instead.
+constexpr int FL_RUNTIME = -1;   // every switch read from AttnArgs at run time (any combination)
+constexpr int FL_LLAMA = 0;      // S*scale, causal + key-padding mask            (hf llama eager_attention_forward)
+constexpr int FL_CLIP = 1;       // S*scale                                        (hf clip eager_attention_forward)
+constexpr int FL_SAM_ENC = 2;    // (q*scale) pre-scaled, + rel_h, + rel_w         (SAM image_encoder.py Attention)
+constexpr int FL_SAM_DEC = 3;    // S / sqrt(hd)                                   (SAM transformer.py Attention)
+
 // One lane's 4 consecutive scores of one query -> the reference's rounding chain -> two packed bf16 pairs.
 //   acc[r] = raw fp32 dot product for key j0 + r;  mk = 4 mask bytes (1 attend, 0 masked, 2 out of range)
 //   brow   = this query's bias row in LDS: [KH rel_h values | KW rel_w values], or null
+template <int FL>
 ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t mk, int qi, int koff, const bf16_t* brow,
                         uint32_t& lo, uint32_t& hi) {
-    uint16_t o[4];
+    const bool do_mul = FL == FL_RUNTIME ? p.scale_mode == 1 : (FL == FL_LLAMA || FL == FL_CLIP);
+    const bool do_div = FL == FL_RUNTIME ? p.scale_mode == 2 : (FL == FL_SAM_DEC);
+    const bool do_bias = FL == FL_RUNTIME ? brow != nullptr : (FL == FL_SAM_ENC);
+    const bool do_causal = FL == FL_RUNTIME ? p.causal != 0 : (FL == FL_LLAMA);
+    float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int j = j0 + r;
         float sv = rbf(acc[r]);
-        if (p.scale_mode == 1) sv = rbf(sv * p.scale);
-        else if (p.scale_mode == 2) sv = rbf(sv / p.scale);
-        if (brow != nullptr) {
+        if (do_mul) sv = rbf(sv * p.scale);
+        if (do_div) sv = rbf(sv / p.scale);
+        if (do_bias) {
             // j / KW without the integer-division sequence: exact for j < 2^16, KW <= 256 (|err| << 0.5 / KW)
             const int kh = min((int)(((float)j + 0.5f) * p.inv_kw), p.KH - 1), kw = j - kh * p.KW;
             sv = rbf(rbf(sv + bf2f(brow[kh])) + bf2f(brow[p.KH + kw]));
         }
         const uint32_t mb = (mk >> (8 * r)) & 0xff;
-        const bool allowed = (mb == 1) && (!p.causal || j <= qi + koff);
-        o[r] = (mb == 2) ? BF16_NEG_INF : (allowed ? f2bf(sv) : BF16_MIN);
+        const bool allowed = (mb == 1) && (!do_causal || j <= qi + koff);
+        o[r] = (mb == 2) ? -INFINITY : (allowed ? sv : -3.3895313892515355e38f);   // -inf / finfo(bf16).min, exact in bf16
     }
-    lo = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-    hi = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+    lo = pack2bf(o[0], o[1]);
+    hi = pack2bf(o[2], o[3]);
 }
 
 ULL_DEV uint4 scale_q8(const uint4& v, float sc) {
@@ -88,7 +102,7 @@ ULL_DEV int swz(int row) { return CPR >= 16 ? (row & 15) : CPR == 8 ? (row & 7) 
 // Block = 8 waves = 128 queries of one (batch, head); wave w owns queries q0+16w .. +16 against ALL keys.
 //   HDP : head dim padded to 32/64/128 (K-tile row = HDP bf16);  NT : max number of 64-key tiles held in registers.
 // Per lane the whole score/probability row segment lives in registers as packed bf16 (8 VGPRs per 64 keys).
-template <int HDP, int NT>
+template <int HDP, int NT, int FL>
 __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NWV = 8, BQ = 16 * NWV;
@@ -139,18 +153,18 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
             maskb[j] = m;
         }
         if (p.rel_h != nullptr) {           // this wave's 16 bias rows -> LDS (read back by the lanes that own each query)
-            const int bw = p.KH + p.KW;
-            bf16_t* dst = biasb + wave * 16 * bw;
+            const int bw = p.KH + p.KW, bp = bw + 2;   // +2 elements: odd dword pitch, the 16 query rows hit 16 different LDS banks
+            bf16_t* dst = biasb + wave * 16 * bp;
             for (int i = lane; i < 16 * bw; i += 64) {
                 const int r = i / bw, c = i % bw;
                 const int q = min(q0 + wave * 16 + r, p.Sq - 1);
                 const long row = (long)head * p.Sq + q;
-                dst[i] = (c < p.KH) ? p.rel_h[row * p.KH + c] : p.rel_w[row * p.KW + (c - p.KH)];
+                dst[r * bp + c] = (c < p.KH) ? p.rel_h[row * p.KH + c] : p.rel_w[row * p.KW + (c - p.KH)];
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bf16_t* brow = (p.rel_h != nullptr) ? biasb + (wave * 16 + fr) * (p.KH + p.KW) : nullptr;
+    const bf16_t* brow = (p.rel_h != nullptr) ? biasb + (wave * 16 + fr) * (p.KH + p.KW + 2) : nullptr;
 
     const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
     const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
                         }
                     }
                     const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
-                    score_quad(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
+                    score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
                 }
             }
         }
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
 //   pass 1  S tiles -> running row max and sum of exp (fp32; combined across the 4 lanes of a query at the end);
 //   pass 2  the same S tiles again (bit-identical), P = bf16(exp(S - max) / sum) straight into the P*V MFMA.
 // Nothing but O is written; K is read twice from L2 instead of S/P being materialised in HBM like the reference does.
-template <int HDP>
+template <int HDP, int FL>
 __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NWV = 8, BQ = 16 * NWV;
@@ -345,18 +359,18 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
             maskb[j] = m;
         }
         if (p.rel_h != nullptr) {
-            const int bw = p.KH + p.KW;
-            bf16_t* dst = biasb + wave * 16 * bw;
+            const int bw = p.KH + p.KW, bp = bw + 2;   // +2 elements: odd dword pitch, the 16 query rows hit 16 different LDS banks
+            bf16_t* dst = biasb + wave * 16 * bp;
             for (int i = lane; i < 16 * bw; i += 64) {
                 const int r = i / bw, c = i % bw;
                 const int q = min(q0 + wave * 16 + r, p.Sq - 1);
                 const long row = (long)head * p.Sq + q;
-                dst[i] = (c < p.KH) ? p.rel_h[row * p.KH + c] : p.rel_w[row * p.KW + (c - p.KH)];
+                dst[r * bp + c] = (c < p.KH) ? p.rel_h[row * p.KH + c] : p.rel_w[row * p.KW + (c - p.KH)];
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bf16_t* brow = (p.rel_h != nullptr) ? biasb + (wave * 16 + fr) * (p.KH + p.KW) : nullptr;
+    const bf16_t* brow = (p.rel_h != nullptr) ? biasb + (wave * 16 + fr) * (p.KH + p.KW + 2) : nullptr;
 
     const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
     const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
@@ -403,7 +417,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
                 }
             }
             const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
-            score_quad(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sq[ns * 2], sq[ns * 2 + 1]);
+            score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sq[ns * 2], sq[ns * 2 + 1]);
         }
     };
 
@@ -546,38 +560,68 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
     }
 }
 
-template <int HDP, int NT>
+template <int HDP, int NT, int FL>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
-    const int lds = 2 * TILE + NT * KT + (a.rel_h ? 8 * 16 * (a.KH + a.KW) * 2 : 0);
+    const int lds = 2 * TILE + NT * KT + (a.rel_h ? 8 * 16 * (a.KH + a.KW + 2) * 2 : 0);
     const int nq = (a.Sq + 127) / 128;
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL>), grid, dim3(512), lds, st, a);
     return ull_check_launch();
+}
+
+template <int HDP, int FL>
+int launch_long(const AttnArgs& a, hipStream_t st) {
+    constexpr int TILE = 64 * HDP * 2;
+    const int nt = (a.Sk + KT - 1) / KT;
+    const int lds = 4 * TILE + ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (a.KH + a.KW + 2) * 2 : 0);
+    if (lds > 160 * 1024) return ULL_ERR_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_long_kernel<HDP, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int nq = (a.Sq + 127) / 128;
+    const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
+    hipLaunchKernelGGL((attn_long_kernel<HDP, FL>), grid, dim3(512), lds, st, a);
+    return ull_check_launch();
+}
+
+// Which straight-line flavor (if any) the arguments correspond to.
+int flavor_of(const AttnArgs& a) {
+    if (a.scale_mode == 1 && a.causal && !a.rel_h && a.q_scale == 1.0f) return FL_LLAMA;
+    if (a.scale_mode == 1 && !a.causal && !a.rel_h && !a.key_mask && a.q_scale == 1.0f) return FL_CLIP;
+    if (a.scale_mode == 0 && !a.causal && a.rel_h && !a.key_mask) return FL_SAM_ENC;
+    if (a.scale_mode == 2 && !a.causal && !a.rel_h && !a.key_mask && a.q_scale == 1.0f) return FL_SAM_DEC;
+    return FL_RUNTIME;
 }
 
 template <int HDP>
 int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     const int nt = (a.Sk + KT - 1) / KT;
+    const int fl = flavor_of(a);
+    // specialised instantiations exist for the shapes on the u-LLaVA path; everything else takes the run-time-flag kernels
+    if constexpr (HDP == 128) {
+        if (fl == FL_LLAMA && nt <= 11) return launch_attn<128, 11, FL_LLAMA>(a, st);
+        if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
+        if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
+        if (fl == FL_SAM_ENC && nt > 16) return launch_long<128, FL_SAM_ENC>(a, st);
+    }
+    if constexpr (HDP == 64) {
+        if (fl == FL_CLIP && nt <= 5) return launch_attn<64, 5, FL_CLIP>(a, st);
+        if (fl == FL_CLIP && nt <= 11) return launch_attn<64, 11, FL_CLIP>(a, st);
+    }
+    if constexpr (HDP == 32) {
+        if (fl == FL_SAM_DEC && nt <= 5) return launch_attn<32, 5, FL_SAM_DEC>(a, st);
+        if (fl == FL_SAM_DEC && nt > 16) return launch_long<32, FL_SAM_DEC>(a, st);
+    }
     if constexpr (HDP < 128) {          // (the <128, 5> instantiation spills; hd=128 starts at the 11-tile variant)
-        if (nt <= 5) return launch_attn<HDP, 5>(a, st);
+        if (nt <= 5) return launch_attn<HDP, 5, FL_RUNTIME>(a, st);
     }
-    if (nt <= 11) return launch_attn<HDP, 11>(a, st);
-    if (nt <= 16) return launch_attn<HDP, 16>(a, st);
-    // > 1024 keys do not fit the register-resident score row: two-pass streaming kernel
-    constexpr int TILE = 64 * HDP * 2;
-    const int lds = 4 * TILE + ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (a.KH + a.KW) * 2 : 0);
-    if (lds > 160 * 1024) return ULL_ERR_LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_long_kernel<HDP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    const int nq = (a.Sq + 127) / 128;
-    const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_long_kernel<HDP>), grid, dim3(512), lds, st, a);
-    return ull_check_launch();
+    if (nt <= 11) return launch_attn<HDP, 11, FL_RUNTIME>(a, st);
+    if (nt <= 16) return launch_attn<HDP, 16, FL_RUNTIME>(a, st);
+    return launch_long<HDP, FL_RUNTIME>(a, st);     // > 1024 keys: two-pass streaming kernel
 }
 
 }  // namespace
