@@ -34,6 +34,30 @@ def test_gemm_plain(M, N, K):
     assert_close_bf16(y, _mm_ref(x, w), what=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(256 * 20 + 40, 256 * 13, 512, "plain"), (256 * 33, 256 * 8, 1024, "bias_resid"),
+                                          (256 * 9 + 3, 256 * 30, 256, "swiglu"), (4100, 32011, 128, "odd")])
+def test_gemm_streamk_tail(M, N, K, kind):
+    """Tile counts that are not a multiple of the CU count: the tail tiles are split along K and summed by the finalize kernel."""
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    x = _rand(M, K, seed=21)
+    if kind == "swiglu":
+        wg, wu = _rand(N // 2, K, seed=22, scale=K ** -0.5), _rand(N // 2, K, seed=23, scale=K ** -0.5)
+        y = ops.linear(x.to(DEV), M_.interleave_gate_up(wg, wu).to(DEV), swiglu=True)
+        ref = F.silu(_mm_ref(x, wg)) * _mm_ref(x, wu)
+    elif kind == "bias_resid":
+        w, b, r = _rand(N, K, seed=22, scale=K ** -0.5), _rand(N, seed=23), _rand(M, N, seed=24)
+        y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=r.to(DEV))
+        lin = F.linear(x.float(), w.float(), b.float()).to(BF)
+        # a 1-ulp flip of the (larger) Linear output survives the residual add: bound those few by the Linear's magnitude
+        assert_close_bf16(y, r + lin, what="stream-K bias_resid", outlier_frac=1e-5, outlier_floor=float(lin.float().abs().max()))
+        return
+    else:
+        w = _rand(N, K, seed=22, scale=K ** -0.5)
+        y = ops.linear(x.to(DEV), w.to(DEV))
+        ref = _mm_ref(x, w)
+    assert_close_bf16(y, ref, what=f"stream-K {kind}")
+
+
 def test_gemm_transpose_detecting():
     """A = I against an asymmetric W catches swapped operands / C layouts."""
     ops = pkg("ops")

@@ -41,6 +41,10 @@ struct GemmArgs {
     long ldx, ldw, ldc, ldr;
     int M, N, K, flags;
     int nbm, nbn;
+    // stream-K tail (big kernel only): tiles [t_full, nbm*nbn) are each computed by `sk` blocks over disjoint K ranges that
+    // dump raw fp32 accumulators into `ws` ([tile - t_full][slice][256][256]); gemm_splitk_finalize sums them + epilogue.
+    int t_full, sk;
+    float* ws;
 };
 
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0+1024) (lane-linear).
@@ -260,11 +264,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wm = wave >> 2;
-    const int nwg = p.nbm * p.nbn;
+    // Blocks [0, t_full) own one whole tile each (t_full is a multiple of the CU count, so those rounds are full); the
+    // remaining tiles -- which would otherwise occupy a few CUs for one more whole round -- are split `sk` ways along K.
     int bid = blockIdx.x;
-    {
+    int slice = 0;
+    const bool split = bid >= p.t_full;
+    if (!split) {
+        const int nwg = p.t_full;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective for any nwg
+    } else {
+        const int r = bid - p.t_full;
+        bid = p.t_full + r / p.sk;
+        slice = r % p.sk;
     }
     const int per_group = GROUP_M * p.nbn;
     const int gid = bid / per_group;
@@ -338,7 +350,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     };
 
-    const int nk = p.K / BK;                          // >= 2 (host dispatch)
+    int nk = p.K / BK;                                // >= 2 (host dispatch, also per K-slice)
+    if (split) {
+        const int kt0 = (int)((long)nk * slice / p.sk), kt1 = (int)((long)nk * (slice + 1) / p.sk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xsrc[i] += (long)kt0 * BK; wsrc[i] += (long)kt0 * BK; }
+        nk = kt1 - kt0;
+    }
     stage(0);
     stage(1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed, tile 1 in flight
@@ -372,6 +390,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
+    if (split) {
+        float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 8; ++j)
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 4; ++i)
+                *(f32x4_t*)(slab + (wm * 128 + j * 16 + fr) * BN + wn * 64 + i * 16 + fg * 4) = acc[i][j];
+        return;
+    }
     const int flags = p.flags;
     const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
     const bool out_f32 = flags & EPI_OUT_F32;
@@ -454,6 +481,72 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
 }
 
+// Sum the K-slices of the stream-K tail tiles and apply the same epilogue as the main kernel.  One thread per 4 output
+// columns (8 accumulator columns for SwiGLU).
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
+    const int flags = p.flags;
+    const bool swiglu = flags & EPI_SWIGLU;
+    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+    const bool out_f32 = flags & EPI_OUT_F32;
+    const int n_out_total = swiglu ? p.N / 2 : p.N;
+    const int tile_r = blockIdx.y;
+    const int pid = p.t_full + tile_r;
+    const int per_group = GROUP_M * p.nbn;
+    const int gid = pid / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(p.nbm - first_m, GROUP_M);
+    const int m0 = (first_m + (pid % per_group) % gsz) * BM, n0 = ((pid % per_group) / gsz) * BN;
+    const float* slab0 = p.ws + (long)tile_r * p.sk * (BM * BN);
+    const int quads_per_row = swiglu ? BN / 8 : BN / 4;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < BM * quads_per_row; q += gridDim.x * 256) {
+        const int ml = q / quads_per_row, qc = q % quads_per_row;
+        const int m = m0 + ml;
+        if (m >= p.M) continue;
+        float v[4];
+        int n;
+        if (swiglu) {
+            // accumulator columns: 32-wide groups of [16 gate | 16 up]; this thread: 4 gate + the matching 4 up columns
+            const int grp = qc / 4, off = (qc % 4) * 4;
+            float g[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.sk; ++s) {
+                const float* row = slab0 + (long)s * (BM * BN) + ml * BN + grp * 32 + off;
+                const f32x4_t a = *(const f32x4_t*)row, b = *(const f32x4_t*)(row + 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { g[r] += a[r]; u[r] += b[r]; }
+            }
+            n = n0 / 2 + grp * 16 + off;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rbf(rbf(act_silu(rbf(g[r]))) * rbf(u[r]));
+        } else {
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.sk; ++s) {
+                const f32x4_t a = *(const f32x4_t*)(slab0 + (long)s * (BM * BN) + ml * BN + qc * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a4[r] += a[r];
+            }
+            n = n0 + qc * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = a4[r];
+                if ((flags & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
+                if (!out_f32 || act || (flags & EPI_RESID)) t = rbf(t);
+                if (act == 1) t = act_quick_gelu_bf16(t);
+                else if (act == 2) t = rbf(act_gelu_erf(t));
+                else if (act == 3) t = fmaxf(t, 0.f);
+                v[r] = t;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= n_out_total) continue;
+            float t = v[r];
+            if (flags & EPI_RESID) t = rbf(bf2f(p.R[(long)m * p.ldr + n + r]) + t);
+            if (out_f32) ((float*)p.C)[(long)m * p.ldc + n + r] = t;
+            else ((bf16_t*)p.C)[(long)m * p.ldc + n + r] = f2bf(t);
+        }
+    }
+}
+
 }  // namespace big
 
 }  // namespace
@@ -480,10 +573,37 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
             (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
         }
         a.nbm = (int)((M + big::BM - 1) / big::BM); a.nbn = (int)((N + big::BN - 1) / big::BN);
+        // stream-K tail: whole rounds of one tile per CU, the remainder split along K (needs >= 2 K-steps per slice)
+        static int n_cu = 0;
+        static float* ws = nullptr;
+        static const bool no_sk = getenv("ULL_GEMM_NO_STREAMK") != nullptr;
+        constexpr int MAX_SLABS = 256;
+        if (!n_cu) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            if (hipMalloc(&ws, (size_t)MAX_SLABS * big::BM * big::BN * sizeof(float)) != hipSuccess) ws = nullptr;   // 64 MiB, once
+        }
+        const int T = a.nbm * a.nbn;
+        const int rem = T % n_cu;
+        int sk = 1;
+        if (!no_sk && ws && T > n_cu && rem > 0 && rem <= n_cu / 2) {
+            sk = n_cu / rem;
+            if (sk > 16) sk = 16;
+            const int nk = (int)(K / big::BK);
+            while (sk > 1 && nk / sk < 2) --sk;
+            if (rem * sk > MAX_SLABS) sk = MAX_SLABS / rem;
+        }
+        a.sk = sk > 1 ? sk : 1;
+        a.t_full = sk > 1 ? T - rem : T;
+        a.ws = ws;
+        const int grid = a.sk > 1 ? a.t_full + rem * a.sk : T;
         if (flags & EPI_SWIGLU)
-            hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(a.nbm * a.nbn), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
         else
-            hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(a.nbm * a.nbn), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+        if (a.sk > 1) hipLaunchKernelGGL(big::splitk_finalize_kernel, dim3(32, rem), dim3(256), 0, (hipStream_t)stream, a);
         return ull_check_launch();
     }
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
