@@ -481,6 +481,236 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
 }
 
+// Same kernel on v_mfma_f32_32x32x16_bf16 (half as many matrix instructions for the same fragment traffic; the 32x32 form
+// has the higher measured issue ceiling on gfx950: 2.38 vs 2.08 PF/s).  Wave tile 128(m) x 64(n) = 4 x 2 accumulators of
+// 16 registers.  LDS chunk swizzle p = c ^ ((row >> 1) & 7): the 16 rows of every ds_read_b128 lane group (rows are now
+// 32 apart per fragment) land on 16 distinct bank slots.
+struct Frags32 { uint4 w[2][2]; uint4 x[2][4]; };   // [k16 step within the half][fragment]
+
+template <bool SWIGLU>
+__global__ __launch_bounds__(512) void gemm256_m32_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+    int bid = blockIdx.x;
+    int slice = 0;
+    const bool split = bid >= p.t_full;
+    if (!split) {
+        const int nwg = p.t_full;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    } else {
+        const int r = bid - p.t_full;
+        bid = p.t_full + r / p.sk;
+        slice = r % p.sk;
+    }
+    const int per_group = GROUP_M * p.nbn;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(p.nbm - first_m, GROUP_M);
+    const int bm = first_m + (bid % per_group) % gsz;
+    const int bn = (bid % per_group) / gsz;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const int srow = lane >> 3;
+    const bf16_t* xsrc[4];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + srow;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        xsrc[i] = p.X + (long)min(m0 + r, p.M - 1) * p.ldx + chunk * 8;
+        wsrc[i] = p.W + (long)min(n0 + r, p.N - 1) * p.ldw + chunk * 8;
+    }
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    const uint32_t piece_off = wave * 4 * 1024;
+    auto stage = [&](int kt) {
+        const uint32_t bx = lds_base + (kt & 1) * SLOT_BYTES + piece_off;
+        const long ko = (long)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(xsrc[i] + ko, bx + i * 1024);
+            glds16(wsrc[i] + ko, bx + OP_BYTES + i * 1024);
+        }
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fsw = (lane >> 1) & 7;                       // ((row >> 1) & 7) for row = 32*k + fr
+    const int xoff = (wm * 128 + fr) * (BK * 2);
+    const int woff = OP_BYTES + (wn * 64 + fr) * (BK * 2);
+    auto read_frags = [&](int kt, int kk, Frags32& f) {
+        const char* base = smem + (kt & 1) * SLOT_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int off = ((((kk * 2 + q) * 2 + fh) ^ fsw) << 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) f.w[q][i] = *(const uint4*)(base + woff + i * 32 * (BK * 2) + off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f.x[q][j] = *(const uint4*)(base + xoff + j * 32 * (BK * 2) + off);
+        }
+    };
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma = [&](const Frags32& f) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = mfma32(f.w[q][i], f.x[q][j], acc[i][j]);
+    };
+    auto pipeline_hint = [&]() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA (32x32x16 = two 16x16x32's worth)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    };
+
+    int nk = p.K / BK;
+    if (split) {
+        const int kt0 = (int)((long)nk * slice / p.sk), kt1 = (int)((long)nk * (slice + 1) / p.sk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xsrc[i] += (long)kt0 * BK; wsrc[i] += (long)kt0 * BK; }
+        nk = kt1 - kt0;
+    }
+    stage(0);
+    stage(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags32 fa, fb;
+    read_frags(0, 0, fa);
+    for (int kt = 0; kt < nk - 2; ++kt) {
+        read_frags(kt, 1, fb);
+        mma(fa);
+        pipeline_hint();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(kt + 2);
+        read_frags(kt + 1, 0, fa);
+        mma(fb);
+        pipeline_hint();
+    }
+    {
+        const int kt = nk - 2;
+        read_frags(kt, 1, fb);
+        mma(fa);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(kt + 1, 0, fa);
+        mma(fb);
+        read_frags(kt + 1, 1, fb);
+        mma(fa);
+        mma(fb);
+    }
+
+    // ---- epilogue: acc[i][j][4*g + r] = D[n = n0 + wn*64 + i*32 + 8*g + 4*fh + r][m = m0 + wm*128 + j*32 + fr] ----------
+    if (split) {
+        float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j)
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 2; ++i)
+#pragma clang loop unroll(full)
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *(f32x4_t*)(slab + (wm * 128 + j * 32 + fr) * BN + wn * 64 + i * 32 + 8 * g + 4 * fh) = v;
+                }
+        return;
+    }
+    const int flags = p.flags;
+    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+    const bool out_f32 = flags & EPI_OUT_F32;
+    const int n_out_total = SWIGLU ? p.N / 2 : p.N;
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((n_out_total & 3) == 0) && (!(flags & EPI_RESID) || (p.ldr & 3) == 0);
+    auto emit = [&](int m, int n, float (&v)[4]) {
+        if (n >= n_out_total) return;
+        if (flags & EPI_RESID) {
+            const bf16_t* rp = p.R + (long)m * p.ldr + n;
+            if (vec_ok) {
+                const uint2 rv = *(const uint2*)rp;
+                v[0] = rbf(bf2f((bf16_t)(rv.x & 0xffff)) + v[0]);
+                v[1] = rbf(bf2f((bf16_t)(rv.x >> 16)) + v[1]);
+                v[2] = rbf(bf2f((bf16_t)(rv.y & 0xffff)) + v[2]);
+                v[3] = rbf(bf2f((bf16_t)(rv.y >> 16)) + v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out_total) v[r] = rbf(bf2f(rp[r]) + v[r]);
+            }
+        }
+        if (out_f32) {
+            float* cp = (float*)p.C + (long)m * p.ldc + n;
+            if (vec_ok) *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out_total) cp[r] = v[r];
+            }
+        } else {
+            bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
+            if (vec_ok) {
+                uint2 o;
+                o.x = pack2bf(v[0], v[1]);
+                o.y = pack2bf(v[2], v[3]);
+                *(uint2*)cp = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < n_out_total) cp[r] = f2bf(v[r]);
+            }
+        }
+    };
+#pragma clang loop unroll(full)
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 128 + j * 32 + fr;
+        if (m < p.M) {
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (SWIGLU) {
+                    // a 32-row fragment = [16 gate rows | 16 up rows]: register groups g (gate) and g+2 (up) pair up in-lane
+#pragma clang loop unroll(full)
+                    for (int g = 0; g < 2; ++g) {
+                        const int n = (n0 + wn * 64 + i * 32) / 2 + 8 * g + 4 * fh;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gt = rbf(acc[i][j][4 * g + r]);
+                            const float up = rbf(acc[i][j][4 * (g + 2) + r]);
+                            v[r] = rbf(rbf(act_silu(gt)) * up);
+                        }
+                        emit(m, n, v);
+                    }
+                } else {
+#pragma clang loop unroll(full)
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * fh;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = acc[i][j][4 * g + r];
+                            if ((flags & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
+                            if (!out_f32 || act || (flags & EPI_RESID)) t = rbf(t);
+                            if (act == 1) t = act_quick_gelu_bf16(t);
+                            else if (act == 2) t = rbf(act_gelu_erf(t));
+                            else if (act == 3) t = fmaxf(t, 0.f);
+                            v[r] = t;
+                        }
+                        emit(m, n, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Sum the K-slices of the stream-K tail tiles and apply the same epilogue as the main kernel.  One thread per 4 output
 // columns (8 accumulator columns for SwiGLU).
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
@@ -571,6 +801,8 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
             (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)big::gemm256_m32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)big::gemm256_m32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
         }
         a.nbm = (int)((M + big::BM - 1) / big::BM); a.nbn = (int)((N + big::BN - 1) / big::BN);
         // stream-K tail: whole rounds of one tile per CU, the remainder split along K (needs >= 2 K-steps per slice)
@@ -599,10 +831,20 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         a.t_full = sk > 1 ? T - rem : T;
         a.ws = ws;
         const int grid = a.sk > 1 ? a.t_full + rem * a.sk : T;
-        if (flags & EPI_SWIGLU)
-            hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+        // 32x32x16 variant: measured slower in this structure (1031-1094 vs 1163 TF/s on the LLaMA layer shapes,
+        // profiles/r01_gemm_notes.md); kept behind an env switch for A/B runs.
+        static const bool mfma32 = getenv("ULL_GEMM_MFMA32") != nullptr;
+        if (!mfma32) {
+            if (flags & EPI_SWIGLU)
+                hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+        } else {
+            if (flags & EPI_SWIGLU)
+                hipLaunchKernelGGL(big::gemm256_m32_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(big::gemm256_m32_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+        }
         if (a.sk > 1) hipLaunchKernelGGL(big::splitk_finalize_kernel, dim3(32, rem), dim3(256), 0, (hipStream_t)stream, a);
         return ull_check_launch();
     }

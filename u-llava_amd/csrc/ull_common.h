@@ -71,6 +71,13 @@ ULL_DEV f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// v_mfma_f32_32x32x16_bf16: D[32x32] += A[32x16] * B[16x32].
+//   operand A: lane l holds A[row = l&31][k = 8*(l>>5) + j];  operand B: lane l holds B[k = 8*(l>>5) + j][col = l&31]
+//   C/D      : lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+ULL_DEV f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 // ---- activations (computed in fp32 on a bf16-rounded input, like torch's bf16 CPU/GPU kernels)
 ULL_DEV float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 ULL_DEV float act_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
