@@ -39,6 +39,12 @@ extern "C" {
 int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                   int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
+/* The same Linear for decode steps (M <= 4 rows, K % 8 == 0): a pure weight stream, one wave per output feature, no LDS/MFMA.
+ * Same flags, layouts and rounding points as ull_gemm_bf16.  Reached from generate() after the prefill
+ * (models/ullava_core.py:357-395 keeps only the last token once a KV cache exists). */
+int ull_gemv_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
+                  int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+
 /* y = w * bf16(x * rsqrt(mean(x^2) + eps)).  hf: LlamaRMSNorm.forward. */
 int ull_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
 

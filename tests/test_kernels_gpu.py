@@ -58,6 +58,20 @@ def test_gemm_streamk_tail(M, N, K, kind):
     assert_close_bf16(y, ref, what=f"stream-K {kind}")
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+def test_gemv_decode_shapes(M):
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    K, N, I = 1088, 520, 352
+    x, w, b, r = _rand(M, K, seed=31), _rand(N, K, seed=32, scale=K ** -0.5), _rand(N, seed=33), _rand(M, N, seed=34)
+    assert_close_bf16(ops.linear(x.to(DEV), w.to(DEV)), _mm_ref(x, w), what="gemv plain")
+    t = F.linear(x.float(), w.float(), b.float()).to(BF)
+    assert_close_bf16(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act="gelu"), F.gelu(t), what="gemv bias+gelu")
+    assert_close_bf16(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=r.to(DEV)), r + t, what="gemv bias+residual")
+    wg, wu = _rand(I, K, seed=35, scale=K ** -0.5), _rand(I, K, seed=36, scale=K ** -0.5)
+    y = ops.linear(x.to(DEV), M_.interleave_gate_up(wg, wu).to(DEV), swiglu=True)
+    assert_close_bf16(y, F.silu(_mm_ref(x, wg)) * _mm_ref(x, wu), what="gemv swiglu")
+
+
 def test_gemm_transpose_detecting():
     """A = I against an asymmetric W catches swapped operands / C layouts."""
     ops = pkg("ops")

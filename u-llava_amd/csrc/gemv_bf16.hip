@@ -1,0 +1,101 @@
+// Decode-shape Linear for gfx950: C[M,N] = epilogue(X[M,K] * W[N,K]^T) with M <= 4 (token-by-token generation).
+//
+// reference: the same nn.Linear modules as gemm_bf16.hip, reached from `generate()` steps after the prefill
+// (models/ullava_core.py:357-395 prepare_inputs_for_generation keeps only the last token when a KV cache exists).
+//
+// At M <= 4 the op is a pure weight stream (LLaMA-7B: 13.5 GB per token), so there is no LDS staging and no MFMA: one wave
+// owns one output feature at a time, its 64 lanes stream that weight row with 16-byte loads (1 KiB per wave-instruction,
+// read exactly once), X comes from L1/L2, fp32 accumulation, wave reduction, same epilogues/rounding points as the GEMM.
+#include "ull_common.h"
+
+namespace {
+
+constexpr int EPI_BIAS = 1, EPI_ACT_SHIFT = 1, EPI_ACT_MASK = 3 << 1, EPI_RESID = 8, EPI_SWIGLU = 16, EPI_OUT_F32 = 32;
+constexpr int MAXM = 4;
+
+template <int M>
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ W, long ldw, void* C,
+                                                   long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, long ldr, int N, int K,
+                                                   int flags, int n_out) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave id
+    const int nwaves = gridDim.x * 4;
+    const bool swiglu = flags & EPI_SWIGLU;
+    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+    const int nchunk = K >> 3;
+    for (int o = gw; o < n_out; o += nwaves) {
+        // SwiGLU pack: output o <- gate row (o/16)*32 + o%16 and up row 16 below it
+        const int row0 = swiglu ? (o >> 4) * 32 + (o & 15) : o;
+        const bf16_t* w0 = W + (long)row0 * ldw;
+        const bf16_t* w1 = w0 + 16 * ldw;
+        float a0[M], a1[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) a0[m] = a1[m] = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            float wv[8], uv[8];
+            unpack8(*(const uint4*)(w0 + c * 8), wv);
+            if (swiglu) unpack8(*(const uint4*)(w1 + c * 8), uv);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                float xv[8];
+                unpack8(*(const uint4*)(X + (long)m * ldx + c * 8), xv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a0[m] += wv[j] * xv[j];
+                    if (swiglu) a1[m] += uv[j] * xv[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            a0[m] = wave_sum(a0[m]);
+            if (swiglu) a1[m] = wave_sum(a1[m]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                float t;
+                if (swiglu) {
+                    t = rbf(rbf(act_silu(rbf(a0[m]))) * rbf(a1[m]));
+                } else {
+                    t = a0[m];
+                    if (flags & EPI_BIAS) t += bf2f(bias[o]);
+                    if (!(flags & EPI_OUT_F32) || act || (flags & EPI_RESID)) t = rbf(t);
+                    if (act == 1) t = act_quick_gelu_bf16(t);
+                    else if (act == 2) t = rbf(act_gelu_erf(t));
+                    else if (act == 3) t = fmaxf(t, 0.f);
+                }
+                if (flags & EPI_RESID) t = rbf(bf2f(R[(long)m * ldr + o]) + t);
+                if (flags & EPI_OUT_F32) ((float*)C)[(long)m * ldc + o] = t;
+                else ((bf16_t*)C)[(long)m * ldc + o] = f2bf(t);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Same contract as ull_gemm_bf16 (flags, layouts) for M <= 4; K % 8 == 0.
+extern "C" int ull_gemv_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
+                             int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream) {
+    if (!X || !W || !C || M <= 0 || N <= 0 || K <= 0) return ULL_ERR_ARG;
+    if (M > MAXM || (K & 7) || (ldx & 7) || (ldw & 7)) return ULL_ERR_SHAPE;
+    if ((flags & EPI_BIAS) && !bias) return ULL_ERR_ARG;
+    if ((flags & EPI_RESID) && !R) return ULL_ERR_ARG;
+    if ((flags & EPI_SWIGLU) && ((N & 31) || (flags & (EPI_BIAS | EPI_ACT_MASK)))) return ULL_ERR_SHAPE;
+    const int n_out = (int)((flags & EPI_SWIGLU) ? N / 2 : N);
+    int blocks = (n_out + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+#define ULL_GV(MM)                                                                                                                        \
+    hipLaunchKernelGGL(gemv_kernel<MM>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)X, ldx, (const bf16_t*)W, ldw, C, ldc,              \
+                       (const bf16_t*)bias, (const bf16_t*)R, ldr, (int)N, (int)K, flags, n_out)
+    switch ((int)M) {
+        case 1: ULL_GV(1); break;
+        case 2: ULL_GV(2); break;
+        case 3: ULL_GV(3); break;
+        default: ULL_GV(4); break;
+    }
+#undef ULL_GV
+    return ull_check_launch();
+}

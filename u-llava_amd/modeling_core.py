@@ -125,6 +125,31 @@ class GenerateOutput(dict):
     __getattr__ = dict.__getitem__
 
 
+class KVCache:
+    """Per-layer K [B,H,Smax,hd] (post-RoPE) and V^T [B,H,hd,Smax] in the attention kernel's key-permuted layout, plus the
+    last-layer hidden states of every position seen so far (what `evaluate()` reads for [SEG]/[LOC] rows).  Truthy once a
+    prefill has been stored, like a non-empty HF past_key_values tuple."""
+
+    def __init__(self, n_layers, B, H, hd, smax, device):
+        self.smax = ((smax + 63) // 64) * 64
+        self.k = [torch.empty(B, H, self.smax, hd, device=device, dtype=BF16) for _ in range(n_layers)]
+        self.vt = [torch.zeros(B, H, hd, self.smax, device=device, dtype=BF16) for _ in range(n_layers)]
+        self.length = 0
+        self.last_hidden = []
+
+    def __bool__(self):
+        return self.length > 0
+
+    def __len__(self):
+        return len(self.k)
+
+    @staticmethod
+    def vt_slot(pos: int) -> int:
+        """column of key `pos` inside V^T (32-key blocks stored as slot 8g+4a+r <- key 16a+4g+r, see transpose_v)."""
+        w = pos & 31
+        return (pos & ~31) + 8 * ((w >> 2) & 3) + 4 * (w >> 4) + (w & 3)
+
+
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     """[I, K] x2 -> [2I, K] with rows [gate 16g..16g+15 | up 16g..16g+15] per group g (ULL_EPI_SWIGLU layout)."""
     I, K = gate.shape
@@ -315,38 +340,60 @@ class UllavaCoreForCausalLM(nn.Module):
             self._inv_freq = inv.to(device)
         return self._inv_freq
 
-    def _llama(self, inputs_embeds, attention_mask, position_ids, output_hidden_states):
+    def _llama(self, inputs_embeds, attention_mask, position_ids, output_hidden_states, cache: Optional[KVCache] = None):
+        """LlamaModel.forward.  cache=None: plain prefill.  cache empty: prefill that also fills the cache.  cache filled:
+        incremental step(s) -- the new tokens' q attend to cached K / V^T plus their own."""
         cfg = self.config
         pk = self._pk()
         B, S, D = inputs_embeds.shape
         H = cfg.num_attention_heads
         hd = D // H
         dev = inputs_embeds.device
+        past = cache.length if cache is not None else 0
         if position_ids is None:
-            pos = torch.arange(S, device=dev, dtype=torch.int64).repeat(B)
+            pos = (torch.arange(S, device=dev, dtype=torch.int64) + past).repeat(B)
         else:
             pos = position_ids.to(torch.int64).expand(B, S).reshape(-1).contiguous()
         key_mask = None if attention_mask is None else attention_mask.to(torch.int32).contiguous()
+        if cache is not None and past + S > cache.smax:
+            raise RuntimeError(f"KV cache too small: {past + S} > {cache.smax}")
         inv_freq = self._rope_inv_freq(dev)
         x = inputs_embeds.reshape(B * S, D)
         T = B * S
         all_h = []
-        for w in pk["llama"]:
+        for li, w in enumerate(pk["llama"]):
             if output_hidden_states:
                 all_h.append(x.view(B, S, D))
             y = ops.rmsnorm(x, w["ln1"], cfg.rms_norm_eps)
             qkv = ops.linear(y, w["w_qkv"])
             ops.rope_inplace(qkv, 3 * D, pos, inv_freq, T, 2 * H, hd)
-            vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
             att = torch.empty(T, D, device=dev, dtype=BF16)
-            ops.attention(qkv, qkv[:, D:], vt, att, B, H, S, S, hd, (S * 3 * D, hd, 3 * D), (S * 3 * D, hd, 3 * D), (S * D, hd, D),
-                          key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
+            if cache is None:
+                vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
+                ops.attention(qkv, qkv[:, D:], vt, att, B, H, S, S, hd, (S * 3 * D, hd, 3 * D), (S * 3 * D, hd, 3 * D), (S * D, hd, D),
+                              key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
+            else:
+                kc, vtc = cache.k[li], cache.vt[li]
+                kv = qkv.view(B, S, 3, H, hd)
+                if past == 0:
+                    kc[:, :, :S].copy_(kv[:, :, 1].permute(0, 2, 1, 3))
+                    ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd, pitch=cache.smax, out=vtc)
+                else:
+                    for t in range(S):                       # generation appends one token at a time
+                        kc[:, :, past + t].copy_(kv[:, t, 1])
+                        vtc[:, :, :, KVCache.vt_slot(past + t)].copy_(kv[:, t, 2])
+                Sk = past + S
+                ops.attention(qkv, kc, vtc, att, B, H, S, Sk, hd, (S * 3 * D, hd, 3 * D), (H * cache.smax * hd, cache.smax * hd, hd),
+                              (S * D, hd, D), key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
             x = ops.linear(att, w["w_o"], residual=x)
             y = ops.rmsnorm(x, w["ln2"], cfg.rms_norm_eps)
             a = ops.linear(y, w["w_gu"], swiglu=True)
             x = ops.linear(a, w["w_down"], residual=x)
         x = ops.rmsnorm(x, self.model.norm.weight, cfg.rms_norm_eps)
         last = x.view(B, S, D)
+        if cache is not None:
+            cache.length = past + S
+            cache.last_hidden.append(last)
         if output_hidden_states:
             all_h.append(last)
         return last, (tuple(all_h) if output_hidden_states else None)
@@ -360,15 +407,23 @@ class UllavaCoreForCausalLM(nn.Module):
         """reference :279-355 (same argument list)."""
         if output_attentions:
             raise NotImplementedError("attention probabilities never leave LDS on this path")
-        if past_key_values is not None:
-            raise NotImplementedError("incremental decoding is handled by generate(); forward() always runs a full prefill")
+        cache = None
+        if past_key_values is not None or use_cache:
+            if past_key_values is not None and not isinstance(past_key_values, KVCache):
+                raise NotImplementedError("past_key_values must be the KVCache returned by a previous forward(use_cache=True)")
+            cache = past_key_values
         output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         if inputs_embeds is None:
             ids, inputs_embeds = self.embed_images_videos(input_ids, images, videos)
             if inputs_embeds is None:
                 inputs_embeds = ops.embed_splice(ids.contiguous(), self.model.embed_tokens.weight, None, None, None)
-        last, all_h = self._llama(inputs_embeds, attention_mask, position_ids, output_hidden_states)
+        if use_cache and cache is None:
+            B_, S_ = inputs_embeds.shape[:2]
+            cache = KVCache(self.config.num_hidden_layers, B_, self.config.num_attention_heads,
+                            self.config.hidden_size // self.config.num_attention_heads,
+                            max(S_ + getattr(self, "_cache_headroom", 512), 64), inputs_embeds.device)
+        last, all_h = self._llama(inputs_embeds, attention_mask, position_ids, output_hidden_states, cache)
         logits = ops.linear(last, self.lm_head.weight)
         loss = None
         if labels is not None:
@@ -376,7 +431,7 @@ class UllavaCoreForCausalLM(nn.Module):
         if not return_dict:
             out = (logits,) + ((all_h,) if all_h is not None else ())
             return out
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=all_h, attentions=None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=all_h, attentions=None)
 
     __call__ = forward
 
@@ -400,24 +455,40 @@ class UllavaCoreForCausalLM(nn.Module):
     def generate(self, input_ids=None, images=None, videos=None, attention_mask=None, max_new_tokens=32, do_sample=False,
                  temperature=1.0, top_p=None, num_beams=1, no_repeat_ngram_size=None, stopping_criteria=None, eos_token_id=None,
                  output_hidden_states=False, return_dict_in_generate=False, use_cache=None, keep_last_step_only=False, **kwargs):
-        """Token-by-token decoding with the reference's no-KV-cache semantics (every step re-runs the multimodal prefill,
-        which is what the released checkpoints do: SURVEY 3.2).  Greedy (`do_sample=False`) is bit-reproducible; sampling
-        draws from torch's RNG on the softmax of logits/temperature with optional nucleus filtering."""
+        """Token-by-token decoding.  use_cache=False reproduces the reference checkpoints' behaviour (config.use_cache=False:
+        every step re-runs the multimodal prefill); use_cache=True (config default) prefills once and then streams
+        the weights once per token through the GEMV kernels with a KV cache.  Greedy (`do_sample=False`) is deterministic;
+        sampling draws from torch's RNG on softmax(logits / temperature) with optional nucleus filtering."""
         if num_beams != 1:
             raise NotImplementedError("beam search is not used by the reference callers (num_beams=1)")
+        use_cache = self.config.use_cache if use_cache is None else use_cache
         seq = input_ids
         steps_hidden = []
         eos = eos_token_id
-        for _ in range(max_new_tokens):
+        cache = None
+        self._cache_headroom = max_new_tokens + 1
+        for step in range(max_new_tokens):
             mask = torch.ones_like(seq) if attention_mask is None else torch.cat(
                 [attention_mask, attention_mask.new_ones(seq.shape[0], seq.shape[1] - attention_mask.shape[1])], dim=1)
-            out = self.forward(input_ids=seq, attention_mask=mask, images=images, videos=videos,
-                               output_hidden_states=output_hidden_states)
-            if output_hidden_states:
-                if keep_last_step_only:
-                    steps_hidden = [out.hidden_states]      # evaluate() only reads hidden_states[-1] (the last step)
+            if use_cache:
+                # KV-cached decoding (SURVEY 8(f) row 1): prefill once, then one token per step; vision runs once
+                if step == 0:
+                    out = self.forward(input_ids=seq, attention_mask=mask, images=images, videos=videos, use_cache=True)
                 else:
-                    steps_hidden.append(out.hidden_states)
+                    out = self.forward(input_ids=seq[:, -1:], attention_mask=mask, past_key_values=cache, use_cache=True)
+                cache = out.past_key_values
+                if output_hidden_states:
+                    # same tensor the no-cache path returns at this step: last-layer states of ALL positions so far
+                    steps_hidden = [(torch.cat(cache.last_hidden, dim=1),)]
+            else:
+                # the reference's released checkpoints run with use_cache=False: every step re-runs the multimodal prefill
+                out = self.forward(input_ids=seq, attention_mask=mask, images=images, videos=videos,
+                                   output_hidden_states=output_hidden_states)
+                if output_hidden_states:
+                    if keep_last_step_only:
+                        steps_hidden = [out.hidden_states]      # evaluate() only reads hidden_states[-1] (the last step)
+                    else:
+                        steps_hidden.append(out.hidden_states)
             logits = out.logits[:, -1].float()
             if do_sample and temperature and temperature > 0:
                 probs = torch.softmax(logits / temperature, dim=-1)

@@ -70,6 +70,17 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     lead = tuple(x.shape[:-1])
     if x.shape[-1] != K:
         raise RuntimeError(f"u-llava_amd.linear: K mismatch {x.shape[-1]} vs {K}")
+    if M <= 4 and K % 8 == 0:
+        # decode shape: weight-streaming GEMV (no padding, no MFMA)
+        n_out = N // 2 if swiglu else N
+        if out is None:
+            out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else BF16)
+        flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | \
+            (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0)
+        ldr = _rows(residual)[1] if residual is not None else 0
+        _lib.call("ull_gemv_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias), _p(residual), ldr, M, N, K, flags,
+                  _stream())
+        return out
     if K % 64:
         # The MFMA kernel consumes K in 64-wide DMA tiles.  Every real width on the path (1024, 1280, 4096, 5120,
         # 11008, 256, 128, 2048, 64, patch K padded by im2col) is a multiple of 64; only the tiny test models are not.
@@ -145,10 +156,11 @@ def rope_inplace(x: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_
     _lib.call("ull_rope_inplace_bf16", _p(x), row_stride, _p(positions), _p(inv_freq), tokens, n_heads, hd, _stream())
 
 
-def transpose_v(v: torch.Tensor, v_bs: int, v_ss: int, B: int, S: int, H: int, hd: int, pitch: Optional[int] = None) -> torch.Tensor:
+def transpose_v(v: torch.Tensor, v_bs: int, v_ss: int, B: int, S: int, H: int, hd: int, pitch: Optional[int] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(v, "v")
     pitch = pitch or ((S + 63) // 64) * 64
-    vt = torch.empty(B, H, hd, pitch, device=v.device, dtype=BF16)
+    vt = out if out is not None else torch.empty(B, H, hd, pitch, device=v.device, dtype=BF16)
     _lib.call("ull_transpose_v_bf16", _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, _stream())
     return vt
 
