@@ -45,6 +45,7 @@ struct GemmArgs {
     // dump raw fp32 accumulators into `ws` ([tile - t_full][slice][256][256]); gemm_splitk_finalize sums them + epilogue.
     int t_full, sk;
     float* ws;
+    int group_m;                     // tile raster: blocks walk `group_m` M-tiles before stepping to the next N-tile
 };
 
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0+1024) (lane-linear).
@@ -278,10 +279,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         bid = p.t_full + r / p.sk;
         slice = r % p.sk;
     }
-    const int per_group = GROUP_M * p.nbn;
+    const int per_group = p.group_m * p.nbn;
     const int gid = bid / per_group;
-    const int first_m = gid * GROUP_M;
-    const int gsz = min(p.nbm - first_m, GROUP_M);
+    const int first_m = gid * p.group_m;
+    const int gsz = min(p.nbm - first_m, p.group_m);
     const int bm = first_m + (bid % per_group) % gsz;
     const int bn = (bid % per_group) / gsz;
     const int m0 = bm * BM, n0 = bn * BN;
@@ -505,10 +506,10 @@ __global__ __launch_bounds__(512) void gemm256_m32_kernel(GemmArgs p) {
         bid = p.t_full + r / p.sk;
         slice = r % p.sk;
     }
-    const int per_group = GROUP_M * p.nbn;
+    const int per_group = p.group_m * p.nbn;
     const int gid = bid / per_group;
-    const int first_m = gid * GROUP_M;
-    const int gsz = min(p.nbm - first_m, GROUP_M);
+    const int first_m = gid * p.group_m;
+    const int gsz = min(p.nbm - first_m, p.group_m);
     const int bm = first_m + (bid % per_group) % gsz;
     const int bn = (bid % per_group) / gsz;
     const int m0 = bm * BM, n0 = bn * BN;
@@ -721,10 +722,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
     const int n_out_total = swiglu ? p.N / 2 : p.N;
     const int tile_r = blockIdx.y;
     const int pid = p.t_full + tile_r;
-    const int per_group = GROUP_M * p.nbn;
+    const int per_group = p.group_m * p.nbn;
     const int gid = pid / per_group;
-    const int first_m = gid * GROUP_M;
-    const int gsz = min(p.nbm - first_m, GROUP_M);
+    const int first_m = gid * p.group_m;
+    const int gsz = min(p.nbm - first_m, p.group_m);
     const int m0 = (first_m + (pid % per_group) % gsz) * BM, n0 = ((pid % per_group) / gsz) * BN;
     const float* slab0 = p.ws + (long)tile_r * p.sk * (BM * BN);
     const int quads_per_row = swiglu ? BN / 8 : BN / 4;
@@ -830,6 +831,9 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         a.sk = sk > 1 ? sk : 1;
         a.t_full = sk > 1 ? T - rem : T;
         a.ws = ws;
+        // measured sweep at M=20576 (profiles/r01_gemm_notes.md): 4 M-tiles x 8 N-tiles per XCD wave beats 8 x 4 by ~5 %
+        static const int group_m = getenv("ULL_GEMM_GROUP_M") ? atoi(getenv("ULL_GEMM_GROUP_M")) : 4;
+        a.group_m = group_m;
         const int grid = a.sk > 1 ? a.t_full + rem * a.sk : T;
         // 32x32x16 variant: measured slower in this structure (1031-1094 vs 1163 TF/s on the LLaMA layer shapes,
         // profiles/r01_gemm_notes.md); kept behind an env switch for A/B runs.
