@@ -17,6 +17,7 @@
 //
 // Also here: the QKV post-processing kernels (RoPE in place on q|k, V -> V^T with zero padding).
 #include "ull_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -99,13 +100,14 @@ ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */)
 template <int CPR>
 ULL_DEV int swz(int row) { return CPR >= 16 ? (row & 15) : CPR == 8 ? (row & 7) : ((row >> 2) & 3); }
 
-// Block = 8 waves = 128 queries of one (batch, head); wave w owns queries q0+16w .. +16 against ALL keys.
+// Block = NWV waves = 16*NWV queries of one (batch, head); wave w owns queries q0+16w .. +16 against ALL keys.
+// (NWV = 4 lets two blocks share a CU so one block's barrier / DMA waits overlap the other's MFMAs.)
 //   HDP : head dim padded to 32/64/128 (K-tile row = HDP bf16);  NT : max number of 64-key tiles held in registers.
 // Per lane the whole score/probability row segment lives in registers as packed bf16 (8 VGPRs per 64 keys).
-template <int HDP, int NT, int FL>
-__global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
+template <int HDP, int NT, int FL, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NWV = 8, BQ = 16 * NWV;
+    constexpr int BQ = 16 * NWV;
     constexpr int CPR = HDP / 8;          // 16-byte chunks per K-tile row
     constexpr int KROW = HDP * 2;         // K-tile row bytes
     constexpr int NKS = HDP / 32, NDS = HDP / 16;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(512) void attn_reg_kernel(AttnArgs p) {
             qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
             if (p.q_scale != 1.0f) qf[ks] = scale_q8(qf[ks], p.q_scale);
         }
-        for (int j = tid; j < nkt * KT; j += 512) {
+        for (int j = tid; j < nkt * KT; j += NWV * 64) {
             unsigned char m = 2;
             if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
             maskb[j] = m;
@@ -560,14 +562,14 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
     }
 }
 
-template <int HDP, int NT, int FL>
+template <int HDP, int NT, int FL, int NWV = 8>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
-    const int lds = 2 * TILE + NT * KT + (a.rel_h ? 8 * 16 * (a.KH + a.KW + 2) * 2 : 0);
-    const int nq = (a.Sq + 127) / 128;
+    const int lds = 2 * TILE + NT * KT + (a.rel_h ? NWV * 16 * (a.KH + a.KW + 2) * 2 : 0);
+    const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV>), grid, dim3(NWV * 64), lds, st, a);
     return ull_check_launch();
 }
 
@@ -603,14 +605,16 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     const int fl = flavor_of(a);
     // specialised instantiations exist for the shapes on the u-LLaVA path; everything else takes the run-time-flag kernels
     if constexpr (HDP == 128) {
-        if (fl == FL_LLAMA && nt <= 11) return launch_attn<128, 11, FL_LLAMA>(a, st);
+        static const bool w8 = getenv("ULL_ATTN_8WAVES") != nullptr;          // A/B switch
+        if (fl == FL_LLAMA && nt <= 11) return w8 ? launch_attn<128, 11, FL_LLAMA, 8>(a, st) : launch_attn<128, 11, FL_LLAMA, 4>(a, st);
         if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
         if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
         if (fl == FL_SAM_ENC && nt > 16) return launch_long<128, FL_SAM_ENC>(a, st);
     }
     if constexpr (HDP == 64) {
         if (fl == FL_CLIP && nt <= 5) return launch_attn<64, 5, FL_CLIP>(a, st);
-        if (fl == FL_CLIP && nt <= 11) return launch_attn<64, 11, FL_CLIP>(a, st);
+        static const bool w8c = getenv("ULL_ATTN_8WAVES") != nullptr;
+        if (fl == FL_CLIP && nt <= 11) return w8c ? launch_attn<64, 11, FL_CLIP, 8>(a, st) : launch_attn<64, 11, FL_CLIP, 4>(a, st);
     }
     if constexpr (HDP == 32) {
         if (fl == FL_SAM_DEC && nt <= 5) return launch_attn<32, 5, FL_SAM_DEC>(a, st);
