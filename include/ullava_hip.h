@@ -59,15 +59,16 @@ int ull_clip_embed_ln_bf16(const void* patch, int64_t ldp, const void* cls, cons
 /* Attention.  Sk <= 1024: score rows stay in registers; larger Sk: two-pass streaming kernel with the same rounding points.
  * hf: llama eager_attention_forward (causal + key padding mask), clip eager_attention_forward (no mask): scale_mode 1
  * multiplies after the matmul like both.  SAM encoder (image_encoder.py:235-260,354-392): q_scale = hd^-0.5 applied to Q
- * as a bf16 tensor op, scale_mode 0, rel_h [B*H,Sq,rel_kh] / rel_w [B*H,Sq,rel_kw] added to the bf16 scores one after the
- * other.  SAM decoder (transformer.py:220-242): scale_mode 2 divides by sqrt(hd).
+ * as a bf16 tensor op, scale_mode 0, and the decomposed rel-pos bias added to the bf16 scores (rel_h then rel_w): rel_mode 1 =
+ * rel_h [B*H,Sq,rel_kh] / rel_w [B*H,Sq,rel_kw] precomputed (ull_sam_relpos_bf16); rel_mode 2 = rel_h/rel_w are the module's raw
+ * rel_pos_h [2*rel_kh-1,hd] / rel_pos_w [2*rel_kw-1,hd] parameters and the kernel builds the tables itself on the MFMA.  SAM decoder (transformer.py:220-242): scale_mode 2 divides by sqrt(hd).
  * Q/K: [B,H,S,hd] by strides, hd contiguous.  Vt: [B,H,hd,vt_len] as written by ull_transpose_v_bf16 (vt_len % 64 == 0).
  * key_mask: int32 [B,Sk] (nonzero = attend) or NULL.  zeros: >= 16 readable zero bytes (head-dim padding source). */
 int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs, int64_t k_ss,
                        const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O, int64_t o_bs, int64_t o_hs,
                        int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal,
                        int scale_mode, float scale, float q_scale, const void* rel_h, const void* rel_w, int64_t rel_kh,
-                       int64_t rel_kw, const void* zeros, void* stream);
+                       int64_t rel_kw, int rel_mode, const void* zeros, void* stream);
 
 /* hf: apply_rotary_pos_emb on n_heads consecutive heads (q heads then k heads of a fused QKV row), in place.
  * positions int64 [tokens]; inv_freq float32 [hd/2] computed by the host exactly as LlamaRotaryEmbedding does. */

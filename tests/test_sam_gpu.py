@@ -64,6 +64,12 @@ def test_sam_encoder_attention(side, hd, nH, NB):
                   q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
     vmax = float(qkv[:, 2 * C:].float().abs().max())
     assert_close_bf16(att, ref, ulps=2.0, what=f"sam attention side={side}", outlier_frac=2e-3, outlier_floor=vmax)
+    # fused path: the kernel builds the bias tables from the raw rel_pos parameters (Toeplitz product on the MFMA)
+    att2 = torch.empty_like(att)
+    ops.attention(qkv, qkv[:, C:], vt, att2, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
+                  q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side))
+    # (MFMA vs sequential fp32 accumulation order may flip a bf16 rounding of a table entry, so compare with the reference)
+    assert_close_bf16(att2, ref, ulps=2.0, what=f"sam attention (fused rel-pos) side={side}", outlier_frac=2e-3, outlier_floor=vmax)
 
 
 @pytest.mark.parametrize("Sq,Sk,hd", [(6, 4096, 16), (4096, 6, 16), (6, 6, 32), (130, 1500, 64)])

@@ -20,7 +20,7 @@ SIGNATURES = {
     "ull_layernorm_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "ull_clip_embed_ln_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
     "ull_attention_bf16": [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64,
-                           _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _ptr, _ptr, _i64, _i64, _ptr, _ptr],
+                           _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _ptr, _ptr, _i64, _i64, _i32, _ptr, _ptr],
     "ull_rope_inplace_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "ull_transpose_v_bf16": [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_im2col_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],

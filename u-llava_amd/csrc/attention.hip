@@ -36,6 +36,8 @@ struct AttnArgs {
     // SAM decomposed relative-position bias (image_encoder.py:354-392): S += rel_h[q, key / KW]; S += rel_w[q, key % KW]
     const bf16_t* rel_h; const bf16_t* rel_w;   // [B*H, Sq, KH] / [B*H, Sq, KW] or null
     int KH, KW;
+    int rel_mode;                       // 1: rel_h/rel_w are per-query tables [B*H,Sq,KH|KW]; 2: they are the raw rel_pos_h/w parameters
+                                        //    [2KH-1,hd] / [2KW-1,hd] and the tables are built in the kernel prologue on the MFMA
     float inv_kw;                       // 1 / KW
     float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
 };
@@ -51,10 +53,10 @@ constexpr int FL_SAM_DEC = 3;    // S / sqrt(hd)                                
 
 // One lane's 4 consecutive scores of one query -> the reference's rounding chain -> two packed bf16 pairs.
 //   acc[r] = raw fp32 dot product for key j0 + r;  mk = 4 mask bytes (1 attend, 0 masked, 2 out of range)
-//   brow   = this query's bias row in LDS: [KH rel_h values | KW rel_w values], or null
+//   brow   = this query's bias row in LDS, rel_h(kh) = brow[bh_off - kh], rel_w(kw) = brow[bw_off - kw]; or null
 template <int FL>
-ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t mk, int qi, int koff, const bf16_t* brow,
-                        uint32_t& lo, uint32_t& hi) {
+ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t mk, int qi, int koff, const bf16_t* brow, int bh_off,
+                        int bw_off, uint32_t& lo, uint32_t& hi) {
     const bool do_mul = FL == FL_RUNTIME ? p.scale_mode == 1 : (FL == FL_LLAMA || FL == FL_CLIP);
     const bool do_div = FL == FL_RUNTIME ? p.scale_mode == 2 : (FL == FL_SAM_DEC);
     const bool do_bias = FL == FL_RUNTIME ? brow != nullptr : (FL == FL_SAM_ENC);
@@ -69,7 +71,7 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
         if (do_bias) {
             // j / KW without the integer-division sequence: exact for j < 2^16, KW <= 256 (|err| << 0.5 / KW)
             const int kh = min((int)(((float)j + 0.5f) * p.inv_kw), p.KH - 1), kw = j - kh * p.KW;
-            sv = rbf(rbf(sv + bf2f(brow[kh])) + bf2f(brow[p.KH + kw]));
+            sv = rbf(rbf(sv + bf2f(brow[bh_off - kh])) + bf2f(brow[bw_off - kw]));
         }
         const uint32_t mb = (mk >> (8 * r)) & 0xff;
         const bool allowed = (mb == 1) && (!do_causal || j <= qi + koff);
@@ -77,6 +79,62 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
     }
     lo = pack2bf(o[0], o[1]);
     hi = pack2bf(o[2], o[3]);
+}
+
+
+// Stage this wave's 16 relative-position bias rows in LDS (`dst`, row pitch `bp` elements, see bias_pitch()).
+//   rel_mode 1: copy the precomputed per-query tables (stored reversed so both modes index the same way);
+//   rel_mode 2: build them here: G[q][t] = bf16(q . rel_pos[t]) for every table row t on the MFMA (the reference's
+//               einsum("bhwc,hkc->bhwk") is a Toeplitz slice of exactly this product: rel_h[q][kh] = Gh[q][qy - kh + KH - 1]).
+// qf0 = the wave's UNSCALED query fragments.  Returns the two lookup offsets of this lane's query.
+template <int NKS>
+ULL_DEV void stage_rel_bias(const AttnArgs& p, bf16_t* dst, int bp, const uint4 (&qf0)[NKS], int q_first, long head, int lane,
+                            int& bh_off, int& bw_off) {
+    const int fr = lane & 15, fg = lane >> 4;
+    const int qi = min(q_first + fr, p.Sq - 1);
+    if (p.rel_mode == 1) {
+        const int bw = p.KH + p.KW;
+        for (int i = lane; i < 16 * bw; i += 64) {
+            const int r = i / bw, c = i % bw;
+            const long row = head * p.Sq + min(q_first + r, p.Sq - 1);
+            if (c < p.KH) dst[r * bp + (p.KH - 1 - c)] = p.rel_h[row * p.KH + c];
+            else dst[r * bp + p.KH + (p.KW - 1 - (c - p.KH))] = p.rel_w[row * p.KW + (c - p.KH)];
+        }
+        bh_off = p.KH - 1;
+        bw_off = p.KH + p.KW - 1;
+    } else {
+        const int nth = 2 * p.KH - 1, ntw = 2 * p.KW - 1;
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const bf16_t* tab = which ? p.rel_w : p.rel_h;
+            const int nt = which ? ntw : nth, base = which ? nth : 0;
+            for (int st = 0; st * 16 < nt; ++st) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                const int t = min(st * 16 + fr, nt - 1);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const int d = ks * 32 + fg * 8;
+                    if (ks * 32 < p.hd) {
+                        const uint4 a = (d < p.hd) ? *(const uint4*)(tab + (long)t * p.hd + d) : make_uint4(0, 0, 0, 0);
+                        acc = mfma16(a, qf0[ks], acc);
+                    }
+                }
+                // acc[r] = G[t = st*16 + 4*fg + r][query fr]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tt = st * 16 + fg * 4 + r;
+                    if (tt < nt) dst[fr * bp + base + tt] = f2bf(acc[r]);
+                }
+            }
+        }
+        bh_off = qi / p.KW + p.KH - 1;
+        bw_off = nth + qi % p.KW + p.KW - 1;
+    }
+}
+
+ULL_DEV int bias_pitch(const AttnArgs& p) {       // elements; odd so the 16 query rows start in different LDS banks
+    const int n = p.rel_mode == 2 ? (2 * p.KH - 1) + (2 * p.KW - 1) : p.KH + p.KW;
+    return n | 1;
 }
 
 ULL_DEV uint4 scale_q8(const uint4& v, float sc) {
@@ -147,26 +205,25 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
             qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
-            if (p.q_scale != 1.0f) qf[ks] = scale_q8(qf[ks], p.q_scale);
         }
         for (int j = tid; j < nkt * KT; j += NWV * 64) {
             unsigned char m = 2;
             if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
             maskb[j] = m;
         }
-        if (p.rel_h != nullptr) {           // this wave's 16 bias rows -> LDS (read back by the lanes that own each query)
-            const int bw = p.KH + p.KW, bp = bw + 2;   // +2 elements: odd dword pitch, the 16 query rows hit 16 different LDS banks
-            bf16_t* dst = biasb + wave * 16 * bp;
-            for (int i = lane; i < 16 * bw; i += 64) {
-                const int r = i / bw, c = i % bw;
-                const int q = min(q0 + wave * 16 + r, p.Sq - 1);
-                const long row = (long)head * p.Sq + q;
-                dst[r * bp + c] = (c < p.KH) ? p.rel_h[row * p.KH + c] : p.rel_w[row * p.KW + (c - p.KH)];
-            }
-        }
+    }
+    const bf16_t* brow = nullptr;
+    int bh_off = 0, bw_off = 0;
+    if (p.rel_h != nullptr) {
+        const int bp = bias_pitch(p);
+        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off);
+        brow = biasb + (wave * 16 + fr) * bp;
+    }
+    if (p.q_scale != 1.0f) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = scale_q8(qf[ks], p.q_scale);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bf16_t* brow = (p.rel_h != nullptr) ? biasb + (wave * 16 + fr) * (p.KH + p.KW + 2) : nullptr;
 
     const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
     const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
@@ -225,7 +282,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
                         }
                     }
                     const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
-                    score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
+                    score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
                 }
             }
         }
@@ -353,26 +410,25 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
             qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
-            if (p.q_scale != 1.0f) qf[ks] = scale_q8(qf[ks], p.q_scale);
         }
         for (int j = tid; j < nkt * KT; j += 512) {
             unsigned char m = 2;
             if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
             maskb[j] = m;
         }
-        if (p.rel_h != nullptr) {
-            const int bw = p.KH + p.KW, bp = bw + 2;   // +2 elements: odd dword pitch, the 16 query rows hit 16 different LDS banks
-            bf16_t* dst = biasb + wave * 16 * bp;
-            for (int i = lane; i < 16 * bw; i += 64) {
-                const int r = i / bw, c = i % bw;
-                const int q = min(q0 + wave * 16 + r, p.Sq - 1);
-                const long row = (long)head * p.Sq + q;
-                dst[r * bp + c] = (c < p.KH) ? p.rel_h[row * p.KH + c] : p.rel_w[row * p.KW + (c - p.KH)];
-            }
-        }
+    }
+    const bf16_t* brow = nullptr;
+    int bh_off = 0, bw_off = 0;
+    if (p.rel_h != nullptr) {
+        const int bp = bias_pitch(p);
+        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off);
+        brow = biasb + (wave * 16 + fr) * bp;
+    }
+    if (p.q_scale != 1.0f) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = scale_q8(qf[ks], p.q_scale);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bf16_t* brow = (p.rel_h != nullptr) ? biasb + (wave * 16 + fr) * (p.KH + p.KW + 2) : nullptr;
 
     const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
     const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
@@ -419,7 +475,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
                 }
             }
             const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
-            score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, sq[ns * 2], sq[ns * 2 + 1]);
+            score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, sq[ns * 2], sq[ns * 2 + 1]);
         }
     };
 
@@ -565,7 +621,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 template <int HDP, int NT, int FL, int NWV = 8>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
-    const int lds = 2 * TILE + NT * KT + (a.rel_h ? NWV * 16 * (a.KH + a.KW + 2) * 2 : 0);
+    const int lds = 2 * TILE + NT * KT + (a.rel_h ? NWV * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
@@ -577,7 +633,7 @@ template <int HDP, int FL>
 int launch_long(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2;
     const int nt = (a.Sk + KT - 1) / KT;
-    const int lds = 4 * TILE + ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (a.KH + a.KW + 2) * 2 : 0);
+    const int lds = 4 * TILE + ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     if (lds > 160 * 1024) return ULL_ERR_LDS;
     static bool attr_set = false;
     if (!attr_set) {
@@ -637,7 +693,7 @@ extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int
                                   int64_t k_ss, const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O,
                                   int64_t o_bs, int64_t o_hs, int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq,
                                   int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, float q_scale, const void* rel_h,
-                                  const void* rel_w, int64_t rel_kh, int64_t rel_kw, const void* zeros, void* stream) {
+                                  const void* rel_w, int64_t rel_kh, int64_t rel_kw, int rel_mode, const void* zeros, void* stream) {
     if (!Q || !K || !Vt || !O || !zeros || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return ULL_ERR_ARG;
     if (hd <= 0 || hd > 128 || (hd & 15) || (vt_len & 63) || vt_len < ((Sk + 63) & ~63)) return ULL_ERR_SHAPE;
     if ((q_ss & 7) || (k_ss & 7) || (vt_ds & 7) || (q_hs & 7) || (k_hs & 7) || (q_bs & 7) || (k_bs & 7) || (vt_hs & 7) || (vt_bs & 7) ||
@@ -653,6 +709,8 @@ extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int
     a.zeros = (const bf16_t*)zeros;
     a.rel_h = (const bf16_t*)rel_h; a.rel_w = (const bf16_t*)rel_w; a.KH = (int)rel_kh; a.KW = (int)rel_kw; a.q_scale = q_scale;
     a.inv_kw = rel_kw > 0 ? 1.0f / (float)rel_kw : 0.f;
+    a.rel_mode = rel_h ? rel_mode : 0;
+    if (rel_h && rel_mode != 1 && rel_mode != 2) return ULL_ERR_ARG;
     if ((rel_h == nullptr) != (rel_w == nullptr)) return ULL_ERR_ARG;
     if (rel_h && (rel_kh <= 0 || rel_kw <= 0 || rel_kh + rel_kw > 256 || rel_kh * rel_kw < Sk)) return ULL_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;

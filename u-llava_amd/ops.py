@@ -139,15 +139,26 @@ def clip_embed_ln(patch: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, w: 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Sq: int, Sk: int, hd: int,
               q_strides, k_strides, o_strides, key_mask: Optional[torch.Tensor] = None, causal: bool = False, scale_mode: int = 1,
-              scale: float = 1.0, q_scale: float = 1.0, rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None):
-    """q/k/out are views into larger buffers: strides = (batch, head, seq) in elements.  vt [B, H, hd, pitch] contiguous."""
+              scale: float = 1.0, q_scale: float = 1.0, rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None,
+              rel_pos_hw: Optional[tuple] = None):
+    """rel_h/rel_w: either per-query bias tables [B*H, Sq, KH|KW] (from sam_relpos), or -- with rel_pos_hw=(KH, KW) -- the raw
+    rel_pos_h / rel_pos_w parameters [2KH-1, hd] / [2KW-1, hd], in which case the kernel builds the tables itself."""
     _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt"); _chk(out, "out")
+    rel_mode, kh, kw = 0, 0, 0
+    if rel_h is not None:
+        _chk(rel_h, "rel_h"); _chk(rel_w, "rel_w")
+        if rel_pos_hw is not None:
+            rel_mode, (kh, kw) = 2, rel_pos_hw
+            if rel_h.shape[0] != 2 * kh - 1 or rel_w.shape[0] != 2 * kw - 1 or rel_h.shape[1] != hd:
+                raise NotImplementedError("rel_pos interpolation (image_encoder.py:336-343) is not needed for 1024x1024 SAM inputs")
+        else:
+            rel_mode, kh, kw = 1, rel_h.shape[-1], rel_w.shape[-1]
     if key_mask is not None:
         _chk(key_mask, "key_mask", torch.int32)
     pitch = vt.shape[-1]
     _lib.call("ull_attention_bf16", _p(q), *q_strides, _p(k), *k_strides, _p(vt), H * hd * pitch, hd * pitch, pitch, pitch, _p(out),
               *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), float(q_scale), _p(rel_h), _p(rel_w),
-              0 if rel_h is None else rel_h.shape[-1], 0 if rel_w is None else rel_w.shape[-1], _zeros(q.device).data_ptr(), _stream())
+              kh, kw, rel_mode, _zeros(q.device).data_ptr(), _stream())
     return out
 
 

@@ -167,11 +167,10 @@ class SamEngine:
             S = side * side
             qkv = ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)          # [NB*S, 3C]: q | k | v, heads contiguous
             strides = (S * 3 * C, hd, 3 * C)
-            rel_h, rel_w = ops.sam_relpos(qkv, strides, blk.attn.rel_pos_h, blk.attn.rel_pos_w, NB, nH, side, side, hd)
             vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
             att = torch.empty(NB * S, C, device=x.device, dtype=BF16)
             ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
-                          scale_mode=0, q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
+                          scale_mode=0, q_scale=hd ** -0.5, rel_h=blk.attn.rel_pos_h, rel_w=blk.attn.rel_pos_w, rel_pos_hw=(side, side))
             if ws:
                 o = ops.linear(att, blk.attn.proj.weight, blk.attn.proj.bias)
                 x = ops.window_unpartition_add(o, x, B, g, g, ws)
