@@ -10,8 +10,39 @@
 namespace {
 
 // out[(img, py, px)][k], k = (c*ps + ky)*ps + kx  (the flattening of conv weight [D, C, ps, ps]); columns
-// [C*ps*ps, Kp) are zero so the GEMM can use K = Kp (multiple of 64).  `skip_rows_per_img` rows are left
-// untouched in front of every image's patches (not used: patches are written densely).
+// [C*ps*ps, Kp) are zero so the GEMM can use K = Kp (multiple of 64).
+// Fast path (even patch size, W % 8 == 0): one thread per 8-pixel chunk of an image row -> one coalesced 16-byte load and four
+// 4-byte stores (a dword never straddles a patch because ps and the chunk start are even).
+__global__ __launch_bounds__(256) void im2col_vec_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int C, int Hh, int Ww, int ps,
+                                                         int gw, int Kp, long total_chunks) {
+    const int cpr = Ww >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (long)gridDim.x * 256) {
+        const int x0 = (int)(i % cpr) * 8;
+        long t = i / cpr;
+        const int y = (int)(t % Hh);
+        t /= Hh;
+        const int c = (int)(t % C);
+        const long b = t / C;
+        const uint4 v = *(const uint4*)(img + ((b * C + c) * Hh + y) * (long)Ww + x0);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        const int py = y / ps, ky = y - py * ps;
+        const long rowbase = (b * (Hh / ps) + py) * (long)gw;
+        const int kbase = (c * ps + ky) * ps;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + 2 * j;
+            const int px = x / ps, kx = x - px * ps;
+            *(uint32_t*)(out + (rowbase + px) * Kp + kbase + kx) = d[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void im2col_zero_pad_kernel(bf16_t* __restrict__ out, int K, int Kp, long rows) {
+    const int padw = Kp - K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * padw; i += (long)gridDim.x * 256)
+        out[(i / padw) * Kp + K + (i % padw)] = 0;
+}
+
 __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int C, int Hh, int Ww, int ps,
                                                      int gh, int gw, int Kp, long total) {
     const int K = C * ps * ps;
@@ -139,6 +170,17 @@ extern "C" int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_
     const int gh = (int)(H / ps), gw = (int)(W / ps);
     const long total = n_img * gh * gw * Kp;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if ((ps & 1) == 0 && (W & 7) == 0 && (Kp & 1) == 0) {
+        const long chunks = n_img * C * H * (W >> 3);
+        const long rows = n_img * gh * gw;
+        const int K = (int)(C * ps * ps);
+        hipLaunchKernelGGL(im2col_vec_kernel, dim3((unsigned)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384)), dim3(256), 0,
+                           (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, (int)C, (int)H, (int)W, (int)ps, gw, (int)Kp, chunks);
+        if (Kp > K)
+            hipLaunchKernelGGL(im2col_zero_pad_kernel, dim3((unsigned)((rows * (Kp - K) + 255) / 256 < 4096 ? (rows * (Kp - K) + 255) / 256 : 4096)),
+                               dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, K, (int)Kp, rows);
+        return ull_check_launch();
+    }
     hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, (int)C, (int)H, (int)W,
                        (int)ps, gh, gw, (int)Kp, total);
     return ull_check_launch();

@@ -169,8 +169,17 @@ class SamEngine:
             strides = (S * 3 * C, hd, 3 * C)
             vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
             att = torch.empty(NB * S, C, device=x.device, dtype=BF16)
-            ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
-                          scale_mode=0, q_scale=hd ** -0.5, rel_h=blk.attn.rel_pos_h, rel_w=blk.attn.rel_pos_w, rel_pos_hw=(side, side))
+            if glob:
+                # 64x64 grid: 2 x 127 table rows per wave would be rebuilt by every one of the 32 query blocks of a head
+                # (measured +1.9 ms per layer at B=8), so the per-query tables are computed once by their own kernel
+                rel_h, rel_w = ops.sam_relpos(qkv, strides, blk.attn.rel_pos_h, blk.attn.rel_pos_w, NB, nH, side, side, hd)
+                ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
+                              scale_mode=0, q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
+            else:
+                # 14x14 windows: the 2 x 27-row tables are built inside the attention kernel (Toeplitz product on the MFMA)
+                ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
+                              scale_mode=0, q_scale=hd ** -0.5, rel_h=blk.attn.rel_pos_h, rel_w=blk.attn.rel_pos_w,
+                              rel_pos_hw=(side, side))
             if ws:
                 o = ops.linear(att, blk.attn.proj.weight, blk.attn.proj.bias)
                 x = ops.window_unpartition_add(o, x, B, g, g, ws)
