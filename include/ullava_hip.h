@@ -48,6 +48,11 @@ int ull_gemv_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* 
 /* y = w * bf16(x * rsqrt(mean(x^2) + eps)).  hf: LlamaRMSNorm.forward. */
 int ull_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
 
+/* models/ullava_core.py:327-338: shifted CrossEntropyLoss(logits[:, :-1], labels[:, 1:]), ignore_index -100.
+ * out float[2] = {sum of token losses, counted tokens} (caller zeroes it; loss = out[0] / out[1]). */
+int ull_shifted_cross_entropy_bf16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, void* out,
+                                   void* stream);
+
 /* torch.nn.LayerNorm over the last dim (hf CLIPEncoderLayer.layer_norm1/2; SAM Block.norm1/2, TwoWayAttentionBlock.norm1-4). */
 int ull_layernorm_bf16(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int64_t rows, int64_t D, float eps,
                        void* stream);

@@ -17,6 +17,7 @@ SIGNATURES = {
     "ull_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_gemv_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
+    "ull_shifted_cross_entropy_bf16": [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr],
     "ull_layernorm_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "ull_clip_embed_ln_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
     "ull_attention_bf16": [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64,

@@ -142,3 +142,40 @@ extern "C" int ull_clip_embed_ln_bf16(const void* patch, int64_t ldp, const void
     return launch_rownorm<1>((const bf16_t*)patch, ldp, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, n_img * tokens, (int)D, eps,
                              (const bf16_t*)cls, (const bf16_t*)pos, (int)tokens, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Shifted next-token cross entropy (reference models/ullava_core.py:327-338: CrossEntropyLoss over logits[..., :-1, :] vs
+// labels[..., 1:], ignore_index = -100, mean over the counted tokens).  One wave per (b, t) row: fp32 log-sum-exp over the
+// bf16 logits row, minus the label logit; block partials are accumulated with one atomic pair per wave.
+namespace {
+__global__ __launch_bounds__(256) void shifted_ce_kernel(const bf16_t* __restrict__ logits, long ld, const int64_t* __restrict__ labels, int B,
+                                                         int S, int V, float* __restrict__ out /* [loss_sum, count] */) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // over B * (S - 1)
+    if (row >= (long)B * (S - 1)) return;
+    const int b = (int)(row / (S - 1)), t = (int)(row % (S - 1));
+    const int64_t lab = labels[(long)b * S + t + 1];
+    if (lab < 0 || lab >= V) return;                                  // ignore_index (-100)
+    const bf16_t* lp = logits + ((long)b * S + t) * ld;
+    float m = -INFINITY;
+    for (int i = lane; i < V; i += 64) m = fmaxf(m, bf2f(lp[i]));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < V; i += 64) s += __expf(bf2f(lp[i]) - m);
+    s = wave_sum(s);
+    if (lane == 0) {
+        atomicAdd(out, m + __logf(s) - bf2f(lp[lab]));
+        atomicAdd(out + 1, 1.0f);
+    }
+}
+}  // namespace
+
+// out: float[2] = {sum of per-token losses, number of counted tokens}, must be zeroed by the caller.
+extern "C" int ull_shifted_cross_entropy_bf16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, void* out,
+                                              void* stream) {
+    if (!logits || !labels || !out || B <= 0 || S <= 1 || V <= 0) return ULL_ERR_ARG;
+    const long rows = B * (S - 1);
+    hipLaunchKernelGGL(shifted_ce_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld,
+                       (const int64_t*)labels, (int)B, (int)S, (int)V, (float*)out);
+    return ull_check_launch();
+}

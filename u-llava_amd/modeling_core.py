@@ -427,7 +427,7 @@ class UllavaCoreForCausalLM(nn.Module):
         logits = ops.linear(last, self.lm_head.weight)
         loss = None
         if labels is not None:
-            raise NotImplementedError("training loss is outside the forward hot path (SURVEY 8(a) row a16)")
+            loss = ops.shifted_cross_entropy(logits, labels)      # forward-only (no autograd on this path)
         if not return_dict:
             out = (logits,) + ((all_h,) if all_h is not None else ())
             return out

@@ -114,7 +114,7 @@ class UllavaForCausalLM(nn.Module):
         pad = torch.zeros((B, 1), dtype=torch.bool, device=input_ids.device)
         seg_token_mask = torch.cat([input_ids[:, 1:] == self.config.seg_token_idx, pad], dim=1)    # row t selected iff ids[t+1]==[SEG]
         loc_token_mask = torch.cat([input_ids[:, 1:] == self.config.loc_token_idx, pad], dim=1)
-        output = self.llm.forward(images=images, attention_mask=attention_mask, input_ids=input_ids, labels=None,
+        output = self.llm.forward(images=images, attention_mask=attention_mask, input_ids=input_ids, labels=labels,
                                   output_hidden_states=True)
         last = output.hidden_states[-1]
         pred_embeddings = self._select(last, seg_token_mask, self.seg_projector)

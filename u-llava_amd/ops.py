@@ -303,3 +303,12 @@ def bilinear(x: torch.Tensor, in_h: int, in_w: int, out_h: int, out_w: int) -> t
     out = torch.empty(n, out_h, out_w, device=x.device, dtype=torch.float32)
     _lib.call("ull_bilinear_f32", _p(x), int(x.dtype == BF16), Hf * Wf, Wf, in_h, in_w, _p(out), n, out_h, out_w, _stream())
     return out
+
+
+def shifted_cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """mean CE of logits[:, :-1] against labels[:, 1:] (ignore_index -100) -> 0-dim bf16 tensor like the reference's loss."""
+    _chk(logits, "logits"); _chk(labels, "labels", torch.int64)
+    B, S, V = logits.shape
+    acc = torch.zeros(2, device=logits.device, dtype=torch.float32)
+    _lib.call("ull_shifted_cross_entropy_bf16", _p(logits), logits.stride(1), _p(labels.contiguous()), B, S, V, _p(acc), _stream())
+    return (acc[0] / acc[1]).to(BF16)
