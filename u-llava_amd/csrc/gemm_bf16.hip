@@ -255,7 +255,7 @@ namespace big {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int OP_BYTES = BM * BK * 2;             // 32 KiB per operand per slot
 constexpr int SLOT_BYTES = 2 * OP_BYTES;          // 64 KiB
-constexpr int LDS_BYTES = 2 * SLOT_BYTES;         // 128 KiB -> one block (8 waves) per CU
+constexpr int LDS_BYTES = 8 * 128 * (64 * 2 + 16);   // 144 KiB: two 64-KiB K-tile slots, re-used by the 8 x 18-KiB epilogue regions
 
 struct Frags { uint4 w[4]; uint4 x[8]; };
 
@@ -399,6 +399,98 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
                 *(f32x4_t*)(slab + (wm * 128 + j * 16 + fr) * BN + wn * 64 + i * 16 + fg * 4) = acc[i][j];
         return;
+    }
+    // ---- LDS-staged epilogue (bf16 output, 16-byte-aligned rows): the scattered form below writes 16 rows x 32 B per store
+    // instruction; measured from the per-tile time of qkv vs gate/up, it costs ~20 us per 256x256 tile.  Here every wave parks
+    // its 128 x 64 (SwiGLU: 128 x 32) bf16 sub-tile in its own LDS region and writes it back as whole 128-byte rows.
+    {
+        const int flags_ = p.flags;
+        const int act_ = (flags_ & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+        const int n_out_ = SWIGLU ? p.N / 2 : p.N;
+        const bool staged_ok = !(flags_ & EPI_OUT_F32) && (p.ldc & 7) == 0 && (!(flags_ & EPI_RESID) || (p.ldr & 7) == 0);
+        if (staged_ok) {
+            constexpr int WCOLS = SWIGLU ? 32 : 64;            // output columns of this wave
+            constexpr int PITCH = WCOLS * 2 + 16;              // bytes; +16 keeps 16-byte alignment and spreads banks
+            __builtin_amdgcn_s_barrier();                      // every wave has consumed the last K-tile: LDS is free
+            char* reg = smem + wave * (128 * PITCH);
+#pragma clang loop unroll(full)
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (SWIGLU) {
+#pragma clang loop unroll(full)
+                    for (int ip = 0; ip < 2; ++ip) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float g = rbf(acc[2 * ip][j][r]);
+                            const float u = rbf(acc[2 * ip + 1][j][r]);
+                            v[r] = rbf(act_silu(g)) * u;
+                        }
+                        uint2 o;
+                        o.x = pack2bf(v[0], v[1]);
+                        o.y = pack2bf(v[2], v[3]);
+                        *(uint2*)(reg + (j * 16 + fr) * PITCH + (ip * 16 + fg * 4) * 2) = o;
+                    }
+                } else {
+#pragma clang loop unroll(full)
+                    for (int i = 0; i < 4; ++i) {
+                        const int n = n0 + wn * 64 + i * 16 + fg * 4;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = acc[i][j][r];
+                            if ((flags_ & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
+                            if (act_) {
+                                t = rbf(t);
+                                if (act_ == 1) t = act_quick_gelu_bf16(t);
+                                else if (act_ == 2) t = act_gelu_erf(t);
+                                else t = fmaxf(t, 0.f);
+                            }
+                            v[r] = t;
+                        }
+                        uint2 o;
+                        o.x = pack2bf(v[0], v[1]);
+                        o.y = pack2bf(v[2], v[3]);
+                        *(uint2*)(reg + (j * 16 + fr) * PITCH + (i * 16 + fg * 4) * 2) = o;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region only: no block barrier needed
+            constexpr int LPR = WCOLS / 8;                         // lanes per row (16 B each)
+            constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
+            const int ncol0 = SWIGLU ? (n0 + wn * 64) / 2 : n0 + wn * 64;
+#pragma unroll 4
+            for (int it = 0; it < 128 / RPI; ++it) {
+                const int row = it * RPI + lane / LPR, c8 = lane % LPR;
+                const int m = m0 + wm * 128 + row, n = ncol0 + c8 * 8;
+                if (m >= p.M || n >= n_out_) continue;
+                uint4 t = *(const uint4*)(reg + row * PITCH + c8 * 16);
+                if (n + 8 <= n_out_) {
+                    if (flags_ & EPI_RESID) {
+                        float a[8], b[8];
+                        unpack8(t, a);
+                        unpack8(*(const uint4*)(p.R + (long)m * p.ldr + n), b);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] += b[e];
+                        t = pack8(a);
+                    }
+#if defined(ULL_EPI_NT)
+                    { typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+                      __builtin_nontemporal_store(__builtin_bit_cast(u32x4_, t), (u32x4_*)((bf16_t*)p.C + (long)m * p.ldc + n)); }
+#else
+                    *(uint4*)((bf16_t*)p.C + (long)m * p.ldc + n) = t;
+#endif
+                } else {                                            // ragged last columns (N % 8 != 0)
+                    float a[8];
+                    unpack8(t, a);
+                    for (int e = 0; e < 8 && n + e < n_out_; ++e) {
+                        float x = a[e];
+                        if (flags_ & EPI_RESID) x = rbf(bf2f(p.R[(long)m * p.ldr + n + e]) + x);
+                        ((bf16_t*)p.C)[(long)m * p.ldc + n + e] = f2bf(x);
+                    }
+                }
+            }
+            return;
+        }
     }
     const int flags = p.flags;
     const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
