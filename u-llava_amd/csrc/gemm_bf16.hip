@@ -400,19 +400,84 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 *(f32x4_t*)(slab + (wm * 128 + j * 16 + fr) * BN + wn * 64 + i * 16 + fg * 4) = acc[i][j];
         return;
     }
-    // ---- LDS-staged epilogue (bf16 output, 16-byte-aligned rows): the scattered form below writes 16 rows x 32 B per store
-    // instruction; measured from the per-tile time of qkv vs gate/up, it costs ~20 us per 256x256 tile.  Here every wave parks
-    // its 128 x 64 (SwiGLU: 128 x 32) bf16 sub-tile in its own LDS region and writes it back as whole 128-byte rows.
+    // ---- LDS-staged epilogue.  Two things were measured on the previous register-direct form (profiles/r01_gemm_notes.md):
+    // scattered 16-row x 32-B stores, and -- much worse -- ~150 KiB of fully unrolled bias/activation/residual code per
+    // kernel (erf inlined 128 times), which streams through the 64-KiB instruction cache once per tile (~20 us per tile).
+    // So the unrolled part (register-indexed accumulators) only adds the bias, rounds and parks the wave's 128 x 64 sub-tile
+    // in the wave's own LDS region; everything flag-dependent runs in a small rolled loop that writes whole rows.
     {
-        const int flags_ = p.flags;
-        const int act_ = (flags_ & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
-        const int n_out_ = SWIGLU ? p.N / 2 : p.N;
-        const bool staged_ok = !(flags_ & EPI_OUT_F32) && (p.ldc & 7) == 0 && (!(flags_ & EPI_RESID) || (p.ldr & 7) == 0);
-        if (staged_ok) {
+        const int flags = p.flags;
+        const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+        const bool out_f32 = flags & EPI_OUT_F32;
+        const bool has_res = flags & EPI_RESID;
+        const int n_out = SWIGLU ? p.N / 2 : p.N;
+        const bool raw_f32 = !SWIGLU && out_f32 && !act && !has_res;       // fp32 result of the accumulator, never rounded
+        const bool c_al = out_f32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0;   // 16-byte row alignment of C / R
+        const bool r_al = (p.ldr & 7) == 0;
+        __builtin_amdgcn_s_barrier();                                      // every wave has consumed the last K-tile: LDS is free
+        char* reg = smem + wave * (128 * 144);                             // 18 KiB per wave
+        const int mrow0 = m0 + wm * 128;
+        const int ncol0 = SWIGLU ? (n0 + wn * 64) / 2 : n0 + wn * 64;
+
+        // finish 8 consecutive outputs of row m starting at column n: activation, residual, store
+        auto finish8 = [&](float (&a)[8], int m, int n) {
+            if (act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_bf16(a[e]);
+            } else if (act == 2) {
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e) a[e] = rbf(act_gelu_erf(a[e]));
+            } else if (act == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.f);
+            }
+            const bool full = n + 8 <= n_out;
+            if (has_res) {
+                const bf16_t* rp = p.R + (long)m * p.ldr + n;
+                if (full && r_al) {
+                    float b[8];
+                    unpack8(*(const uint4*)rp, b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = rbf(b[e] + a[e]);
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < n_out) a[e] = rbf(bf2f(rp[e]) + a[e]);
+                }
+            }
+            if (out_f32) {
+                float* cp = (float*)p.C + (long)m * p.ldc + n;
+                if (full && c_al) {
+                    *(float4*)cp = make_float4(a[0], a[1], a[2], a[3]);
+                    *(float4*)(cp + 4) = make_float4(a[4], a[5], a[6], a[7]);
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < n_out) cp[e] = a[e];
+                }
+            } else {
+                bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
+                if (full && c_al) {
+                    *(uint4*)cp = pack8(a);
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < n_out) cp[e] = f2bf(a[e]);
+                }
+            }
+        };
+
+        if (!raw_f32) {
             constexpr int WCOLS = SWIGLU ? 32 : 64;            // output columns of this wave
             constexpr int PITCH = WCOLS * 2 + 16;              // bytes; +16 keeps 16-byte alignment and spreads banks
-            __builtin_amdgcn_s_barrier();                      // every wave has consumed the last K-tile: LDS is free
-            char* reg = smem + wave * (128 * PITCH);
+            float bias_v[4][4];                                // -0.0f: x + (-0.0f) == x bit-for-bit when there is no bias
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
+                    bias_v[i][r] = (!SWIGLU && (flags & EPI_BIAS) && n < p.N) ? bf2f(p.bias[n]) : -0.0f;
+                }
 #pragma clang loop unroll(full)
             for (int j = 0; j < 8; ++j) {
                 if constexpr (SWIGLU) {
@@ -433,23 +498,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 } else {
 #pragma clang loop unroll(full)
                     for (int i = 0; i < 4; ++i) {
-                        const int n = n0 + wn * 64 + i * 16 + fg * 4;
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float t = acc[i][j][r];
-                            if ((flags_ & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
-                            if (act_) {
-                                t = rbf(t);
-                                if (act_ == 1) t = act_quick_gelu_bf16(t);
-                                else if (act_ == 2) t = act_gelu_erf(t);
-                                else t = fmaxf(t, 0.f);
-                            }
-                            v[r] = t;
-                        }
                         uint2 o;
-                        o.x = pack2bf(v[0], v[1]);
-                        o.y = pack2bf(v[2], v[3]);
+                        o.x = pack2bf(acc[i][j][0] + bias_v[i][0], acc[i][j][1] + bias_v[i][1]);
+                        o.y = pack2bf(acc[i][j][2] + bias_v[i][2], acc[i][j][3] + bias_v[i][3]);
                         *(uint2*)(reg + (j * 16 + fr) * PITCH + (i * 16 + fg * 4) * 2) = o;
                     }
                 }
@@ -457,352 +508,58 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region only: no block barrier needed
             constexpr int LPR = WCOLS / 8;                         // lanes per row (16 B each)
             constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
-            const int ncol0 = SWIGLU ? (n0 + wn * 64) / 2 : n0 + wn * 64;
-#pragma unroll 4
+#pragma unroll 2
             for (int it = 0; it < 128 / RPI; ++it) {
                 const int row = it * RPI + lane / LPR, c8 = lane % LPR;
-                const int m = m0 + wm * 128 + row, n = ncol0 + c8 * 8;
-                if (m >= p.M || n >= n_out_) continue;
-                uint4 t = *(const uint4*)(reg + row * PITCH + c8 * 16);
-                if (n + 8 <= n_out_) {
-                    if (flags_ & EPI_RESID) {
-                        float a[8], b[8];
-                        unpack8(t, a);
-                        unpack8(*(const uint4*)(p.R + (long)m * p.ldr + n), b);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) a[e] += b[e];
-                        t = pack8(a);
-                    }
-#if defined(ULL_EPI_NT)
-                    { typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-                      __builtin_nontemporal_store(__builtin_bit_cast(u32x4_, t), (u32x4_*)((bf16_t*)p.C + (long)m * p.ldc + n)); }
-#else
-                    *(uint4*)((bf16_t*)p.C + (long)m * p.ldc + n) = t;
-#endif
-                } else {                                            // ragged last columns (N % 8 != 0)
-                    float a[8];
-                    unpack8(t, a);
-                    for (int e = 0; e < 8 && n + e < n_out_; ++e) {
-                        float x = a[e];
-                        if (flags_ & EPI_RESID) x = rbf(bf2f(p.R[(long)m * p.ldr + n + e]) + x);
-                        ((bf16_t*)p.C)[(long)m * p.ldc + n + e] = f2bf(x);
-                    }
-                }
-            }
-            return;
-        }
-    }
-    const int flags = p.flags;
-    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
-    const bool out_f32 = flags & EPI_OUT_F32;
-    const int n_out_total = SWIGLU ? p.N / 2 : p.N;
-    const bool vec_ok = ((p.ldc & 3) == 0) && ((n_out_total & 3) == 0) && (!(flags & EPI_RESID) || (p.ldr & 3) == 0);
-    auto emit = [&](int m, int n, float (&v)[4]) {
-        if (n >= n_out_total) return;
-        if (flags & EPI_RESID) {
-            const bf16_t* rp = p.R + (long)m * p.ldr + n;
-            if (vec_ok) {
-                const uint2 rv = *(const uint2*)rp;
-                v[0] = rbf(bf2f((bf16_t)(rv.x & 0xffff)) + v[0]);
-                v[1] = rbf(bf2f((bf16_t)(rv.x >> 16)) + v[1]);
-                v[2] = rbf(bf2f((bf16_t)(rv.y & 0xffff)) + v[2]);
-                v[3] = rbf(bf2f((bf16_t)(rv.y >> 16)) + v[3]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) v[r] = rbf(bf2f(rp[r]) + v[r]);
-            }
-        }
-        if (out_f32) {
-            float* cp = (float*)p.C + (long)m * p.ldc + n;
-            if (vec_ok) *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) cp[r] = v[r];
+                const int m = mrow0 + row, n = ncol0 + c8 * 8;
+                if (m >= p.M || n >= n_out) continue;
+                float a[8];
+                unpack8(*(const uint4*)(reg + row * PITCH + c8 * 16), a);
+                finish8(a, m, n);
             }
         } else {
-            bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
-            if (vec_ok) {
-                uint2 o;
-                o.x = pack2bf(v[0], v[1]);
-                o.y = pack2bf(v[2], v[3]);
-                *(uint2*)cp = o;
-            } else {
+            // fp32 output of the bare accumulator (+bias): two passes of 64 rows x 64 fp32 columns through the same region
+            constexpr int PITCH = 64 * 4 + 16;
+            float bias_v[4][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) cp[r] = f2bf(v[r]);
-            }
-        }
-    };
-#pragma clang loop unroll(full)
-    for (int j = 0; j < 8; ++j) {
-        const int m = m0 + wm * 128 + j * 16 + fr;
-        if (m < p.M) {
-            if constexpr (SWIGLU) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int ip = 0; ip < 2; ++ip) {
-                    const int n = (n0 + wn * 64) / 2 + ip * 16 + fg * 4;
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float g = rbf(acc[2 * ip][j][r]);
-                        const float u = rbf(acc[2 * ip + 1][j][r]);
-                        v[r] = rbf(rbf(act_silu(g)) * u);
-                    }
-                    emit(m, n, v);
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
+                    bias_v[i][r] = ((flags & EPI_BIAS) && n < p.N) ? bf2f(p.bias[n]) : -0.0f;
                 }
-            } else {
 #pragma clang loop unroll(full)
-                for (int i = 0; i < 4; ++i) {
-                    const int n = n0 + wn * 64 + i * 16 + fg * 4;
-                    float v[4];
+            for (int h = 0; h < 2; ++h) {
+                if (h) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma clang loop unroll(full)
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = h * 4 + jj;
+#pragma clang loop unroll(full)
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4_t o = acc[i][j];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float t = acc[i][j][r];
-                        if ((flags & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
-                        if (!out_f32 || act || (flags & EPI_RESID)) t = rbf(t);
-                        if (act == 1) t = act_quick_gelu_bf16(t);
-                        else if (act == 2) t = rbf(act_gelu_erf(t));
-                        else if (act == 3) t = fmaxf(t, 0.f);
-                        v[r] = t;
+                        for (int r = 0; r < 4; ++r) o[r] += bias_v[i][r];
+                        *(f32x4_t*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fg * 4) * 4) = o;
                     }
-                    emit(m, n, v);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 2
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+                    const int m = mrow0 + h * 64 + row, n = ncol0 + c8 * 8;
+                    if (m >= p.M || n >= n_out) continue;
+                    const f32x4_t lo = *(const f32x4_t*)(reg + row * PITCH + c8 * 32);
+                    const f32x4_t hi = *(const f32x4_t*)(reg + row * PITCH + c8 * 32 + 16);
+                    float a[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    finish8(a, m, n);
                 }
             }
         }
     }
 }
 
-// Same kernel on v_mfma_f32_32x32x16_bf16 (half as many matrix instructions for the same fragment traffic; the 32x32 form
-// has the higher measured issue ceiling on gfx950: 2.38 vs 2.08 PF/s).  Wave tile 128(m) x 64(n) = 4 x 2 accumulators of
-// 16 registers.  LDS chunk swizzle p = c ^ ((row >> 1) & 7): the 16 rows of every ds_read_b128 lane group (rows are now
-// 32 apart per fragment) land on 16 distinct bank slots.
-struct Frags32 { uint4 w[2][2]; uint4 x[2][4]; };   // [k16 step within the half][fragment]
-
-template <bool SWIGLU>
-__global__ __launch_bounds__(512) void gemm256_m32_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 3, wm = wave >> 2;
-    int bid = blockIdx.x;
-    int slice = 0;
-    const bool split = bid >= p.t_full;
-    if (!split) {
-        const int nwg = p.t_full;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    } else {
-        const int r = bid - p.t_full;
-        bid = p.t_full + r / p.sk;
-        slice = r % p.sk;
-    }
-    const int per_group = p.group_m * p.nbn;
-    const int gid = bid / per_group;
-    const int first_m = gid * p.group_m;
-    const int gsz = min(p.nbm - first_m, p.group_m);
-    const int bm = first_m + (bid % per_group) % gsz;
-    const int bn = (bid % per_group) / gsz;
-    const int m0 = bm * BM, n0 = bn * BN;
-
-    const int srow = lane >> 3;
-    const bf16_t* xsrc[4];
-    const bf16_t* wsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + srow;
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        xsrc[i] = p.X + (long)min(m0 + r, p.M - 1) * p.ldx + chunk * 8;
-        wsrc[i] = p.W + (long)min(n0 + r, p.N - 1) * p.ldw + chunk * 8;
-    }
-    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    const uint32_t piece_off = wave * 4 * 1024;
-    auto stage = [&](int kt) {
-        const uint32_t bx = lds_base + (kt & 1) * SLOT_BYTES + piece_off;
-        const long ko = (long)kt * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(xsrc[i] + ko, bx + i * 1024);
-            glds16(wsrc[i] + ko, bx + OP_BYTES + i * 1024);
-        }
-    };
-
-    const int fr = lane & 31, fh = lane >> 5;
-    const int fsw = (lane >> 1) & 7;                       // ((row >> 1) & 7) for row = 32*k + fr
-    const int xoff = (wm * 128 + fr) * (BK * 2);
-    const int woff = OP_BYTES + (wn * 64 + fr) * (BK * 2);
-    auto read_frags = [&](int kt, int kk, Frags32& f) {
-        const char* base = smem + (kt & 1) * SLOT_BYTES;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int off = ((((kk * 2 + q) * 2 + fh) ^ fsw) << 4);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) f.w[q][i] = *(const uint4*)(base + woff + i * 32 * (BK * 2) + off);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) f.x[q][j] = *(const uint4*)(base + xoff + j * 32 * (BK * 2) + off);
-        }
-    };
-    f32x16_t acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto mma = [&](const Frags32& f) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][j] = mfma32(f.w[q][i], f.x[q][j], acc[i][j]);
-    };
-    auto pipeline_hint = [&]() {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA (32x32x16 = two 16x16x32's worth)
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    };
-
-    int nk = p.K / BK;
-    if (split) {
-        const int kt0 = (int)((long)nk * slice / p.sk), kt1 = (int)((long)nk * (slice + 1) / p.sk);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { xsrc[i] += (long)kt0 * BK; wsrc[i] += (long)kt0 * BK; }
-        nk = kt1 - kt0;
-    }
-    stage(0);
-    stage(1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    Frags32 fa, fb;
-    read_frags(0, 0, fa);
-    for (int kt = 0; kt < nk - 2; ++kt) {
-        read_frags(kt, 1, fb);
-        mma(fa);
-        pipeline_hint();
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        stage(kt + 2);
-        read_frags(kt + 1, 0, fa);
-        mma(fb);
-        pipeline_hint();
-    }
-    {
-        const int kt = nk - 2;
-        read_frags(kt, 1, fb);
-        mma(fa);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        read_frags(kt + 1, 0, fa);
-        mma(fb);
-        read_frags(kt + 1, 1, fb);
-        mma(fa);
-        mma(fb);
-    }
-
-    // ---- epilogue: acc[i][j][4*g + r] = D[n = n0 + wn*64 + i*32 + 8*g + 4*fh + r][m = m0 + wm*128 + j*32 + fr] ----------
-    if (split) {
-        float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
-#pragma clang loop unroll(full)
-        for (int j = 0; j < 4; ++j)
-#pragma clang loop unroll(full)
-            for (int i = 0; i < 2; ++i)
-#pragma clang loop unroll(full)
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    *(f32x4_t*)(slab + (wm * 128 + j * 32 + fr) * BN + wn * 64 + i * 32 + 8 * g + 4 * fh) = v;
-                }
-        return;
-    }
-    const int flags = p.flags;
-    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
-    const bool out_f32 = flags & EPI_OUT_F32;
-    const int n_out_total = SWIGLU ? p.N / 2 : p.N;
-    const bool vec_ok = ((p.ldc & 3) == 0) && ((n_out_total & 3) == 0) && (!(flags & EPI_RESID) || (p.ldr & 3) == 0);
-    auto emit = [&](int m, int n, float (&v)[4]) {
-        if (n >= n_out_total) return;
-        if (flags & EPI_RESID) {
-            const bf16_t* rp = p.R + (long)m * p.ldr + n;
-            if (vec_ok) {
-                const uint2 rv = *(const uint2*)rp;
-                v[0] = rbf(bf2f((bf16_t)(rv.x & 0xffff)) + v[0]);
-                v[1] = rbf(bf2f((bf16_t)(rv.x >> 16)) + v[1]);
-                v[2] = rbf(bf2f((bf16_t)(rv.y & 0xffff)) + v[2]);
-                v[3] = rbf(bf2f((bf16_t)(rv.y >> 16)) + v[3]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) v[r] = rbf(bf2f(rp[r]) + v[r]);
-            }
-        }
-        if (out_f32) {
-            float* cp = (float*)p.C + (long)m * p.ldc + n;
-            if (vec_ok) *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) cp[r] = v[r];
-            }
-        } else {
-            bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
-            if (vec_ok) {
-                uint2 o;
-                o.x = pack2bf(v[0], v[1]);
-                o.y = pack2bf(v[2], v[3]);
-                *(uint2*)cp = o;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) cp[r] = f2bf(v[r]);
-            }
-        }
-    };
-#pragma clang loop unroll(full)
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 128 + j * 32 + fr;
-        if (m < p.M) {
-#pragma clang loop unroll(full)
-            for (int i = 0; i < 2; ++i) {
-                if constexpr (SWIGLU) {
-                    // a 32-row fragment = [16 gate rows | 16 up rows]: register groups g (gate) and g+2 (up) pair up in-lane
-#pragma clang loop unroll(full)
-                    for (int g = 0; g < 2; ++g) {
-                        const int n = (n0 + wn * 64 + i * 32) / 2 + 8 * g + 4 * fh;
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float gt = rbf(acc[i][j][4 * g + r]);
-                            const float up = rbf(acc[i][j][4 * (g + 2) + r]);
-                            v[r] = rbf(rbf(act_silu(gt)) * up);
-                        }
-                        emit(m, n, v);
-                    }
-                } else {
-#pragma clang loop unroll(full)
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * fh;
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float t = acc[i][j][4 * g + r];
-                            if ((flags & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
-                            if (!out_f32 || act || (flags & EPI_RESID)) t = rbf(t);
-                            if (act == 1) t = act_quick_gelu_bf16(t);
-                            else if (act == 2) t = rbf(act_gelu_erf(t));
-                            else if (act == 3) t = fmaxf(t, 0.f);
-                            v[r] = t;
-                        }
-                        emit(m, n, v);
-                    }
-                }
-            }
-        }
-    }
-}
+// (A v_mfma_f32_32x32x16_bf16 variant of this kernel measured 6-11 % slower in this structure and was removed;
+// numbers in profiles/r01_gemm_notes.md.)
 
 // Sum the K-slices of the stream-K tail tiles and apply the same epilogue as the main kernel.  One thread per 4 output
 // columns (8 accumulator columns for SwiGLU).
@@ -894,8 +651,7 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
             (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)big::gemm256_m32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)big::gemm256_m32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+
         }
         a.nbm = (int)((M + big::BM - 1) / big::BM); a.nbn = (int)((N + big::BN - 1) / big::BN);
         // stream-K tail: whole rounds of one tile per CU, the remainder split along K (needs >= 2 K-steps per slice)
@@ -927,20 +683,10 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         static const int group_m = getenv("ULL_GEMM_GROUP_M") ? atoi(getenv("ULL_GEMM_GROUP_M")) : 4;
         a.group_m = group_m;
         const int grid = a.sk > 1 ? a.t_full + rem * a.sk : T;
-        // 32x32x16 variant: measured slower in this structure (1031-1094 vs 1163 TF/s on the LLaMA layer shapes,
-        // profiles/r01_gemm_notes.md); kept behind an env switch for A/B runs.
-        static const bool mfma32 = getenv("ULL_GEMM_MFMA32") != nullptr;
-        if (!mfma32) {
-            if (flags & EPI_SWIGLU)
-                hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
-            else
-                hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
-        } else {
-            if (flags & EPI_SWIGLU)
-                hipLaunchKernelGGL(big::gemm256_m32_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
-            else
-                hipLaunchKernelGGL(big::gemm256_m32_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
-        }
+        if (flags & EPI_SWIGLU)
+            hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
         if (a.sk > 1) hipLaunchKernelGGL(big::splitk_finalize_kernel, dim3(32, rem), dim3(256), 0, (hipStream_t)stream, a);
         return ull_check_launch();
     }
