@@ -60,6 +60,160 @@ ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
+// ---- LDS-staged epilogue shared by both kernels ------------------------------------------------------------------------
+// A wave owns JT*16 rows (m) x 64 W-rows (n): acc[i][j][r] = D[n = nw0 + i*16 + 4*(lane>>4) + r][m = mrow0 + j*16 + (lane&15)].
+// Two things were measured on the earlier register-direct form (profiles/r01_gemm_notes.md): scattered 16-row x 32-B stores,
+// and -- much worse -- ~150 KiB of fully unrolled bias/activation/residual code per kernel (erf inlined 128 times), which
+// streamed through the 64-KiB instruction cache once per tile (~15 us per 256x256 tile).  So the unrolled part (register-
+// indexed accumulators) only adds the bias, rounds and parks the sub-tile in the wave's own LDS region `reg`
+// (JT*16 rows x 144 B); everything flag-dependent runs in a small rolled loop that writes whole rows.
+// The caller has passed a block barrier after its last LDS fragment read.
+template <bool SWIGLU, int JT>
+ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg, int lane, int mrow0, int nw0) {
+    constexpr int ROWS = JT * 16;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int flags = p.flags;
+    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+    const bool out_f32 = flags & EPI_OUT_F32;
+    const bool has_res = flags & EPI_RESID;
+    const int n_out = SWIGLU ? p.N / 2 : p.N;
+    const bool raw_f32 = !SWIGLU && out_f32 && !act && !has_res;       // fp32 result of the accumulator, never rounded
+    const bool c_al = out_f32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0;   // 16-byte row alignment of C / R
+    const bool r_al = (p.ldr & 7) == 0;
+    const int ncol0 = SWIGLU ? nw0 / 2 : nw0;
+
+    // finish 8 consecutive outputs of row m starting at column n: activation, residual, store
+    auto finish8 = [&](float (&a)[8], int m, int n) {
+        if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_bf16(a[e]);
+        } else if (act == 2) {
+#pragma unroll 1
+            for (int e = 0; e < 8; ++e) a[e] = rbf(act_gelu_erf(a[e]));
+        } else if (act == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.f);
+        }
+        const bool full = n + 8 <= n_out;
+        if (has_res) {
+            const bf16_t* rp = p.R + (long)m * p.ldr + n;
+            if (full && r_al) {
+                float b[8];
+                unpack8(*(const uint4*)rp, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = rbf(b[e] + a[e]);
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < n_out) a[e] = rbf(bf2f(rp[e]) + a[e]);
+            }
+        }
+        if (out_f32) {
+            float* cp = (float*)p.C + (long)m * p.ldc + n;
+            if (full && c_al) {
+                *(float4*)cp = make_float4(a[0], a[1], a[2], a[3]);
+                *(float4*)(cp + 4) = make_float4(a[4], a[5], a[6], a[7]);
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < n_out) cp[e] = a[e];
+            }
+        } else {
+            bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
+            if (full && c_al) {
+                *(uint4*)cp = pack8(a);
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < n_out) cp[e] = f2bf(a[e]);
+            }
+        }
+    };
+
+    float bias_v[4][4];                                    // -0.0f: x + (-0.0f) == x bit-for-bit when there is no bias
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nw0 + i * 16 + fg * 4 + r;
+            bias_v[i][r] = (!SWIGLU && (flags & EPI_BIAS) && n < p.N) ? bf2f(p.bias[n]) : -0.0f;
+        }
+
+    if (!raw_f32) {
+        constexpr int WCOLS = SWIGLU ? 32 : 64;            // output columns of this wave
+        constexpr int PITCH = WCOLS * 2 + 16;              // bytes; +16 keeps 16-byte alignment and spreads banks
+#pragma clang loop unroll(full)
+        for (int j = 0; j < JT; ++j) {
+            if constexpr (SWIGLU) {
+                // W rows are interleaved in 16-row groups: [gate 16g..16g+15][up 16g..16g+15]
+#pragma clang loop unroll(full)
+                for (int ip = 0; ip < 2; ++ip) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = rbf(acc[2 * ip][j][r]);          // gate_proj output (bf16 tensor)
+                        const float u = rbf(acc[2 * ip + 1][j][r]);      // up_proj output (bf16 tensor)
+                        v[r] = rbf(act_silu(g)) * u;                     // silu -> bf16, product -> bf16 (by the pack)
+                    }
+                    uint2 o;
+                    o.x = pack2bf(v[0], v[1]);
+                    o.y = pack2bf(v[2], v[3]);
+                    *(uint2*)(reg + (j * 16 + fr) * PITCH + (ip * 16 + fg * 4) * 2) = o;
+                }
+            } else {
+#pragma clang loop unroll(full)
+                for (int i = 0; i < 4; ++i) {
+                    uint2 o;                                             // the Linear's bf16 output
+                    o.x = pack2bf(acc[i][j][0] + bias_v[i][0], acc[i][j][1] + bias_v[i][1]);
+                    o.y = pack2bf(acc[i][j][2] + bias_v[i][2], acc[i][j][3] + bias_v[i][3]);
+                    *(uint2*)(reg + (j * 16 + fr) * PITCH + (i * 16 + fg * 4) * 2) = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region only: no block barrier needed
+        constexpr int LPR = WCOLS / 8;                         // lanes per row (16 B each)
+        constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
+#pragma unroll 2
+        for (int it = 0; it < ROWS / RPI; ++it) {
+            const int row = it * RPI + lane / LPR, c8 = lane % LPR;
+            const int m = mrow0 + row, n = ncol0 + c8 * 8;
+            if (m >= p.M || n >= n_out) continue;
+            float a[8];
+            unpack8(*(const uint4*)(reg + row * PITCH + c8 * 16), a);
+            finish8(a, m, n);
+        }
+    } else {
+        // fp32 output of the bare accumulator (+bias): two passes of ROWS/2 rows x 64 fp32 columns through the same region
+        constexpr int PITCH = 64 * 4 + 16;
+        constexpr int JH = JT / 2;
+#pragma clang loop unroll(full)
+        for (int h = 0; h < 2; ++h) {
+#pragma clang loop unroll(full)
+            for (int jj = 0; jj < JH; ++jj) {
+#pragma clang loop unroll(full)
+                for (int i = 0; i < 4; ++i) {
+                    f32x4_t o = acc[i][h * JH + jj];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += bias_v[i][r];
+                    *(f32x4_t*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fg * 4) * 4) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 2
+            for (int it = 0; it < JH * 2; ++it) {
+                const int row = it * 8 + (lane >> 3), c8 = lane & 7;
+                const int m = mrow0 + h * (JH * 16) + row, n = ncol0 + c8 * 8;
+                if (m >= p.M || n >= n_out) continue;
+                const f32x4_t lo = *(const f32x4_t*)(reg + row * PITCH + c8 * 32);
+                const f32x4_t hi = *(const f32x4_t*)(reg + row * PITCH + c8 * 32 + 16);
+                float a[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                finish8(a, m, n);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this pass done before the next pass overwrites
+        }
+    }
+}
+
 template <bool SWIGLU>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,91 +304,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
         }
     }
 
-    // ---- epilogue -------------------------------------------------------------------------
-    // acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*(l>>4) + r][m = m0 + wm*64 + j*16 + (l&15)]
-    const int flags = p.flags;
-    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
-    const bool out_f32 = flags & EPI_OUT_F32;
-    const int n_out_total = SWIGLU ? p.N / 2 : p.N;
-    const bool vec_ok = ((p.ldc & 3) == 0) && ((n_out_total & 3) == 0) && (!(flags & EPI_RESID) || (p.ldr & 3) == 0);
-
-    auto emit = [&](int m, int n, float (&v)[4]) {
-        if (n >= n_out_total) return;
-        if (flags & EPI_RESID) {
-            const bf16_t* rp = p.R + (long)m * p.ldr + n;
-            if (vec_ok) {
-                const uint2 rv = *(const uint2*)rp;
-                v[0] = rbf(bf2f((bf16_t)(rv.x & 0xffff)) + v[0]);
-                v[1] = rbf(bf2f((bf16_t)(rv.x >> 16)) + v[1]);
-                v[2] = rbf(bf2f((bf16_t)(rv.y & 0xffff)) + v[2]);
-                v[3] = rbf(bf2f((bf16_t)(rv.y >> 16)) + v[3]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) v[r] = rbf(bf2f(rp[r]) + v[r]);
-            }
-        }
-        if (out_f32) {
-            float* cp = (float*)p.C + (long)m * p.ldc + n;
-            if (vec_ok) *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) cp[r] = v[r];
-            }
-        } else {
-            bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
-            if (vec_ok) {
-                uint2 o;
-                o.x = pack2bf(v[0], v[1]);
-                o.y = pack2bf(v[2], v[3]);
-                *(uint2*)cp = o;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < n_out_total) cp[r] = f2bf(v[r]);
-            }
-        }
-    };
-
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + frow;
-        if (m < p.M) {
-            if constexpr (SWIGLU) {
-                // W rows are interleaved in 16-row groups: [gate 16g..16g+15][up 16g..16g+15]
-#pragma unroll
-                for (int ip = 0; ip < 2; ++ip) {
-                    const int n = (n0 + wn * 64) / 2 + ip * 16 + fgrp * 4;
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float g = rbf(acc[2 * ip][j][r]);          // gate_proj output (bf16 tensor)
-                        const float u = rbf(acc[2 * ip + 1][j][r]);      // up_proj output (bf16 tensor)
-                        v[r] = rbf(rbf(act_silu(g)) * u);                // silu -> bf16, product -> bf16
-                    }
-                    emit(m, n, v);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = n0 + wn * 64 + i * 16 + fgrp * 4;
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float t = acc[i][j][r];
-                        if ((flags & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
-                        if (!out_f32 || act || (flags & EPI_RESID)) t = rbf(t);   // the Linear's bf16 output
-                        if (act == 1) t = act_quick_gelu_bf16(t);
-                        else if (act == 2) t = rbf(act_gelu_erf(t));
-                        else if (act == 3) t = fmaxf(t, 0.f);
-                        v[r] = t;
-                    }
-                    emit(m, n, v);
-                }
-            }
-        }
-    }
+    // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*(l>>4) + r][m = m0 + wm*64 + j*16 + (l&15)] --------------
+    __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
+    staged_epilogue<SWIGLU, 4>(p, acc, smem + wave * (64 * 144), lane, m0 + wm * 64, n0 + wn * 64);
 }
 
 
@@ -400,162 +472,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 *(f32x4_t*)(slab + (wm * 128 + j * 16 + fr) * BN + wn * 64 + i * 16 + fg * 4) = acc[i][j];
         return;
     }
-    // ---- LDS-staged epilogue.  Two things were measured on the previous register-direct form (profiles/r01_gemm_notes.md):
-    // scattered 16-row x 32-B stores, and -- much worse -- ~150 KiB of fully unrolled bias/activation/residual code per
-    // kernel (erf inlined 128 times), which streams through the 64-KiB instruction cache once per tile (~20 us per tile).
-    // So the unrolled part (register-indexed accumulators) only adds the bias, rounds and parks the wave's 128 x 64 sub-tile
-    // in the wave's own LDS region; everything flag-dependent runs in a small rolled loop that writes whole rows.
-    {
-        const int flags = p.flags;
-        const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
-        const bool out_f32 = flags & EPI_OUT_F32;
-        const bool has_res = flags & EPI_RESID;
-        const int n_out = SWIGLU ? p.N / 2 : p.N;
-        const bool raw_f32 = !SWIGLU && out_f32 && !act && !has_res;       // fp32 result of the accumulator, never rounded
-        const bool c_al = out_f32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0;   // 16-byte row alignment of C / R
-        const bool r_al = (p.ldr & 7) == 0;
-        __builtin_amdgcn_s_barrier();                                      // every wave has consumed the last K-tile: LDS is free
-        char* reg = smem + wave * (128 * 144);                             // 18 KiB per wave
-        const int mrow0 = m0 + wm * 128;
-        const int ncol0 = SWIGLU ? (n0 + wn * 64) / 2 : n0 + wn * 64;
-
-        // finish 8 consecutive outputs of row m starting at column n: activation, residual, store
-        auto finish8 = [&](float (&a)[8], int m, int n) {
-            if (act == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_bf16(a[e]);
-            } else if (act == 2) {
-#pragma unroll 1
-                for (int e = 0; e < 8; ++e) a[e] = rbf(act_gelu_erf(a[e]));
-            } else if (act == 3) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.f);
-            }
-            const bool full = n + 8 <= n_out;
-            if (has_res) {
-                const bf16_t* rp = p.R + (long)m * p.ldr + n;
-                if (full && r_al) {
-                    float b[8];
-                    unpack8(*(const uint4*)rp, b);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] = rbf(b[e] + a[e]);
-                } else {
-#pragma unroll 1
-                    for (int e = 0; e < 8; ++e)
-                        if (n + e < n_out) a[e] = rbf(bf2f(rp[e]) + a[e]);
-                }
-            }
-            if (out_f32) {
-                float* cp = (float*)p.C + (long)m * p.ldc + n;
-                if (full && c_al) {
-                    *(float4*)cp = make_float4(a[0], a[1], a[2], a[3]);
-                    *(float4*)(cp + 4) = make_float4(a[4], a[5], a[6], a[7]);
-                } else {
-#pragma unroll 1
-                    for (int e = 0; e < 8; ++e)
-                        if (n + e < n_out) cp[e] = a[e];
-                }
-            } else {
-                bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
-                if (full && c_al) {
-                    *(uint4*)cp = pack8(a);
-                } else {
-#pragma unroll 1
-                    for (int e = 0; e < 8; ++e)
-                        if (n + e < n_out) cp[e] = f2bf(a[e]);
-                }
-            }
-        };
-
-        if (!raw_f32) {
-            constexpr int WCOLS = SWIGLU ? 32 : 64;            // output columns of this wave
-            constexpr int PITCH = WCOLS * 2 + 16;              // bytes; +16 keeps 16-byte alignment and spreads banks
-            float bias_v[4][4];                                // -0.0f: x + (-0.0f) == x bit-for-bit when there is no bias
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
-                    bias_v[i][r] = (!SWIGLU && (flags & EPI_BIAS) && n < p.N) ? bf2f(p.bias[n]) : -0.0f;
-                }
-#pragma clang loop unroll(full)
-            for (int j = 0; j < 8; ++j) {
-                if constexpr (SWIGLU) {
-#pragma clang loop unroll(full)
-                    for (int ip = 0; ip < 2; ++ip) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float g = rbf(acc[2 * ip][j][r]);
-                            const float u = rbf(acc[2 * ip + 1][j][r]);
-                            v[r] = rbf(act_silu(g)) * u;
-                        }
-                        uint2 o;
-                        o.x = pack2bf(v[0], v[1]);
-                        o.y = pack2bf(v[2], v[3]);
-                        *(uint2*)(reg + (j * 16 + fr) * PITCH + (ip * 16 + fg * 4) * 2) = o;
-                    }
-                } else {
-#pragma clang loop unroll(full)
-                    for (int i = 0; i < 4; ++i) {
-                        uint2 o;
-                        o.x = pack2bf(acc[i][j][0] + bias_v[i][0], acc[i][j][1] + bias_v[i][1]);
-                        o.y = pack2bf(acc[i][j][2] + bias_v[i][2], acc[i][j][3] + bias_v[i][3]);
-                        *(uint2*)(reg + (j * 16 + fr) * PITCH + (i * 16 + fg * 4) * 2) = o;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region only: no block barrier needed
-            constexpr int LPR = WCOLS / 8;                         // lanes per row (16 B each)
-            constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
-#pragma unroll 2
-            for (int it = 0; it < 128 / RPI; ++it) {
-                const int row = it * RPI + lane / LPR, c8 = lane % LPR;
-                const int m = mrow0 + row, n = ncol0 + c8 * 8;
-                if (m >= p.M || n >= n_out) continue;
-                float a[8];
-                unpack8(*(const uint4*)(reg + row * PITCH + c8 * 16), a);
-                finish8(a, m, n);
-            }
-        } else {
-            // fp32 output of the bare accumulator (+bias): two passes of 64 rows x 64 fp32 columns through the same region
-            constexpr int PITCH = 64 * 4 + 16;
-            float bias_v[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
-                    bias_v[i][r] = ((flags & EPI_BIAS) && n < p.N) ? bf2f(p.bias[n]) : -0.0f;
-                }
-#pragma clang loop unroll(full)
-            for (int h = 0; h < 2; ++h) {
-                if (h) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma clang loop unroll(full)
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = h * 4 + jj;
-#pragma clang loop unroll(full)
-                    for (int i = 0; i < 4; ++i) {
-                        f32x4_t o = acc[i][j];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] += bias_v[i][r];
-                        *(f32x4_t*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fg * 4) * 4) = o;
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 2
-                for (int it = 0; it < 8; ++it) {
-                    const int row = it * 8 + (lane >> 3), c8 = lane & 7;
-                    const int m = mrow0 + h * 64 + row, n = ncol0 + c8 * 8;
-                    if (m >= p.M || n >= n_out) continue;
-                    const f32x4_t lo = *(const f32x4_t*)(reg + row * PITCH + c8 * 32);
-                    const f32x4_t hi = *(const f32x4_t*)(reg + row * PITCH + c8 * 32 + 16);
-                    float a[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    finish8(a, m, n);
-                }
-            }
-        }
-    }
+    __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
+    staged_epilogue<SWIGLU, 8>(p, acc, smem + wave * (128 * 144), lane, m0 + wm * 128, n0 + wn * 64);
 }
 
 // (A v_mfma_f32_32x32x16_bf16 variant of this kernel measured 6-11 % slower in this structure and was removed;
