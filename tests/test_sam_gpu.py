@@ -47,7 +47,10 @@ def test_relpos_tables(side, hd, nH, NB):
 
 @pytest.mark.parametrize("side,hd,nH,NB", [(14, 80, 2, 3), (64, 80, 2, 1), (64, 32, 2, 1)])
 def test_sam_encoder_attention(side, hd, nH, NB):
-    """windowed (196 keys, register kernel + bias) and global (4096 keys, two-pass kernel + bias) SAM attention."""
+    """windowed (196 keys, register kernel + bias) and global (4096 keys, single-pass streaming kernel + bias) SAM attention.
+    The streaming kernel rounds P = bf16(exp(s - running max)) before the normalisation, the reference after it: the two
+    bf16 results carry independent rounding noise of the same size, so (a) a slightly larger share of elements may sit
+    beyond the 2-ulp bound and (b) the kernel must be as close to the fp32 truth as the reference's own bf16 path is."""
     ops = pkg("ops")
     S, C = side * side, nH * hd
     x = _rand(NB, side, side, C, seed=6)
@@ -63,13 +66,18 @@ def test_sam_encoder_attention(side, hd, nH, NB):
     ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
                   q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
     vmax = float(qkv[:, 2 * C:].float().abs().max())
-    assert_close_bf16(att, ref, ulps=2.0, what=f"sam attention side={side}", outlier_frac=2e-3, outlier_floor=vmax)
+    frac = 2e-3 if S <= 1024 else 6e-3
+    assert_close_bf16(att, ref, ulps=2.0, what=f"sam attention side={side}", outlier_frac=frac, outlier_floor=vmax)
+    truth = O.sam_attention({k: v.float() for k, v in sd.items()}, "", x.float(), nH).reshape(NB * S, C)
+    e_ours = float((att.float().cpu() - truth).pow(2).mean().sqrt())
+    e_ref = float((ref.float() - truth).pow(2).mean().sqrt())
+    assert e_ours <= 1.15 * e_ref, f"rms error vs fp32 truth: kernel {e_ours:.4g}, reference bf16 path {e_ref:.4g}"
     # fused path: the kernel builds the bias tables from the raw rel_pos parameters (Toeplitz product on the MFMA)
     att2 = torch.empty_like(att)
     ops.attention(qkv, qkv[:, C:], vt, att2, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
                   q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side))
     # (MFMA vs sequential fp32 accumulation order may flip a bf16 rounding of a table entry, so compare with the reference)
-    assert_close_bf16(att2, ref, ulps=2.0, what=f"sam attention (fused rel-pos) side={side}", outlier_frac=2e-3, outlier_floor=vmax)
+    assert_close_bf16(att2, ref, ulps=2.0, what=f"sam attention (fused rel-pos) side={side}", outlier_frac=frac, outlier_floor=vmax)
 
 
 @pytest.mark.parametrize("Sq,Sk,hd", [(6, 4096, 16), (4096, 6, 16), (6, 6, 32), (130, 1500, 64)])

@@ -371,7 +371,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Any number of keys (SAM global attention: 4096 keys; mask-decoder token->image cross attention: 4096 keys).
+// Any number of keys, exact form (mask-decoder token->image cross attention: 4096 keys; any other > 1024-key call; the SAM
+// encoder's global attention takes the single-pass kernel further down unless ULL_ATTN_TWO_PASS is set).
 // Same rounding points as above, but the score row no longer fits in registers, so the kernel streams the keys TWICE:
 //   pass 1  S tiles -> running row max and sum of exp (fp32; combined across the 4 lanes of a query at the end);
 //   pass 2  the same S tiles again (bit-identical), P = bf16(exp(S - max) / sum) straight into the P*V MFMA.
@@ -558,6 +559,206 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-pass form of the long-key kernel: one sweep over the keys with a running row max (the "online" softmax).
+// Per 64-key tile: S tile (same rounding points as everywhere else: bf16 scores, bf16 bias adds), tile max combined over the 4
+// lanes of a query, P = bf16(exp(S - m)) into the P*V MFMA, O rescaled by exp(m_old - m_new) only when some query of the
+// wave saw a new maximum; O / sum(exp) at the end.  Against the two-pass form it drops the second QK^T and the second
+// round of score arithmetic -- the kernel is VALU-bound (~17 VALU-instruction equivalents per score against 22 MFMAs per
+// tile), not MFMA-bound -- at the price of rounding P before instead of after the normalisation (same 2^-9 relative error
+// per probability as the reference's bf16 softmax, but not the identical bits).
+//   HOIST (SAM global attention, 64 x 64 key grid, KW == 64 == tile width, per-query tables from relpos_kernel): a key tile
+//   is one grid row, so rel_h is ONE value per (query, tile) and the 16 rel_w values of a lane are the same for every tile:
+//   they live in registers and the per-score table lookups / index arithmetic / LDS bias rows disappear; without the mask
+//   bytes and bias rows a block needs 64 KiB of LDS and two blocks share a CU.
+template <int HDP, int FL, bool HOIST>
+__global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NWV = 8, BQ = 16 * NWV;
+    constexpr int CPR = HDP / 8, KROW = HDP * 2;
+    constexpr int NKS = HDP / 32, NDS = HDP / 16;
+    constexpr int TILE = 64 * KROW;       // a K tile (64 x HDP) and a V^T tile (HDP x 64) have the same size
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nq = (p.Sq + BQ - 1) / BQ;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int head = (slot / nq) * 8 + xcd;
+    if (head >= p.B * p.H) return;
+    const int qt = nq - 1 - slot % nq;
+    const int b = head / p.H, h = head % p.H;
+    const int q0 = qt * BQ;
+    const int koff = p.Sk - p.Sq;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    int kend = p.Sk;
+    if (p.causal) kend = min(p.Sk, q0 + BQ + koff);
+    if (kend < 1) kend = 1;
+    const int nkt = (kend + KT - 1) / KT;
+    char* maskb = smem + 4 * TILE;
+    bf16_t* biasb = (bf16_t*)(smem + 4 * TILE + ((nkt * KT + 15) & ~15));
+
+    uint4 qf[NKS];
+    const int qi = q0 + wave * 16 + fr;
+    const int qic = min(qi, p.Sq - 1);
+    {
+        const bf16_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 32 + fg * 8;
+            qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+        }
+        if constexpr (!HOIST) {
+            for (int j = tid; j < nkt * KT; j += 512) {
+                unsigned char m = 2;
+                if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
+                maskb[j] = m;
+            }
+        }
+    }
+    const bf16_t* brow = nullptr;
+    int bh_off = 0, bw_off = 0;
+    float rw[16];                                              // HOIST: rel_w of this lane's 16 key columns
+    const bf16_t* rh_row = nullptr;                            // HOIST: rel_h row of this lane's query
+    if constexpr (HOIST) {
+        const long row = (long)head * p.Sq + qic;
+        const bf16_t* wrow = p.rel_w + row * p.KW;
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+            const uint2 v = *(const uint2*)(wrow + ns * 16 + fg * 4);
+            rw[ns * 4 + 0] = bf2f((bf16_t)(v.x & 0xffff)); rw[ns * 4 + 1] = bf2f((bf16_t)(v.x >> 16));
+            rw[ns * 4 + 2] = bf2f((bf16_t)(v.y & 0xffff)); rw[ns * 4 + 3] = bf2f((bf16_t)(v.y >> 16));
+        }
+        rh_row = p.rel_h + row * p.KH;
+    } else if (p.rel_h != nullptr) {
+        const int bp = bias_pitch(p);
+        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off);
+        brow = biasb + (wave * 16 + fr) * bp;
+    }
+    if (p.q_scale != 1.0f) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = scale_q8(qf[ks], p.q_scale);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    auto issue = [&](int kt) {                                // K tile kt and V^T tile kt -> slot kt & 1 = [K | V^T]
+        if (kt >= nkt) return;
+        const uint32_t dst = lds_base + (kt & 1) * (2 * TILE);
+#pragma unroll
+        for (int i0 = 0; i0 < CPR; i0 += NWV) {
+            const int i = i0 + wave;
+            if (i < CPR) {
+                const int row = i * (64 / CPR) + lane / CPR;
+                const int c = (lane % CPR) ^ swz<CPR>(row);
+                const int key = min(kt * KT + row, p.Sk - 1);
+                const bf16_t* src = (c * 8 < p.hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                glds16(src, dst + i * 1024);
+            }
+        }
+        const int npieces = p.hd >> 3;
+#pragma unroll
+        for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
+            const int i = i0 + wave;
+            if (i < npieces) {
+                const int row = i * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (row & 7);
+                glds16(vbase + (long)row * p.vt_ds + kt * KT + c * 8, dst + TILE + i * 1024);
+            }
+        }
+    };
+
+    f32x4_t oacc[NDS];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    float rh = 0.f;
+    if constexpr (HOIST) rh = bf2f(rh_row[0]);
+    issue(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(kt + 1);
+        float rh_next = 0.f;
+        if constexpr (HOIST) rh_next = bf2f(rh_row[min(kt + 1, p.KH - 1)]);
+        const char* tb = smem + (kt & 1) * (2 * TILE);
+        float sv[16];
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const int row = ns * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks * 32 < p.hd) {
+                    const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
+                    acc = mfma16(kf, qf[ks], acc);
+                }
+            }
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sv[ns * 4 + r] = rbf(rbf(rbf(acc[r]) + rh) + rw[ns * 4 + r]);
+            } else {
+                const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
+                uint32_t lo, hi;
+                score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, lo, hi);
+                sv[ns * 4 + 0] = __uint_as_float(lo << 16); sv[ns * 4 + 1] = __uint_as_float(lo & 0xffff0000u);
+                sv[ns * 4 + 2] = __uint_as_float(hi << 16); sv[ns * 4 + 3] = __uint_as_float(hi & 0xffff0000u);
+            }
+        }
+        float tm = sv[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tm = fmaxf(tm, sv[i]);
+        tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float mn = fmaxf(m, tm);                         // finite from tile 0 on (key 0 is always in range)
+        if (__builtin_amdgcn_ballot_w64(mn > m) != 0) {        // some query of this wave has a new maximum
+            const float alpha = __expf(m - mn);                // exp(-inf) = 0 on the first tile
+            l *= alpha;
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[ds][r] *= alpha;
+            m = mn;
+        }
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float e0 = __expf(sv[2 * i] - m), e1 = __expf(sv[2 * i + 1] - m);
+            pk[i] = pack2bf(e0, e1);
+            // the sum runs over the ROUNDED probabilities, so that O / l is a true weighted mean of V rows
+            l += __uint_as_float(pk[i] << 16) + __uint_as_float(pk[i] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint4 pf = make_uint4(pk[4 * kk], pk[4 * kk + 1], pk[4 * kk + 2], pk[4 * kk + 3]);
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                if (ds * 16 < p.hd) {
+                    const int row = ds * 16 + fr;
+                    const uint4 vf = *(const uint4*)(tb + TILE + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                    oacc[ds] = mfma16(vf, pf, oacc[ds]);
+                }
+            }
+        }
+        rh = rh_next;
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qi < p.Sq) {
+        bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            if (ds * 16 < p.hd) {
+                uint2 o;
+                o.x = pack2bf(oacc[ds][0] * inv, oacc[ds][1] * inv);
+                o.y = pack2bf(oacc[ds][2] * inv, oacc[ds][3] * inv);
+                *(uint2*)(op + ds * 16 + fg * 4) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // RoPE in place on the q|k part of a fused QKV buffer (transformers apply_rotary_pos_emb on bf16
 // tensors: q*cos -> bf16, rotate_half(q)*sin -> bf16, sum -> bf16; cos/sin are fp32 values cast to bf16).
 // One block per token; thread t owns the 8-wide dim chunk (t % (hd/16)) of head-instances t / (hd/16), ...
@@ -646,6 +847,24 @@ int launch_long(const AttnArgs& a, hipStream_t st) {
     return ull_check_launch();
 }
 
+template <int HDP, int FL, bool HOIST>
+int launch_stream(const AttnArgs& a, hipStream_t st) {
+    constexpr int TILE = 64 * HDP * 2;
+    const int nt = (a.Sk + KT - 1) / KT;
+    int lds = 4 * TILE;
+    if (!HOIST) lds += ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
+    if (lds > 160 * 1024) return ULL_ERR_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_stream_kernel<HDP, FL, HOIST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int nq = (a.Sq + 127) / 128;
+    const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
+    hipLaunchKernelGGL((attn_stream_kernel<HDP, FL, HOIST>), grid, dim3(512), lds, st, a);
+    return ull_check_launch();
+}
+
 // Which straight-line flavor (if any) the arguments correspond to.
 int flavor_of(const AttnArgs& a) {
     if (a.scale_mode == 1 && a.causal && !a.rel_h && a.q_scale == 1.0f) return FL_LLAMA;
@@ -665,6 +884,11 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
         if (fl == FL_LLAMA && nt <= 11) return w8 ? launch_attn<128, 11, FL_LLAMA, 8>(a, st) : launch_attn<128, 11, FL_LLAMA, 4>(a, st);
         if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
         if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
+        static const bool two_pass = getenv("ULL_ATTN_TWO_PASS") != nullptr;     // A/B switch: the exact two-pass kernel
+        if (fl == FL_SAM_ENC && nt > 16 && !two_pass) {
+            if (a.rel_mode == 1 && a.KW == KT && (a.Sk % KT) == 0) return launch_stream<128, FL_SAM_ENC, true>(a, st);
+            return launch_stream<128, FL_SAM_ENC, false>(a, st);
+        }
         if (fl == FL_SAM_ENC && nt > 16) return launch_long<128, FL_SAM_ENC>(a, st);
     }
     if constexpr (HDP == 64) {
@@ -674,7 +898,7 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     }
     if constexpr (HDP == 32) {
         if (fl == FL_SAM_DEC && nt <= 5) return launch_attn<32, 5, FL_SAM_DEC>(a, st);
-        if (fl == FL_SAM_DEC && nt > 16) return launch_long<32, FL_SAM_DEC>(a, st);
+        if (fl == FL_SAM_DEC && nt > 16) return launch_long<32, FL_SAM_DEC>(a, st);      // mask decoder: the exact two-pass form
     }
     if constexpr (HDP < 128) {          // (the <128, 5> instantiation spills; hd=128 starts at the 11-tile variant)
         if (nt <= 5) return launch_attn<HDP, 5, FL_RUNTIME>(a, st);
