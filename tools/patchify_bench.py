@@ -22,4 +22,4 @@ for size, alg_mb, gf in ((224, 27.6, 9.87), (336, 60.6, 22.2)):
         run()
     e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"patchify {size}x{size} B=32: {us:7.1f} us  -> {alg_mb / us * 1e3 / 1e3:6.3f} TB/s algorithmic ({alg_mb / us * 1e3 / 8000 * 100:4.1f} % of 8 TB/s), {gf / us * 1e3 / 1e3:6.1f} TFLOP/s")
+    print(f"patchify {size}x{size} B=32: {us:7.1f} us  -> {alg_mb / us * 1e3 / 1e3:6.3f} TB/s algorithmic ({alg_mb / us * 1e3 / 8000 * 100:4.1f} % of 8 TB/s), {gf / us * 1e3:6.1f} TFLOP/s")

@@ -89,7 +89,7 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
 // qf0 = the wave's UNSCALED query fragments.  Returns the two lookup offsets of this lane's query.
 template <int NKS>
 ULL_DEV void stage_rel_bias(const AttnArgs& p, bf16_t* dst, int bp, const uint4 (&qf0)[NKS], int q_first, long head, int lane,
-                            int& bh_off, int& bw_off) {
+                            int& bh_off, int& bw_off, int hd) {
     const int fr = lane & 15, fg = lane >> 4;
     const int qi = min(q_first + fr, p.Sq - 1);
     if (p.rel_mode == 1) {
@@ -114,8 +114,8 @@ ULL_DEV void stage_rel_bias(const AttnArgs& p, bf16_t* dst, int bp, const uint4 
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
                     const int d = ks * 32 + fg * 8;
-                    if (ks * 32 < p.hd) {
-                        const uint4 a = (d < p.hd) ? *(const uint4*)(tab + (long)t * p.hd + d) : make_uint4(0, 0, 0, 0);
+                    if (ks * 32 < hd) {
+                        const uint4 a = (d < hd) ? *(const uint4*)(tab + (long)t * hd + d) : make_uint4(0, 0, 0, 0);
                         acc = mfma16(a, qf0[ks], acc);
                     }
                 }
@@ -158,12 +158,25 @@ ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */)
 template <int CPR>
 ULL_DEV int swz(int row) { return CPR >= 16 ? (row & 15) : CPR == 8 ? (row & 7) : ((row >> 2) & 3); }
 
+// Head dim as a compile-time constant where the flavor pins it (flavor_of() checks the argument): the `ks * 32 < hd` /
+// `ds * 16 < hd` tests that skip pure-padding MFMAs then fold away.  With a run-time hd every MFMA sits in its own basic
+// block behind an s_waitcnt (seen in the ISA of the first version of these kernels).
+template <int HDP, int FL>
+ULL_DEV int head_dim_of(const AttnArgs& p) {
+    if constexpr (FL == FL_LLAMA || FL == FL_CLIP) return HDP;
+    else if constexpr (FL == FL_SAM_ENC && HDP == 128) return 80;
+    else return p.hd;
+}
+
 // Block = NWV waves = 16*NWV queries of one (batch, head); wave w owns queries q0+16w .. +16 against ALL keys.
 // (NWV = 4 lets two blocks share a CU so one block's barrier / DMA waits overlap the other's MFMAs.)
 //   HDP : head dim padded to 32/64/128 (K-tile row = HDP bf16);  NT : max number of 64-key tiles held in registers.
 // Per lane the whole score/probability row segment lives in registers as packed bf16 (8 VGPRs per 64 keys).
-template <int HDP, int NT, int FL, int NWV>
-__global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
+//   EXACT: the caller guarantees a non-causal call with exactly NT key tiles, so every `kt < nkt` test folds away, and the
+//   kernel is built for 4 waves per SIMD (<= 128 VGPRs; sched_barriers keep hipcc from hoisting a whole tile's fragment and
+//   bias reads above the first MFMA, which is what blows the register budget of the small-NT instantiations at HDP = 128).
+template <int HDP, int NT, int FL, int NWV, bool EXACT = false>
+__global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BQ = 16 * NWV;
     constexpr int CPR = HDP / 8;          // 16-byte chunks per K-tile row
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
     constexpr int NKS = HDP / 32, NDS = HDP / 16;
     constexpr int TILE = 64 * KROW > HDP * 128 ? 64 * KROW : HDP * 128;   // bytes per tile buffer (K: 64 x HDP, V^T: HDP x 64)
     const int tid = threadIdx.x, lane = tid & 63;
+    const int hd = head_dim_of<HDP, FL>(p);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
 
@@ -191,10 +205,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
     int kend = p.Sk;
     if (p.causal) kend = min(p.Sk, q0 + BQ + koff);
     if (kend < 1) kend = 1;
-    const int nkt = (kend + KT - 1) / KT;                       // tiles this block streams
+    const int nkt = EXACT ? NT : (kend + KT - 1) / KT;          // tiles this block streams
     int kend_w = p.Sk;
     if (p.causal) kend_w = min(p.Sk, q0 + wave * 16 + 16 + koff);
-    const int nkt_w = (q0 + wave * 16 < p.Sq) ? max(1, (kend_w + KT - 1) / KT) : 0;   // tiles this wave computes on
+    const int nkt_w = EXACT ? NT : (q0 + wave * 16 < p.Sq) ? max(1, (kend_w + KT - 1) / KT) : 0;   // tiles this wave computes on
 
     // ---- Q fragments + key-mask bytes (ordinary loads; drained before any DMA is issued) ---------------
     uint4 qf[NKS];
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
-            qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+            qf[ks] = (qi < p.Sq && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
         }
         for (int j = tid; j < nkt * KT; j += NWV * 64) {
             unsigned char m = 2;
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
     int bh_off = 0, bw_off = 0;
     if (p.rel_h != nullptr) {
         const int bp = bias_pitch(p);
-        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off);
+        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off, hd);
         brow = biasb + (wave * 16 + fr) * bp;
     }
     if (p.q_scale != 1.0f) {
@@ -239,13 +253,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
                     const int row = i * (64 / CPR) + lane / CPR;
                     const int c = (lane % CPR) ^ swz<CPR>(row);
                     const int key = min(kt * KT + row, p.Sk - 1);
-                    const bf16_t* src = (c * 8 < p.hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                    const bf16_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
                     glds16(src, dst + i * 1024);
                 }
             }
         } else {
             const int kt = s - nkt;
-            const int npieces = p.hd >> 3;                      // 8 V^T rows (head dims) per 1-KiB piece
+            const int npieces = hd >> 3;                      // 8 V^T rows (head dims) per 1-KiB piece
 #pragma unroll
             for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
                 const int i = i0 + wave;
@@ -276,13 +290,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
                     const int row = ns * 16 + fr;
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
-                        if (ks * 32 < p.hd) {                    // k-steps that are pure head-dim padding are skipped
+                        if (ks * 32 < hd) {                    // k-steps that are pure head-dim padding are skipped
                             const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
                             acc = mfma16(kf, qf[ks], acc);
                         }
                     }
                     const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
                     score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
+                    if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -311,6 +326,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
                     sum += __expf(__uint_as_float(sp[kt][i] << 16) - m);
                     sum += __expf(__uint_as_float(sp[kt][i] & 0xffff0000u) - m);
                 }
+                if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
@@ -324,6 +340,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
                     const float hi = __expf(__uint_as_float(sp[kt][i] & 0xffff0000u) - m) * inv;
                     sp[kt][i] = pack2bf(lo, hi);
                 }
+                if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
     }
 
@@ -346,12 +363,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
                     const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
 #pragma unroll
                     for (int ds = 0; ds < NDS; ++ds) {
-                        if (ds * 16 < p.hd) {
+                        if (ds * 16 < hd) {
                             const int row = ds * 16 + fr;
                             const uint4 vf = *(const uint4*)(tb + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
                             oacc[ds] = mfma16(vf, pf, oacc[ds]);
                         }
                     }
+                    if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_reg_kernel(AttnArgs p) {
         bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
-            if (ds * 16 < p.hd) {
+            if (ds * 16 < hd) {
                 uint2 pk;
                 pk.x = pack2bf(oacc[ds][0], oacc[ds][1]);
                 pk.y = pack2bf(oacc[ds][2], oacc[ds][3]);
@@ -385,6 +403,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
     constexpr int NKS = HDP / 32, NDS = HDP / 16;
     constexpr int TILE = 64 * KROW;       // == HDP * 128: a K tile (64 x HDP) and a V^T tile (HDP x 64) have the same size
     const int tid = threadIdx.x, lane = tid & 63;
+    const int hd = head_dim_of<HDP, FL>(p);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int nq = (p.Sq + BQ - 1) / BQ;
@@ -410,7 +429,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
-            qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+            qf[ks] = (qi < p.Sq && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
         }
         for (int j = tid; j < nkt * KT; j += 512) {
             unsigned char m = 2;
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
     int bh_off = 0, bw_off = 0;
     if (p.rel_h != nullptr) {
         const int bp = bias_pitch(p);
-        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off);
+        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off, hd);
         brow = biasb + (wave * 16 + fr) * bp;
     }
     if (p.q_scale != 1.0f) {
@@ -445,12 +464,12 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
                 const int row = i * (64 / CPR) + lane / CPR;
                 const int c = (lane % CPR) ^ swz<CPR>(row);
                 const int key = min(kt * KT + row, p.Sk - 1);
-                const bf16_t* src = (c * 8 < p.hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                const bf16_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
                 glds16(src, dst + i * 1024);
             }
         }
         if (s >= nkt) {
-            const int npieces = p.hd >> 3;
+            const int npieces = hd >> 3;
 #pragma unroll
             for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
                 const int i = i0 + wave;
@@ -470,7 +489,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
             const int row = ns * 16 + fr;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                if (ks * 32 < p.hd) {
+                if (ks * 32 < hd) {
                     const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
                     acc = mfma16(kf, qf[ks], acc);
                 }
@@ -536,7 +555,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
             const uint4 pf = make_uint4(sq[4 * kk], sq[4 * kk + 1], sq[4 * kk + 2], sq[4 * kk + 3]);
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
-                if (ds * 16 < p.hd) {
+                if (ds * 16 < hd) {
                     const int row = ds * 16 + fr;
                     const uint4 vf = *(const uint4*)(tb + TILE + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
                     oacc[ds] = mfma16(vf, pf, oacc[ds]);
@@ -548,7 +567,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
         bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
-            if (ds * 16 < p.hd) {
+            if (ds * 16 < hd) {
                 uint2 pk;
                 pk.x = pack2bf(oacc[ds][0], oacc[ds][1]);
                 pk.y = pack2bf(oacc[ds][2], oacc[ds][3]);
@@ -578,6 +597,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     constexpr int NKS = HDP / 32, NDS = HDP / 16;
     constexpr int TILE = 64 * KROW;       // a K tile (64 x HDP) and a V^T tile (HDP x 64) have the same size
     const int tid = threadIdx.x, lane = tid & 63;
+    const int hd = head_dim_of<HDP, FL>(p);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int nq = (p.Sq + BQ - 1) / BQ;
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
-            qf[ks] = (qi < p.Sq && d < p.hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+            qf[ks] = (qi < p.Sq && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
         }
         if constexpr (!HOIST) {
             for (int j = tid; j < nkt * KT; j += 512) {
@@ -630,7 +650,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
         rh_row = p.rel_h + row * p.KH;
     } else if (p.rel_h != nullptr) {
         const int bp = bias_pitch(p);
-        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off);
+        stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off, hd);
         brow = biasb + (wave * 16 + fr) * bp;
     }
     if (p.q_scale != 1.0f) {
@@ -651,11 +671,11 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                 const int row = i * (64 / CPR) + lane / CPR;
                 const int c = (lane % CPR) ^ swz<CPR>(row);
                 const int key = min(kt * KT + row, p.Sk - 1);
-                const bf16_t* src = (c * 8 < p.hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                const bf16_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
                 glds16(src, dst + i * 1024);
             }
         }
-        const int npieces = p.hd >> 3;
+        const int npieces = hd >> 3;
 #pragma unroll
         for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
             const int i = i0 + wave;
@@ -688,7 +708,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             const int row = ns * 16 + fr;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                if (ks * 32 < p.hd) {
+                if (ks * 32 < hd) {
                     const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
                     acc = mfma16(kf, qf[ks], acc);
                 }
@@ -732,7 +752,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             const uint4 pf = make_uint4(pk[4 * kk], pk[4 * kk + 1], pk[4 * kk + 2], pk[4 * kk + 3]);
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
-                if (ds * 16 < p.hd) {
+                if (ds * 16 < hd) {
                     const int row = ds * 16 + fr;
                     const uint4 vf = *(const uint4*)(tb + TILE + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
                     oacc[ds] = mfma16(vf, pf, oacc[ds]);
@@ -748,7 +768,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
         bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
-            if (ds * 16 < p.hd) {
+            if (ds * 16 < hd) {
                 uint2 o;
                 o.x = pack2bf(oacc[ds][0] * inv, oacc[ds][1] * inv);
                 o.y = pack2bf(oacc[ds][2] * inv, oacc[ds][3] * inv);
@@ -819,14 +839,14 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
     }
 }
 
-template <int HDP, int NT, int FL, int NWV = 8>
+template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
     const int lds = 2 * TILE + NT * KT + (a.rel_h ? NWV * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV>), grid, dim3(NWV * 64), lds, st, a);
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT>), grid, dim3(NWV * 64), lds, st, a);
     return ull_check_launch();
 }
 
@@ -877,12 +897,16 @@ int flavor_of(const AttnArgs& a) {
 template <int HDP>
 int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     const int nt = (a.Sk + KT - 1) / KT;
-    const int fl = flavor_of(a);
+    int fl = flavor_of(a);
+    // the flavored kernels take the head dim as a compile-time constant (head_dim_of)
+    if ((fl == FL_LLAMA || fl == FL_CLIP) && a.hd != HDP) fl = FL_RUNTIME;
+    if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
     // specialised instantiations exist for the shapes on the u-LLaVA path; everything else takes the run-time-flag kernels
     if constexpr (HDP == 128) {
         static const bool w8 = getenv("ULL_ATTN_8WAVES") != nullptr;          // A/B switch
         if (fl == FL_LLAMA && nt <= 11) return w8 ? launch_attn<128, 11, FL_LLAMA, 8>(a, st) : launch_attn<128, 11, FL_LLAMA, 4>(a, st);
         if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
+        if (fl == FL_SAM_ENC && nt == 4) return launch_attn<128, 4, FL_SAM_ENC, 8, true>(a, st);      // 14 x 14 windows: 196 keys
         if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
         static const bool two_pass = getenv("ULL_ATTN_TWO_PASS") != nullptr;     // A/B switch: the exact two-pass kernel
         if (fl == FL_SAM_ENC && nt > 16 && !two_pass) {
