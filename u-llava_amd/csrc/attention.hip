@@ -172,9 +172,10 @@ ULL_DEV int head_dim_of(const AttnArgs& p) {
 // (NWV = 4 lets two blocks share a CU so one block's barrier / DMA waits overlap the other's MFMAs.)
 //   HDP : head dim padded to 32/64/128 (K-tile row = HDP bf16);  NT : max number of 64-key tiles held in registers.
 // Per lane the whole score/probability row segment lives in registers as packed bf16 (8 VGPRs per 64 keys).
-//   EXACT: the caller guarantees a non-causal call with exactly NT key tiles, so every `kt < nkt` test folds away, and the
-//   kernel is built for 4 waves per SIMD (<= 128 VGPRs; sched_barriers keep hipcc from hoisting a whole tile's fragment and
-//   bias reads above the first MFMA, which is what blows the register budget of the small-NT instantiations at HDP = 128).
+//   EXACT (SAM 14 x 14 windows): a non-causal call with exactly NT key tiles and ALL of them resident: the NT K tiles are
+//   DMA'd up front, the NT V^T tiles right after the K barrier (they land during the score / softmax phases), so a block
+//   passes 2 barriers instead of 2*NT and exposes two memory round trips instead of 2*NT -- the streaming form measured
+//   46 us per block for ~10 us of work.  One block of NWV = 13 waves covers all 196 queries of a (window, head).
 template <int HDP, int NT, int FL, int NWV, bool EXACT = false>
 __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -199,8 +200,9 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     const int koff = p.Sk - p.Sq;
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    char* maskb = smem + 2 * TILE;        // one byte per key: 1 attend, 0 masked (finfo.min), 2 out of range (-inf)
-    bf16_t* biasb = (bf16_t*)(smem + 2 * TILE + NT * KT);
+    constexpr int NBUF = EXACT ? 2 * NT : 2;                     // EXACT: [K tiles 0..NT) [V^T tiles 0..NT)
+    char* maskb = smem + NBUF * TILE;     // one byte per key: 1 attend, 0 masked (finfo.min), 2 out of range (-inf)
+    bf16_t* biasb = (bf16_t*)(smem + NBUF * TILE + NT * KT);
 
     int kend = p.Sk;
     if (p.causal) kend = min(p.Sk, q0 + BQ + koff);
@@ -209,6 +211,44 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     int kend_w = p.Sk;
     if (p.causal) kend_w = min(p.Sk, q0 + wave * 16 + 16 + koff);
     const int nkt_w = EXACT ? NT : (q0 + wave * 16 < p.Sq) ? max(1, (kend_w + KT - 1) / KT) : 0;   // tiles this wave computes on
+
+    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    // stream step s: s < nkt -> K tile s ; else V^T tile s - nkt.   Buffer = s & 1.
+    auto issue = [&](int s) {
+        const uint32_t dst = lds_base + (EXACT ? s : (s & 1)) * TILE;
+        if (s < nkt) {
+            const int kt = s;
+#pragma unroll
+            for (int i0 = 0; i0 < CPR; i0 += NWV) {
+                const int i = i0 + wave;                        // one 1-KiB piece = 64/CPR rows
+                if (i < CPR) {
+                    const int row = i * (64 / CPR) + lane / CPR;
+                    const int c = (lane % CPR) ^ swz<CPR>(row);
+                    const int key = min(kt * KT + row, p.Sk - 1);
+                    const bf16_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                    glds16(src, dst + i * 1024);
+                }
+            }
+        } else {
+            const int kt = s - nkt;
+            const int npieces = hd >> 3;                      // 8 V^T rows (head dims) per 1-KiB piece
+#pragma unroll
+            for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
+                const int i = i0 + wave;
+                if (i < npieces) {
+                    const int row = i * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ (row & 7);
+                    glds16(vbase + (long)row * p.vt_ds + kt * KT + c * 8, dst + i * 1024);
+                }
+            }
+        }
+    };
+
+    if constexpr (EXACT) {                // all K tiles in flight while Q / mask / bias tables are prepared
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) issue(kt);
+    }
 
     // ---- Q fragments + key-mask bytes (ordinary loads; drained before any DMA is issued) ---------------
     uint4 qf[NKS];
@@ -239,51 +279,26 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
-    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
-    // stream step s: s < nkt -> K tile s ; else V^T tile s - nkt.   Buffer = s & 1.
-    auto issue = [&](int s) {
-        const uint32_t dst = lds_base + (s & 1) * TILE;
-        if (s < nkt) {
-            const int kt = s;
-#pragma unroll
-            for (int i0 = 0; i0 < CPR; i0 += NWV) {
-                const int i = i0 + wave;                        // one 1-KiB piece = 64/CPR rows
-                if (i < CPR) {
-                    const int row = i * (64 / CPR) + lane / CPR;
-                    const int c = (lane % CPR) ^ swz<CPR>(row);
-                    const int key = min(kt * KT + row, p.Sk - 1);
-                    const bf16_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
-                    glds16(src, dst + i * 1024);
-                }
-            }
-        } else {
-            const int kt = s - nkt;
-            const int npieces = hd >> 3;                      // 8 V^T rows (head dims) per 1-KiB piece
-#pragma unroll
-            for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
-                const int i = i0 + wave;
-                if (i < npieces) {
-                    const int row = i * 8 + (lane >> 3);
-                    const int c = (lane & 7) ^ (row & 7);
-                    glds16(vbase + (long)row * p.vt_ds + kt * KT + c * 8, dst + i * 1024);
-                }
-            }
-        }
-    };
-
     uint32_t sp[NT][8];                   // [tile][2*ns + half]: bf16 pairs for keys kt*64 + ns*16 + 4*fg + {0,1 | 2,3}
-    issue(0);
+    if constexpr (EXACT) {
+        __builtin_amdgcn_s_barrier();     // (vmcnt(0) above) every K tile, the mask bytes and the bias rows are in LDS
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) issue(NT + kt);          // V^T tiles land during phases 1 and 2
+    } else {
+        issue(0);
+    }
 
     // ---- phase 1: S = bf16(K Q^T) (+scale, +mask), kept in registers -----------------------------------
 #pragma clang loop unroll(full)
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(kt + 1);                                       // next K tile, or V^T tile 0
+            if constexpr (!EXACT) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue(kt + 1);                                   // next K tile, or V^T tile 0
+            }
             if (kt < nkt_w) {
-                const char* tb = smem + (kt & 1) * TILE;
+                const char* tb = smem + (EXACT ? kt : (kt & 1)) * TILE;
 #pragma unroll
                 for (int ns = 0; ns < 4; ++ns) {
                     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -350,14 +365,20 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     f32x4_t oacc[NDS];
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EXACT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 #pragma clang loop unroll(full)
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nkt) issue(nkt + kt + 1);
+            if constexpr (!EXACT) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < nkt) issue(nkt + kt + 1);
+            }
             if (kt < nkt_w) {
-                const char* tb = smem + ((nkt + kt) & 1) * TILE;
+                const char* tb = smem + (EXACT ? NT + kt : ((nkt + kt) & 1)) * TILE;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
@@ -842,7 +863,14 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
-    const int lds = 2 * TILE + NT * KT + (a.rel_h ? NWV * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
+    const int lds = (EXACT ? 2 * NT : 2) * TILE + NT * KT +
+                    (a.rel_h ? NWV * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
+    if (lds > 160 * 1024) return ULL_ERR_LDS;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
@@ -906,7 +934,7 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
         static const bool w8 = getenv("ULL_ATTN_8WAVES") != nullptr;          // A/B switch
         if (fl == FL_LLAMA && nt <= 11) return w8 ? launch_attn<128, 11, FL_LLAMA, 8>(a, st) : launch_attn<128, 11, FL_LLAMA, 4>(a, st);
         if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
-        if (fl == FL_SAM_ENC && nt == 4) return launch_attn<128, 4, FL_SAM_ENC, 8, true>(a, st);      // 14 x 14 windows: 196 keys
+        if (fl == FL_SAM_ENC && nt == 4 && a.Sq <= 208) return launch_attn<128, 4, FL_SAM_ENC, 13, true>(a, st);   // 14 x 14 windows
         if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
         static const bool two_pass = getenv("ULL_ATTN_TWO_PASS") != nullptr;     // A/B switch: the exact two-pass kernel
         if (fl == FL_SAM_ENC && nt > 16 && !two_pass) {
