@@ -800,6 +800,152 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// At most 16 queries per (batch, head): KV-cached decoding (1 query against the whole cache) and the mask decoder's
+// token -> image attention (7..16 queries against 4096 keys).  The kernels above give such a call ONE working wave per head
+// that walks the key tiles one barrier at a time (measured 32 us per LLaMA decode layer, 234 us per mask-decoder call); here the
+// key tiles are split over up to 16 waves of the block (wave w owns tiles w, w + nwv, ...; <= 4 per wave, kept in registers),
+// K / V^T fragments come straight from global memory into the MFMA operands (every byte is used by exactly one wave, so LDS
+// staging would buy nothing), and the waves meet three times in LDS: row max, row sum, partial O.  Same rounding points as the
+// register kernel (bf16 scores, exact two-step fp32 softmax, bf16 P); only the fp32 summation order of sum(exp) and of the
+// P*V partials differs.
+template <int HDP, int FL>
+__global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NKS = HDP / 32, NDS = HDP / 16, TPW = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hd = head_dim_of<HDP, FL>(p);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwv = blockDim.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int head = blockIdx.x;
+    const int b = head / p.H, h = head % p.H;
+    const int koff = p.Sk - p.Sq;
+    const int nkt = (p.Sk + KT - 1) / KT;
+    float* red = (float*)smem;                                  // [2][16 waves][16 queries]
+    float* obuf = red + 2 * 16 * 16;                            // [nwv][NDS * 4][64 lanes]
+
+    uint4 qf[NKS];
+    const int qi = fr;
+    {
+        const bf16_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 32 + fg * 8;
+            qf[ks] = (qi < p.Sq && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+        }
+        if (p.q_scale != 1.0f) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) qf[ks] = scale_q8(qf[ks], p.q_scale);
+        }
+    }
+    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+
+    // ---- scores of this wave's tiles -> registers (packed bf16), running max -------------------------------
+    uint32_t sp[TPW][8];
+    float m = -INFINITY;
+#pragma clang loop unroll(full)
+    for (int t = 0; t < TPW; ++t) {
+        const int kt = wave + t * nwv;
+        if (kt < nkt) {
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns) {
+                const int key = min(kt * KT + ns * 16 + fr, p.Sk - 1);
+                const bf16_t* kp = kbase + (long)key * p.k_ss + fg * 8;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    if (ks * 32 < hd) {
+                        const uint4 kf = (ks * 32 + fg * 8 < hd) ? *(const uint4*)(kp + ks * 32) : make_uint4(0, 0, 0, 0);
+                        acc = mfma16(kf, qf[ks], acc);
+                    }
+                }
+                const int j0 = kt * KT + ns * 16 + fg * 4;
+                uint32_t mk = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + r;
+                    uint32_t mb = 2;
+                    if (j < p.Sk) mb = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
+                    mk |= mb << (8 * r);
+                }
+                score_quad<FL>(p, acc, j0, mk, qi, koff, nullptr, 0, 0, sp[t][ns * 2], sp[t][ns * 2 + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                m = fmaxf(m, __uint_as_float(sp[t][i] << 16));
+                m = fmaxf(m, __uint_as_float(sp[t][i] & 0xffff0000u));
+            }
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (fg == 0) red[wave * 16 + fr] = m;
+    __syncthreads();
+    for (int w = 0; w < nwv; ++w) m = fmaxf(m, red[w * 16 + fr]);
+
+    // ---- exact fp32 softmax over the bf16 scores of ALL waves ----------------------------------------------
+    float sum = 0.f;
+#pragma clang loop unroll(full)
+    for (int t = 0; t < TPW; ++t)
+        if (wave + t * nwv < nkt) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                sum += __expf(__uint_as_float(sp[t][i] << 16) - m);
+                sum += __expf(__uint_as_float(sp[t][i] & 0xffff0000u) - m);
+            }
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (fg == 0) red[256 + wave * 16 + fr] = sum;
+    __syncthreads();
+    sum = 0.f;
+    for (int w = 0; w < nwv; ++w) sum += red[256 + w * 16 + fr];
+    const float inv = 1.0f / sum;
+
+    // ---- partial O^T = V^T P^T over this wave's tiles --------------------------------------------------------
+    f32x4_t oacc[NDS];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma clang loop unroll(full)
+    for (int t = 0; t < TPW; ++t) {
+        const int kt = wave + t * nwv;
+        if (kt < nkt) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float lo = __expf(__uint_as_float(sp[t][i] << 16) - m) * inv;
+                const float hi = __expf(__uint_as_float(sp[t][i] & 0xffff0000u) - m) * inv;
+                sp[t][i] = pack2bf(lo, hi);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const uint4 pf = make_uint4(sp[t][4 * kk], sp[t][4 * kk + 1], sp[t][4 * kk + 2], sp[t][4 * kk + 3]);
+#pragma unroll
+                for (int ds = 0; ds < NDS; ++ds) {
+                    if (ds * 16 < hd) {
+                        const uint4 vf = *(const uint4*)(vbase + (long)(ds * 16 + fr) * p.vt_ds + kt * KT + (kk * 4 + fg) * 8);
+                        oacc[ds] = mfma16(vf, pf, oacc[ds]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) obuf[(wave * NDS * 4 + ds * 4 + r) * 64 + lane] = oacc[ds][r];
+    __syncthreads();
+    // element e = (ds*4 + r)*64 + lane  <->  O[query lane & 15][d = ds*16 + 4*(lane >> 4) + r]
+    for (int e = tid; e < NDS * 4 * 64; e += blockDim.x) {
+        float acc = 0.f;
+        for (int w = 0; w < nwv; ++w) acc += obuf[w * NDS * 4 * 64 + e];
+        const int reg = e >> 6, ln = e & 63;
+        const int q = ln & 15, d = (reg >> 2) * 16 + (ln >> 4) * 4 + (reg & 3);
+        if (q < p.Sq && d < hd) p.O[(long)b * p.o_bs + (long)h * p.o_hs + (long)q * p.o_ss + d] = f2bf(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // RoPE in place on the q|k part of a fused QKV buffer (transformers apply_rotary_pos_emb on bf16
 // tensors: q*cos -> bf16, rotate_half(q)*sin -> bf16, sum -> bf16; cos/sin are fp32 values cast to bf16).
 // One block per token; thread t owns the 8-wide dim chunk (t % (hd/16)) of head-instances t / (hd/16), ...
@@ -913,6 +1059,20 @@ int launch_stream(const AttnArgs& a, hipStream_t st) {
     return ull_check_launch();
 }
 
+template <int HDP, int FL>
+int launch_fewq(const AttnArgs& a, hipStream_t st) {
+    const int nt = (a.Sk + KT - 1) / KT;
+    const int nwv = nt < 16 ? nt : 16;
+    const int lds = 2 * 16 * 16 * 4 + nwv * HDP * 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fewq_kernel<HDP, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_fewq_kernel<HDP, FL>), dim3(a.B * a.H), dim3(nwv * 64), lds, st, a);
+    return ull_check_launch();
+}
+
 // Which straight-line flavor (if any) the arguments correspond to.
 int flavor_of(const AttnArgs& a) {
     if (a.scale_mode == 1 && a.causal && !a.rel_h && a.q_scale == 1.0f) return FL_LLAMA;
@@ -929,6 +1089,17 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     // the flavored kernels take the head dim as a compile-time constant (head_dim_of)
     if ((fl == FL_LLAMA || fl == FL_CLIP) && a.hd != HDP) fl = FL_RUNTIME;
     if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
+    // <= 16 queries (decode steps, mask-decoder tokens): split the keys over the waves of one block per head
+    static const bool no_fewq = getenv("ULL_ATTN_NO_FEWQ") != nullptr;                  // A/B switch
+    if (a.Sq <= 16 && !a.rel_h && nt >= 2 && nt <= 64 && !no_fewq) {
+        if constexpr (HDP == 128) {
+            if (fl == FL_LLAMA) return launch_fewq<HDP, FL_LLAMA>(a, st);
+        }
+        if constexpr (HDP == 32) {
+            if (fl == FL_SAM_DEC) return launch_fewq<HDP, FL_SAM_DEC>(a, st);
+        }
+        return launch_fewq<HDP, FL_RUNTIME>(a, st);
+    }
     // specialised instantiations exist for the shapes on the u-LLaVA path; everything else takes the run-time-flag kernels
     if constexpr (HDP == 128) {
         static const bool w8 = getenv("ULL_ATTN_8WAVES") != nullptr;          // A/B switch
