@@ -45,6 +45,11 @@ int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* 
 int ull_gemv_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                   int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
+/* ull_gemv_bf16 with the preceding LlamaRMSNorm fused in: C = epilogue(rmsnorm(X; norm_w, eps) * W^T), M * K <= 16384.
+ * Decode-step form of input_layernorm -> q/k/v_proj and post_attention_layernorm -> gate/up_proj (hf LlamaDecoderLayer.forward). */
+int ull_gemv_rmsnorm_bf16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C, int64_t ldc,
+                          const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+
 /* y = w * bf16(x * rsqrt(mean(x^2) + eps)).  hf: LlamaRMSNorm.forward. */
 int ull_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
 
@@ -79,6 +84,12 @@ int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, 
  * positions int64 [tokens]; inv_freq float32 [hd/2] computed by the host exactly as LlamaRotaryEmbedding does. */
 int ull_rope_inplace_bf16(void* x, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads,
                           int64_t hd, void* stream);
+
+/* Decode step (models/ullava_core.py:357-395 with a KV cache): the same RoPE on the H q heads (in place) and the H k heads of
+ * fused [q|k|v] rows, plus the append of the new tokens' k (roped) / v to the cache: K cache [B,H,smax,hd] row past+s, V^T cache
+ * [B,H,hd,smax] column = the key-permuted slot of position past+s (layout of ull_transpose_v_bf16).  qkv rows = B*S tokens. */
+int ull_rope_append_bf16(void* qkv, int64_t row_stride, const void* positions, const void* inv_freq, int64_t B, int64_t S, int64_t H,
+                         int64_t hd, void* k_cache, void* vt_cache, int64_t smax, int64_t past, void* stream);
 
 /* V [B,S,H,hd] -> Vt [B,H,hd,pitch] (pitch % 64 == 0), zeros for keys >= S, keys permuted inside each 32-key block
  * (slot 8g+4a+r <- key 16a+4g+r): the K-contiguous A-operand layout of P*V matching the P register layout. */

@@ -72,6 +72,23 @@ def test_gemv_decode_shapes(M):
     assert_close_bf16(y, F.silu(_mm_ref(x, wg)) * _mm_ref(x, wu), what="gemv swiglu")
 
 
+@pytest.mark.parametrize("M,K", [(1, 4096), (4, 4096), (2, 1088), (1, 11008)])
+def test_gemv_fused_rmsnorm(M, K):
+    """decode-step input_layernorm -> projection in one launch == the two separate kernels == the reference ops."""
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    N, I = 264, 96
+    x, g, w = _rand(M, K, seed=41), _rand(K, seed=42) + 1.0, _rand(N, K, seed=43, scale=K ** -0.5)
+    xn = O.rms_norm(x, g, 1e-6)
+    y = ops.linear(x.to(DEV), w.to(DEV), rms_w=g.to(DEV), rms_eps=1e-6)
+    assert_close_bf16(y, _mm_ref(xn, w), what="gemv rmsnorm")
+    if K <= 8192:                                   # (the stand-alone row-norm kernel holds a row in registers: D <= 8192)
+        two = ops.linear(ops.rmsnorm(x.to(DEV), g.to(DEV), 1e-6), w.to(DEV))
+        assert_close_bf16(y, two.cpu(), ulps=1.0, what="fused vs rmsnorm kernel + gemv")
+    wg, wu = _rand(I, K, seed=44, scale=K ** -0.5), _rand(I, K, seed=45, scale=K ** -0.5)
+    y = ops.linear(x.to(DEV), M_.interleave_gate_up(wg, wu).to(DEV), swiglu=True, rms_w=g.to(DEV), rms_eps=1e-6)
+    assert_close_bf16(y, F.silu(_mm_ref(xn, wg)) * _mm_ref(xn, wu), what="gemv rmsnorm swiglu")
+
+
 def test_gemm_transpose_detecting():
     """A = I against an asymmetric W catches swapped operands / C layouts."""
     ops = pkg("ops")
@@ -151,6 +168,33 @@ def test_rope(hd, H):
     assert_close_bf16(out[:, :D].view(B, S, H, hd).transpose(1, 2), qr, ulps=1.0, what="rope q")
     assert_close_bf16(out[:, D:2 * D].view(B, S, H, hd).transpose(1, 2), kr, ulps=1.0, what="rope k")
     assert torch.equal(out[:, 2 * D:], qkv[:, 2 * D:]), "v must be untouched"
+
+
+def test_rope_append_matches_rope_plus_copies():
+    """decode-step RoPE + KV-cache append in one launch: q/k bit-equal to rope_inplace, cache rows/columns in place."""
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    B, S, H, hd, smax, past = 2, 3, 4, 128, 128, 37
+    D = H * hd
+    qkv = _rand(B * S, 3 * D, seed=46)
+    pos = (torch.arange(S)[None] + past + torch.tensor([[0], [5]])).reshape(-1)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(DEV)
+    a = qkv.to(DEV)
+    ops.rope_inplace(a, 3 * D, pos.to(DEV), inv, B * S, 2 * H, hd)
+    b = qkv.to(DEV)
+    kc = torch.full((B, H, smax, hd), 7.0, device=DEV, dtype=BF)
+    vtc = torch.full((B, H, hd, smax), 7.0, device=DEV, dtype=BF)
+    ops.rope_append(b, 3 * D, pos.to(DEV), inv, B, S, H, hd, kc, vtc, smax, past)
+    assert torch.equal(a[:, :D], b[:, :D]), "q"
+    ar = a.view(B, S, 3, H, hd)
+    for t in range(S):
+        assert torch.equal(kc[:, :, past + t], ar[:, t, 1]), "k row"
+        assert torch.equal(vtc[:, :, :, M_.KVCache.vt_slot(past + t)], ar[:, t, 2]), "v column"
+    untouched = torch.ones(smax, dtype=torch.bool)
+    untouched[past:past + S] = False
+    assert bool((kc[:, :, untouched.to(DEV)] == 7.0).all())
+    cols = torch.ones(smax, dtype=torch.bool)
+    cols[[M_.KVCache.vt_slot(past + t) for t in range(S)]] = False
+    assert bool((vtc[:, :, :, cols.to(DEV)] == 7.0).all())
 
 
 def _attn_ref(q, k, v, scale, causal, key_mask):

@@ -16,6 +16,7 @@ _i64, _i32, _f32, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_
 SIGNATURES = {
     "ull_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_gemv_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
+    "ull_gemv_rmsnorm_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "ull_shifted_cross_entropy_bf16": [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr],
     "ull_layernorm_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
@@ -23,6 +24,7 @@ SIGNATURES = {
     "ull_attention_bf16": [_ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64,
                            _ptr, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _ptr, _ptr, _i64, _i64, _i32, _ptr, _ptr],
     "ull_rope_inplace_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "ull_rope_append_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr],
     "ull_transpose_v_bf16": [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_im2col_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_mm_spans": [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],

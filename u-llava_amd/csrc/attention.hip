@@ -980,6 +980,55 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(bf16_t* __restrict__ 
     }
 }
 
+// Decode-step variant: RoPE on q (in place) and k, and the append of the new token's k / v to the KV cache, in one launch
+// (was rope + two strided copies per layer).  qkv rows = tokens (b, s) of a step, [q | k | v] heads contiguous; the token at
+// step position s goes to cache slot past + s: K cache [B, H, smax, hd] row past + s, V^T cache [B, H, hd, smax] column
+// vt_slot(past + s) (the key-permuted layout of transpose_v_kernel).  One block per token.
+__global__ __launch_bounds__(256) void rope_append_kernel(bf16_t* __restrict__ qkv, long row_stride, const int64_t* __restrict__ pos,
+                                                          const float* __restrict__ inv_freq, int S, int H, int hd, bf16_t* __restrict__ kc,
+                                                          bf16_t* __restrict__ vtc, int smax, int past) {
+    const long tok = blockIdx.x;
+    const int b = (int)(tok / S), s = (int)(tok % S);
+    const int half = hd >> 1;
+    const int cpr = half >> 3;
+    const int c = threadIdx.x % cpr;
+    const float pf = (float)pos[tok];
+    float cs[8], sn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = pf * inv_freq[c * 8 + j];
+        cs[j] = rbf(cosf(a));
+        sn[j] = rbf(sinf(a));
+    }
+    bf16_t* xr = qkv + tok * row_stride;
+    const int slot_k = past + s;
+    for (int hh = threadIdx.x / cpr; hh < 2 * H; hh += blockDim.x / cpr) {
+        bf16_t* p1 = xr + hh * hd + c * 8;
+        bf16_t* p2 = p1 + half;
+        float a[8], bb[8], o1[8], o2[8];
+        unpack8(*(const uint4*)p1, a);
+        unpack8(*(const uint4*)p2, bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o1[j] = rbf(a[j] * cs[j]) + rbf(-bb[j] * sn[j]);
+            o2[j] = rbf(bb[j] * cs[j]) + rbf(a[j] * sn[j]);
+        }
+        const uint4 r1 = pack8(o1), r2 = pack8(o2);
+        if (hh < H) {
+            *(uint4*)p1 = r1;
+            *(uint4*)p2 = r2;
+        } else {
+            bf16_t* kp = kc + (((long)b * H + (hh - H)) * smax + slot_k) * hd + c * 8;
+            *(uint4*)kp = r1;
+            *(uint4*)(kp + half) = r2;
+        }
+    }
+    const int w = slot_k & 31;
+    const int slot_v = (slot_k & ~31) + 8 * ((w >> 2) & 3) + 4 * (w >> 4) + (w & 3);
+    const bf16_t* vr = xr + 2 * H * hd;
+    for (int i = threadIdx.x; i < H * hd; i += blockDim.x) vtc[((long)b * H * hd + i) * smax + slot_v] = vr[i];
+}
+
 // V [B, S, H, hd] (token stride v_ss, heads contiguous) -> Vt [B, H, hd, pitch], zero-filled for keys >= S.
 // Inside every 32-key block the keys are stored permuted: slot 8g + 4a + r holds key 16a + 4g + r (a<2, g<4, r<4),
 // which is the (lane group g, element j = 4a + r) <-> key map that the attention kernel's probability registers
@@ -1175,6 +1224,18 @@ extern "C" int ull_rope_inplace_bf16(void* x, int64_t row_stride, const void* po
     if ((hd & 15) || hd > 256 || (cpr & (cpr - 1)) || (row_stride & 7)) return ULL_ERR_SHAPE;   // 256 % (hd/16) == 0
     hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, row_stride,
                        (const int64_t*)positions, (const float*)inv_freq, (int)n_heads, (int)hd);
+    return ull_check_launch();
+}
+
+// Decode step: RoPE on the q and k heads of the fused QKV rows + append of k (roped) and v to the KV cache (see the kernel).
+extern "C" int ull_rope_append_bf16(void* qkv, int64_t row_stride, const void* positions, const void* inv_freq, int64_t B, int64_t S,
+                                    int64_t H, int64_t hd, void* k_cache, void* vt_cache, int64_t smax, int64_t past, void* stream) {
+    if (!qkv || !positions || !inv_freq || !k_cache || !vt_cache || B <= 0 || S <= 0) return ULL_ERR_ARG;
+    const int64_t cpr = hd >> 4;
+    if ((hd & 15) || hd > 256 || (cpr & (cpr - 1)) || (row_stride & 7) || past + S > smax) return ULL_ERR_SHAPE;
+    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, row_stride,
+                       (const int64_t*)positions, (const float*)inv_freq, (int)S, (int)H, (int)hd, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+                       (int)smax, (int)past);
     return ull_check_launch();
 }
 

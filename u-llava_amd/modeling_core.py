@@ -364,30 +364,27 @@ class UllavaCoreForCausalLM(nn.Module):
         for li, w in enumerate(pk["llama"]):
             if output_hidden_states:
                 all_h.append(x.view(B, S, D))
-            y = ops.rmsnorm(x, w["ln1"], cfg.rms_norm_eps)
-            qkv = ops.linear(y, w["w_qkv"])
-            ops.rope_inplace(qkv, 3 * D, pos, inv_freq, T, 2 * H, hd)
+            decode = cache is not None and past > 0
+            qkv = ops.linear(x, w["w_qkv"], rms_w=w["ln1"], rms_eps=cfg.rms_norm_eps)      # input_layernorm -> q|k|v
             att = torch.empty(T, D, device=dev, dtype=BF16)
-            if cache is None:
-                vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
+            if decode:
+                # generation step: RoPE + cache append in one launch, then the split-key attention over the cache
+                kc, vtc = cache.k[li], cache.vt[li]
+                ops.rope_append(qkv, 3 * D, pos, inv_freq, B, S, H, hd, kc, vtc, cache.smax, past)
+                ops.attention(qkv, kc, vtc, att, B, H, S, past + S, hd, (S * 3 * D, hd, 3 * D), (H * cache.smax * hd, cache.smax * hd, hd),
+                              (S * D, hd, D), key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
+            else:
+                ops.rope_inplace(qkv, 3 * D, pos, inv_freq, T, 2 * H, hd)
+                if cache is None:
+                    vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
+                else:                                            # prefill that also fills the cache
+                    kc, vt = cache.k[li], cache.vt[li]
+                    kc[:, :, :S].copy_(qkv.view(B, S, 3, H, hd)[:, :, 1].permute(0, 2, 1, 3))
+                    ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd, pitch=cache.smax, out=vt)
                 ops.attention(qkv, qkv[:, D:], vt, att, B, H, S, S, hd, (S * 3 * D, hd, 3 * D), (S * 3 * D, hd, 3 * D), (S * D, hd, D),
                               key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
-            else:
-                kc, vtc = cache.k[li], cache.vt[li]
-                kv = qkv.view(B, S, 3, H, hd)
-                if past == 0:
-                    kc[:, :, :S].copy_(kv[:, :, 1].permute(0, 2, 1, 3))
-                    ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd, pitch=cache.smax, out=vtc)
-                else:
-                    for t in range(S):                       # generation appends one token at a time
-                        kc[:, :, past + t].copy_(kv[:, t, 1])
-                        vtc[:, :, :, KVCache.vt_slot(past + t)].copy_(kv[:, t, 2])
-                Sk = past + S
-                ops.attention(qkv, kc, vtc, att, B, H, S, Sk, hd, (S * 3 * D, hd, 3 * D), (H * cache.smax * hd, cache.smax * hd, hd),
-                              (S * D, hd, D), key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
             x = ops.linear(att, w["w_o"], residual=x)
-            y = ops.rmsnorm(x, w["ln2"], cfg.rms_norm_eps)
-            a = ops.linear(y, w["w_gu"], swiglu=True)
+            a = ops.linear(x, w["w_gu"], swiglu=True, rms_w=w["ln2"], rms_eps=cfg.rms_norm_eps)  # post_attention_layernorm -> gate|up
             x = ops.linear(a, w["w_down"], residual=x)
         x = ops.rmsnorm(x, self.model.norm.weight, cfg.rms_norm_eps)
         last = x.view(B, S, D)

@@ -62,14 +62,19 @@ def _rows(t: torch.Tensor):
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
            residual: Optional[torch.Tensor] = None, swiglu: bool = False, out: Optional[torch.Tensor] = None,
-           out_f32: bool = False) -> torch.Tensor:
-    """y = epilogue(x @ w.T).  x [..., K]; w [N, K] (nn.Linear layout).  swiglu: w is the 16-row interleaved gate/up pack."""
+           out_f32: bool = False, rms_w: Optional[torch.Tensor] = None, rms_eps: float = 0.0) -> torch.Tensor:
+    """y = epilogue(x @ w.T).  x [..., K]; w [N, K] (nn.Linear layout).  swiglu: w is the 16-row interleaved gate/up pack.
+    rms_w/rms_eps: apply LlamaRMSNorm to x first (fused into the GEMV prologue at decode shapes, a separate kernel otherwise)."""
     _chk(x, "x"); _chk(w, "w")
     M, ldx = _rows(x)
     N, K = w.shape
     lead = tuple(x.shape[:-1])
     if x.shape[-1] != K:
         raise RuntimeError(f"u-llava_amd.linear: K mismatch {x.shape[-1]} vs {K}")
+    if rms_w is not None and not (M <= 4 and K % 8 == 0 and M * K <= 16384):
+        x = rmsnorm(x, rms_w, rms_eps)
+        rms_w = None
+        M, ldx = _rows(x)
     if M <= 4 and K % 8 == 0:
         # decode shape: weight-streaming GEMV (no padding, no MFMA)
         n_out = N // 2 if swiglu else N
@@ -78,8 +83,13 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | \
             (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0)
         ldr = _rows(residual)[1] if residual is not None else 0
-        _lib.call("ull_gemv_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias), _p(residual), ldr, M, N, K, flags,
-                  _stream())
+        if rms_w is not None:
+            _chk(rms_w, "rms_w")
+            _lib.call("ull_gemv_rmsnorm_bf16", _p(x), ldx, _p(rms_w), float(rms_eps), _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias),
+                      _p(residual), ldr, M, N, K, flags, _stream())
+        else:
+            _lib.call("ull_gemv_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias), _p(residual), ldr, M, N, K, flags,
+                      _stream())
         return out
     if K % 64:
         # The MFMA kernel consumes K in 64-wide DMA tiles.  Every real width on the path (1024, 1280, 4096, 5120,
@@ -165,6 +175,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
 def rope_inplace(x: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_freq: torch.Tensor, tokens: int, n_heads: int, hd: int):
     _chk(x, "x"); _chk(positions, "positions", torch.int64); _chk(inv_freq, "inv_freq", torch.float32)
     _lib.call("ull_rope_inplace_bf16", _p(x), row_stride, _p(positions), _p(inv_freq), tokens, n_heads, hd, _stream())
+
+
+def rope_append(qkv: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_freq: torch.Tensor, B: int, S: int, H: int, hd: int,
+                k_cache: torch.Tensor, vt_cache: torch.Tensor, smax: int, past: int):
+    """decode step: RoPE on q (in place) and k + append of k / v to the KV cache (K [B,H,smax,hd], V^T [B,H,hd,smax] permuted)."""
+    _chk(qkv, "qkv"); _chk(positions, "positions", torch.int64); _chk(inv_freq, "inv_freq", torch.float32)
+    _chk(k_cache, "k_cache"); _chk(vt_cache, "vt_cache")
+    _lib.call("ull_rope_append_bf16", _p(qkv), row_stride, _p(positions), _p(inv_freq), B, S, H, hd, _p(k_cache), _p(vt_cache), smax, past,
+              _stream())
 
 
 def transpose_v(v: torch.Tensor, v_bs: int, v_ss: int, B: int, S: int, H: int, hd: int, pitch: Optional[int] = None,
