@@ -808,10 +808,12 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 // staging would buy nothing), and the waves meet three times in LDS: row max, row sum, partial O.  Same rounding points as the
 // register kernel (bf16 scores, exact two-step fp32 softmax, bf16 P); only the fp32 summation order of sum(exp) and of the
 // P*V partials differs.
-template <int HDP, int FL>
+//   TPW = tiles per wave held in registers: 1 for <= 1024 keys (decode; the wave's V^T fragments are then requested together
+//   with its K fragments, ahead of the softmax barriers), 4 for up to 4096 keys.
+template <int HDP, int FL, int TPW>
 __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NKS = HDP / 32, NDS = HDP / 16, TPW = 4;
+    constexpr int NKS = HDP / 32, NDS = HDP / 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int hd = head_dim_of<HDP, FL>(p);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -878,6 +880,16 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
             }
         }
     }
+    uint4 vpre[2][NDS];                                         // TPW == 1: this wave's V^T fragments, in flight across the barriers
+    if constexpr (TPW == 1) {
+        if (wave < nkt) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ds = 0; ds < NDS; ++ds)
+                    if (ds * 16 < hd) vpre[kk][ds] = *(const uint4*)(vbase + (long)(ds * 16 + fr) * p.vt_ds + wave * KT + (kk * 4 + fg) * 8);
+        }
+    }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     if (fg == 0) red[wave * 16 + fr] = m;
@@ -923,7 +935,9 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
 #pragma unroll
                 for (int ds = 0; ds < NDS; ++ds) {
                     if (ds * 16 < hd) {
-                        const uint4 vf = *(const uint4*)(vbase + (long)(ds * 16 + fr) * p.vt_ds + kt * KT + (kk * 4 + fg) * 8);
+                        uint4 vf;
+                        if constexpr (TPW == 1) vf = vpre[kk][ds];
+                        else vf = *(const uint4*)(vbase + (long)(ds * 16 + fr) * p.vt_ds + kt * KT + (kk * 4 + fg) * 8);
                         oacc[ds] = mfma16(vf, pf, oacc[ds]);
                     }
                 }
@@ -1108,18 +1122,23 @@ int launch_stream(const AttnArgs& a, hipStream_t st) {
     return ull_check_launch();
 }
 
+template <int HDP, int FL, int TPW>
+int launch_fewq_t(const AttnArgs& a, int nwv, hipStream_t st) {
+    const int lds = 2 * 16 * 16 * 4 + nwv * HDP * 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fewq_kernel<HDP, FL, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_fewq_kernel<HDP, FL, TPW>), dim3(a.B * a.H), dim3(nwv * 64), lds, st, a);
+    return ull_check_launch();
+}
+
 template <int HDP, int FL>
 int launch_fewq(const AttnArgs& a, hipStream_t st) {
     const int nt = (a.Sk + KT - 1) / KT;
     const int nwv = nt < 16 ? nt : 16;
-    const int lds = 2 * 16 * 16 * 4 + nwv * HDP * 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fewq_kernel<HDP, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((attn_fewq_kernel<HDP, FL>), dim3(a.B * a.H), dim3(nwv * 64), lds, st, a);
-    return ull_check_launch();
+    return nt <= 16 ? launch_fewq_t<HDP, FL, 1>(a, nwv, st) : launch_fewq_t<HDP, FL, 4>(a, nwv, st);
 }
 
 // Which straight-line flavor (if any) the arguments correspond to.
