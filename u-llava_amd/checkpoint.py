@@ -1,0 +1,170 @@
+"""HF-format checkpoint directories <-> the MI355X modules.
+
+reference: `UllavaCoreForCausalLM.from_pretrained(path, torch_dtype=...)` (inference_ullava_core.py:35, train_ullava_core.py:94) and
+`UllavaForCausalLM.from_pretrained(...)` (inference_ullava.py:37, evaluation/eval_ullava.py:135, webui/gradio_chat.py:26) go through
+transformers' PreTrainedModel loader: `config.json` + either one weight file or an index json naming shards, safetensors or
+torch-pickle.  This module reads the same directory layouts without importing transformers:
+
+    config.json
+    model.safetensors                | pytorch_model.bin
+    model.safetensors.index.json     | pytorch_model.bin.index.json   -> {"weight_map": {param_name: shard_file}}
+
+Shards are streamed one at a time (a LLaMA-7B checkpoint is 13.5 GB; the host never holds more than one shard), parameters are
+copied into the already-allocated device tensors, and the key-name drift between transformers 4.29 checkpoints and the module tree
+(`vision_encoder.vision_model.*`, `rotary_emb.inv_freq`, `position_ids`) is handled by the modules' own
+`load_state_dict`.  `save_pretrained` writes the reference's key names back, so a directory written here loads in the reference.
+"""
+import json
+import os
+from typing import Dict, Iterable, Iterator, List, Optional, Tuple
+
+import torch
+
+WEIGHT_FILES = ("model.safetensors", "pytorch_model.bin")
+INDEX_FILES = ("model.safetensors.index.json", "pytorch_model.bin.index.json")
+_SKIP = ("position_ids", "rotary_emb.inv_freq")
+
+
+def read_config(path: str) -> dict:
+    with open(os.path.join(path, "config.json")) as f:
+        return json.load(f)
+
+
+def shard_files(path: str) -> List[str]:
+    """Weight files of a checkpoint directory, in a deterministic order."""
+    for idx in INDEX_FILES:
+        p = os.path.join(path, idx)
+        if os.path.exists(p):
+            with open(p) as f:
+                wm = json.load(f)["weight_map"]
+            return [os.path.join(path, n) for n in sorted(set(wm.values()))]
+    for w in WEIGHT_FILES:
+        p = os.path.join(path, w)
+        if os.path.exists(p):
+            return [p]
+    raise FileNotFoundError(f"u-llava_amd: no {' / '.join(WEIGHT_FILES + INDEX_FILES)} under {path}")
+
+
+def _load_file(fn: str) -> Dict[str, torch.Tensor]:
+    if fn.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(fn, device="cpu")
+    return torch.load(fn, map_location="cpu", weights_only=True, mmap=True)
+
+
+def iter_shards(path: str) -> Iterator[Dict[str, torch.Tensor]]:
+    for fn in shard_files(path):
+        yield _load_file(fn)
+
+
+def _canon(key: str, has_vm_prefix: bool) -> str:
+    """checkpoint key -> module key (the inverse of `_reference_key`)."""
+    return key.replace("vision_encoder.vision_model.", "vision_encoder.") if has_vm_prefix else key
+
+
+def load_into(model: torch.nn.Module, path: str, strict: bool = True) -> Tuple[List[str], List[str]]:
+    """Copy every tensor of the checkpoint at `path` into `model`'s parameters/buffers, shard by shard.
+    Returns (missing, unexpected); raises on either when strict (like load_state_dict)."""
+    own = dict(model.state_dict())
+    seen, unexpected = set(), []
+    for shard in iter_shards(path):
+        for k, v in shard.items():
+            if any(s in k for s in _SKIP):
+                continue
+            ck = _canon(k, True)
+            if ck not in own:
+                unexpected.append(k)
+                continue
+            dst = own[ck]
+            if tuple(dst.shape) != tuple(v.shape):
+                raise RuntimeError(f"u-llava_amd: size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(dst.shape)}")
+            with torch.no_grad():
+                dst.copy_(v.to(dst.dtype))
+            seen.add(ck)
+        del shard
+    missing = [k for k in own if k not in seen and not any(s in k for s in _SKIP)]
+    if strict and (missing or unexpected):
+        raise RuntimeError(f"u-llava_amd: checkpoint {path} does not match the model: missing {missing[:8]}{'...' if len(missing) > 8 else ''}, "
+                           f"unexpected {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
+    return missing, unexpected
+
+
+def _reference_key(key: str) -> str:
+    """module key -> the name the reference's module tree gives the same tensor (CLIPVisionModel nests `.vision_model.`)."""
+    for pre in ("llm.vision_encoder.", "vision_encoder."):
+        if key.startswith(pre) and not key.startswith(pre + "vision_model."):
+            return pre + "vision_model." + key[len(pre):]
+    return key
+
+
+def save_pretrained(model: torch.nn.Module, path: str, max_shard_bytes: int = 5 << 30, safe_serialization: bool = True):
+    """config.json + (sharded) weights under the reference's parameter names."""
+    os.makedirs(path, exist_ok=True)
+    cfg = model.config.to_dict()
+    cfg["architectures"] = [type(model).__name__]
+    cfg["torch_dtype"] = "bfloat16"
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f, indent=2, sort_keys=True)
+    sd = {_reference_key(k): v.detach().to("cpu").contiguous() for k, v in model.state_dict().items()}
+    shards, cur, size = [], {}, 0
+    for k in sorted(sd):
+        n = sd[k].numel() * sd[k].element_size()
+        if cur and size + n > max_shard_bytes:
+            shards.append(cur)
+            cur, size = {}, 0
+        cur[k] = sd[k]
+        size += n
+    shards.append(cur)
+    ext = "safetensors" if safe_serialization else "bin"
+    stem = "model" if safe_serialization else "pytorch_model"
+
+    def write(d, fn):
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(d, fn, metadata={"format": "pt"})
+        else:
+            torch.save(d, fn)
+
+    if len(shards) == 1:
+        write(shards[0], os.path.join(path, f"{stem}.{ext}"))
+        return
+    wm = {}
+    for i, d in enumerate(shards):
+        name = f"{stem}-{i + 1:05d}-of-{len(shards):05d}.{ext}"
+        write(d, os.path.join(path, name))
+        wm.update({k: name for k in d})
+    total = sum(v.numel() * v.element_size() for v in sd.values())
+    with open(os.path.join(path, f"{stem}.{ext}.index.json"), "w") as f:
+        json.dump({"metadata": {"total_size": total}, "weight_map": wm}, f, indent=2, sort_keys=True)
+
+
+def _dtype_arg(torch_dtype):
+    if torch_dtype not in (None, torch.bfloat16, "bfloat16", "bf16"):
+        raise NotImplementedError("the MI355X path computes in bf16 (reference configs: bf16: true); pass torch_dtype=torch.bfloat16")
+    return torch.bfloat16
+
+
+def core_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict: bool = True, **config_overrides):
+    from .configuration import UllavaCoreConfig
+    raw = read_config(path)
+    raw.update(config_overrides)
+    model = cls(UllavaCoreConfig(**raw), device=device, dtype=_dtype_arg(torch_dtype))
+    load_into(model, path, strict=strict)
+    model._packed = None
+    return model
+
+
+def ullava_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict: bool = True, **config_overrides):
+    from .configuration import UllavaConfig
+    raw = read_config(path)
+    raw.update(config_overrides)
+    model = cls(UllavaConfig(**raw), device=device, dtype=_dtype_arg(torch_dtype))
+    # stage-2 checkpoints may ship without the frozen SAM encoder (it is loaded from sam_vit_h.pth by load_visual_checkpoint,
+    # reference ullava.py:134-137): tolerate exactly that family of missing keys
+    missing, unexpected = load_into(model, path, strict=False)
+    hard_missing = [k for k in missing if not k.startswith("visual_model.image_encoder.")]
+    if strict and (hard_missing or unexpected):
+        raise RuntimeError(f"u-llava_amd: checkpoint {path} does not match the model: missing {hard_missing[:8]}, unexpected {unexpected[:8]}")
+    model.llm._packed = None
+    model._sam.invalidate()
+    return model

@@ -203,6 +203,16 @@ class UllavaCoreForCausalLM(nn.Module):
         self.config.mm_token_ids = ids
         self.mm_token_ids = ids
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, device=None, **kwargs):
+        """reference: inference_ullava_core.py:35 / train_ullava_core.py:94 (PreTrainedModel.from_pretrained on a local directory)."""
+        from .checkpoint import core_from_pretrained
+        return core_from_pretrained(cls, pretrained_model_name_or_path, torch_dtype, device, **kwargs)
+
+    def save_pretrained(self, save_directory, **kwargs):
+        from .checkpoint import save_pretrained
+        return save_pretrained(self, save_directory, **kwargs)
+
     def load_state_dict(self, state_dict, strict=True, assign=False):
         # transformers 4.29.1 checkpoints nest the CLIP tower under `vision_encoder.vision_model.` (SURVEY section 5)
         sd = {k.replace("vision_encoder.vision_model.", "vision_encoder."): v for k, v in state_dict.items()}

@@ -45,6 +45,16 @@ class UllavaForCausalLM(nn.Module):
         self.det_decoder = _mlp_seq([O, O, O // 2, 4], device, dtype)                         # ullava.py:96-102
         self._sam = SamEngine(self.visual_model, config.sam_config)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, device=None, **kwargs):
+        """reference: inference_ullava.py:37, evaluation/eval_ullava.py:135, webui/gradio_chat.py:26."""
+        from .checkpoint import ullava_from_pretrained
+        return ullava_from_pretrained(cls, pretrained_model_name_or_path, torch_dtype, device, **kwargs)
+
+    def save_pretrained(self, save_directory, **kwargs):
+        from .checkpoint import save_pretrained
+        return save_pretrained(self, save_directory, **kwargs)
+
     def load_state_dict(self, state_dict, strict=True, assign=False):
         sd = {k.replace("llm.vision_encoder.vision_model.", "llm.vision_encoder."): v for k, v in state_dict.items()}
         sd = {k: v for k, v in sd.items() if not k.endswith("position_ids") and "rotary_emb.inv_freq" not in k}
