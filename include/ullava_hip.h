@@ -151,6 +151,26 @@ int ull_mask_matmul_bf16(const void* hyper, const void* up, void* masks, int64_t
 int ull_bilinear_f32(const void* in, int in_is_bf16, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w, void* out,
                      int64_t n, int64_t out_h, int64_t out_w, void* stream);
 
+/* ---- image pre/post-processing either side of the path (byte / integer work, bit-exact against the host libraries) ------------- */
+
+/* One separable pass of Pillow's 8-bit resampler (libImaging/Resample.c ImagingResampleHorizontal_8bpc / Vertical_8bpc) over a
+ * uint8 [H, W, C] image: axis 1 -> dst [H, out_size, C], axis 0 -> dst [out_size, W, C].  bounds int32 [out_size, 2] = (first tap,
+ * tap count); coeffs int32 [out_size, ksize] = the 22-bit fixed-point taps (precompute_coeffs + normalize_coeffs_8bpc, computed
+ * by the host).  Replaces PIL.Image.resize inside transformers CLIPImageProcessor (dataset/processors/clip_processor.py:93) and
+ * inside ResizeLongestSide.apply_image (models/segment_anything/utils/transforms.py:27-35). */
+int ull_resample_u8(const void* src, int64_t H, int64_t W, int64_t C, int axis, int64_t out_size, const void* bounds, const void* coeffs,
+                    int64_t ksize, void* dst, void* stream);
+
+/* uint8 [H, W, 3] -> fp32 / bf16 [3, OH, OW]: dst[c][y][x] = lut[c][src[top+y][left+x][c]] for y < copy_h, x < copy_w, else 0.
+ * lut fp32 [3, 256] holds the reference's normalisation of every byte value.  CLIP: center crop + /255 + (x-mean)/std
+ * (transformers rescale + normalize); SAM: (x-mean)/std + zero pad to 1024 (dataset/tools/mask_toolbox.py:15-25). */
+int ull_u8_lut_chw(const void* src, int64_t H, int64_t W, int64_t C, int64_t top, int64_t left, const void* lut, void* dst, int64_t OH,
+                   int64_t OW, int64_t copy_h, int64_t copy_w, int out_bf16, void* stream);
+
+/* evaluation/tools.py:29-41 intersectionAndUnionGPU(K = 2) on (logits > 0) (trainers/ullava_trainer.py:44): logits fp32
+ * [n, hw], target uint8 [n, hw]; counts int32 [n, 6] += {inter0, inter1, out0, out1, tgt0, tgt1}, ignore_index pixels dropped. */
+int ull_mask_iou_counts(const void* logits, const void* target, int64_t n_masks, int64_t hw, int ignore_index, void* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
