@@ -34,6 +34,8 @@ constexpr int GROUP_M = 8;
 // epilogue flag bits (mirrored in include/ullava_hip.h)
 constexpr int EPI_BIAS = 1, EPI_ACT_SHIFT = 1, EPI_ACT_MASK = 3 << 1;  // act: 0 none 1 quick_gelu 2 gelu(erf) 3 relu
 constexpr int EPI_RESID = 8, EPI_SWIGLU = 16, EPI_OUT_F32 = 32;
+// operand stored tile-major [rows/256][K/64][256][64] (every 256 x 64 K-tile = 32 contiguous KiB); big kernel only
+constexpr int EPI_W_TILED = 64, EPI_X_TILED = 128;
 
 struct GemmArgs {
     const bf16_t* X; const bf16_t* W; void* C;
@@ -358,6 +360,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int bm = first_m + (bid % per_group) % gsz;
     const int bn = (bid % per_group) / gsz;
     const int m0 = bm * BM, n0 = bn * BN;
+    const int nk_total = p.K / BK;
+    const bool w_tiled = p.flags & EPI_W_TILED, x_tiled = p.flags & EPI_X_TILED;
 
     // DMA: a 1-KiB piece = 8 rows x 128 B; wave w stages pieces 4w..4w+3 of X and of W.
     const int srow = lane >> 3;
@@ -367,18 +371,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + srow;
-        xsrc[i] = p.X + (long)min(m0 + r, p.M - 1) * p.ldx + schunk * 8;
-        wsrc[i] = p.W + (long)min(n0 + r, p.N - 1) * p.ldw + schunk * 8;
+        xsrc[i] = x_tiled ? p.X + (((long)bm * nk_total) * BM + r) * BK + schunk * 8
+                          : p.X + (long)min(m0 + r, p.M - 1) * p.ldx + schunk * 8;
+        wsrc[i] = w_tiled ? p.W + (((long)bn * nk_total) * BN + r) * BK + schunk * 8
+                          : p.W + (long)min(n0 + r, p.N - 1) * p.ldw + schunk * 8;
     }
+    const long xstep = x_tiled ? BM * BK : BK, wstep = w_tiled ? BN * BK : BK;    // elements between consecutive K-tiles
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     const uint32_t piece_off = wave * 4 * 1024;
     auto stage = [&](int kt) {
         const uint32_t bx = lds_base + (kt & 1) * SLOT_BYTES + piece_off;
-        const long ko = (long)kt * BK;
+        const long kox = (long)kt * xstep, kow = (long)kt * wstep;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            glds16(xsrc[i] + ko, bx + i * 1024);
-            glds16(wsrc[i] + ko, bx + OP_BYTES + i * 1024);
+            glds16(xsrc[i] + kox, bx + i * 1024);
+            glds16(wsrc[i] + kow, bx + OP_BYTES + i * 1024);
         }
     };
 
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     if (split) {
         const int kt0 = (int)((long)nk * slice / p.sk), kt1 = (int)((long)nk * (slice + 1) / p.sk);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xsrc[i] += (long)kt0 * BK; wsrc[i] += (long)kt0 * BK; }
+        for (int i = 0; i < 4; ++i) { xsrc[i] += (long)kt0 * xstep; wsrc[i] += (long)kt0 * wstep; }
         nk = kt1 - kt0;
     }
     stage(0);
