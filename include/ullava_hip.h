@@ -36,6 +36,9 @@ extern "C" {
  * hf clip/modeling_clip.py CLIPAttention, CLIPMLP; models/ullava_core.py:117-129 (vision_projector), :325 (lm_head);
  * models/ullava.py:86-118 (seg/det projector, det_decoder); segment_anything/modeling/image_encoder.py:235-260,
  * common.py:13-26, transformer.py:220-242, mask_decoder.py:169-191. */
+/* flags also accepts ULL_EPI_W_TILED (64) / ULL_EPI_X_TILED (128): that operand is stored tile-major
+ * [rows/256][K/64][256][64] (rows zero-padded to a multiple of 256; every 256 x 64 K-tile = 32 contiguous KiB, which makes an L2
+ * miss cheaper: +4 % on the LLaMA layer GEMMs).  Only with M >= 1024, N >= 512, K >= 128 (the 256 x 256 kernel); ldw / ldx ignored. */
 int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                   int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 

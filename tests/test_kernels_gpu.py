@@ -304,3 +304,20 @@ def test_gather_and_add():
     assert torch.equal(ops.gather_rows(src.to(DEV), idx.to(DEV)).cpu(), src[idx])
     a, b = _rand(6, 4, 128, seed=81), _rand(4, 128, seed=82)
     assert torch.equal(ops.add_rows(a.to(DEV), b.to(DEV)).cpu(), a + b)
+
+
+def test_gemm_tile_major_weight_is_bit_identical():
+    """ULL_EPI_W_TILED: the same GEMM from a tile-major copy of W (incl. a ragged last row tile and the stream-K tail)."""
+    ops = pkg("ops")
+    M, N, K = 1300, 1000, 320
+    x, w, b = _rand(M, K, seed=51), _rand(N, K, seed=52, scale=K ** -0.5), _rand(N, seed=53)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    plain = ops.linear(xd, wd, bd, act="relu")
+    ops.register_tiled(wd)
+    assert ops._tiled_of(wd) is not None and tuple(ops._tiled_of(wd).shape) == (4, 5, 256, 64)
+    tiled = ops.linear(xd, wd, bd, act="relu")
+    assert torch.equal(plain, tiled)
+    assert_close_bf16(tiled, F.relu(F.linear(x.float(), w.float(), b.float()).to(BF)), ulps=2.0, what="tiled gemm vs reference")
+    small = ops.linear(xd[:8], wd, bd)                  # decode / small-M shapes keep using the row-major tensor
+    assert_close_bf16(small, F.linear(x[:8].float(), w.float(), b.float()).to(BF), what="small-M with a registered tiled copy")
+    ops._TILED.clear()

@@ -615,6 +615,7 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         if (a.sk > 1) hipLaunchKernelGGL(big::splitk_finalize_kernel, dim3(32, rem), dim3(256), 0, (hipStream_t)stream, a);
         return ull_check_launch();
     }
+    if (flags & (EPI_W_TILED | EPI_X_TILED)) return ULL_ERR_SHAPE;      // tile-major operands: 256x256 kernel only
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);

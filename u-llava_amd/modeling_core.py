@@ -244,6 +244,15 @@ class UllavaCoreForCausalLM(nn.Module):
         wp = torch.zeros(w.shape[0], Kp, device=w.device, dtype=w.dtype)
         wp[:, :K] = w.reshape(w.shape[0], K)
         pk["patch_w"], pk["patch_Kp"] = wp, Kp
+        # tile-major copies for the prefill-shape GEMM (+13.5 GB for LLaMA-7B; sized for 288 GB of HBM).  The row-major
+        # tensors stay: they feed the decode GEMV, which streams whole rows.
+        for d in pk["llama"]:
+            for k in ("w_qkv", "w_o", "w_gu", "w_down"):
+                ops.register_tiled(d[k])
+        for d in pk["clip"]:
+            for t in (d["w_qkv"], d["w_out"], d["fc1"].weight, d["fc2"].weight):
+                ops.register_tiled(t)
+        ops.register_tiled(self.lm_head.weight)
         self._packed = pk
         if free_originals:
             for l in self.model.layers:

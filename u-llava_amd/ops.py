@@ -60,6 +60,39 @@ def _rows(t: torch.Tensor):
     return t.numel() // t.shape[-1], t.shape[-1]
 
 
+EPI_W_TILED = 64
+_NO_TILED = bool(__import__("os").environ.get("ULL_NO_TILED"))
+_TILED = {}          # data_ptr of a row-major weight -> (weakref to it, its tile-major copy)
+
+
+def tile_major(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] (K % 64 == 0) -> [ceil(N/256), K/64, 256, 64] contiguous: the ULL_EPI_W_TILED layout of ull_gemm_bf16."""
+    N, K = w.shape
+    Np = (N + 255) // 256 * 256
+    if Np != N:
+        w = torch.cat([w, w.new_zeros(Np - N, K)])
+    return w.view(Np // 256, 256, K // 64, 64).permute(0, 2, 1, 3).contiguous()
+
+
+def register_tiled(w: torch.Tensor) -> None:
+    """Keep a tile-major copy of a weight for the prefill-shape GEMM (the row-major original still feeds the decode GEMV)."""
+    import weakref
+    if w.dim() == 2 and w.shape[1] % 64 == 0 and w.shape[0] >= 512 and w.shape[1] >= 128 and w.is_contiguous():
+        _TILED[w.data_ptr()] = (weakref.ref(w), tile_major(w))
+
+
+def _tiled_of(w: torch.Tensor):
+    if _NO_TILED:
+        return None
+    e = _TILED.get(w.data_ptr())
+    if e is None:
+        return None
+    if e[0]() is not w:
+        _TILED.pop(w.data_ptr(), None)       # the address was recycled by another tensor
+        return None
+    return e[1]
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
            residual: Optional[torch.Tensor] = None, swiglu: bool = False, out: Optional[torch.Tensor] = None,
            out_f32: bool = False, rms_w: Optional[torch.Tensor] = None, rms_eps: float = 0.0) -> torch.Tensor:
@@ -111,7 +144,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         _chk(residual, "residual")
         _, ldr = _rows(residual)
     _, ldc = _rows(out)
-    _lib.call("ull_gemm_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags, _stream())
+    wt = _tiled_of(w) if (M >= 1024 and N >= 512 and K >= 128) else None
+    if wt is not None:
+        _lib.call("ull_gemm_bf16", _p(x), ldx, _p(wt), K, _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags | EPI_W_TILED, _stream())
+    else:
+        _lib.call("ull_gemm_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags, _stream())
     return out
 
 

@@ -137,6 +137,11 @@ class SamEngine:
         pk["up0_b"] = u0.bias.repeat(4).contiguous()
         pk["up3_w"] = u3.weight.permute(2, 3, 1, 0).reshape(-1, u3.weight.shape[0]).contiguous()
         pk["up3_b"] = u3.bias.repeat(4).contiguous()
+        # tile-major copies of the encoder's big Linears for the prefill-shape GEMM (see ops.register_tiled)
+        for blk in enc.blocks:
+            for t in (blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.lin1.weight, blk.mlp.lin2.weight):
+                ops.register_tiled(t)
+        ops.register_tiled(pk["patch_w"])
         self._pk = pk
         return pk
 
