@@ -113,15 +113,17 @@ def gemm_roofline(cfg, tokens, device, iters=5):
         tot_t += ms
         tot_f += fl
     achieved = tot_f / tot_t / 1e9
-    traffic = None
-    try:   # PMC pass recorded separately (rocprofv3 --pmc cannot run inside this process): profiles/r01_gemm_traffic.json
+    traffic, detail = None, None
+    try:   # PMC passes are recorded separately (rocprofv3 --pmc cannot run inside this process): profiles/r01_gemm_traffic.json
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))
-        traffic = {"bytes_per_launch": tj["traffic_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
-                   "kernel": tj["kernel"], "note": tj["note"]}
+        traffic = tj["traffic_bytes_per_launch"]
+        detail = {"kernel": tj["kernel"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"], "note": tj["note"],
+                  "mfma_pipe_busy_fraction": tj.get("mfma", {}).get("mfma_pipe_busy_fraction_of_simd_cycles")}
     except Exception:
         pass
-    return dict(bound="mfma", kernel="gemm_bf16_nt_kernel (LLaMA-7B layer: qkv, o, gate/up+SwiGLU, down)", achieved=round(achieved, 1),
-                peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic, per_launch=per)
+    return dict(bound="mfma", kernel="big::gemm256_kernel (LLaMA-7B layer: qkv, o, gate/up+SwiGLU, down; 2*M*N*K flop per launch)",
+                achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
+                traffic=traffic, traffic_detail=detail, per_launch=per)
 
 
 def cpu_baseline(image_size, prompt_tokens):
