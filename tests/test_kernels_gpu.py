@@ -214,7 +214,8 @@ def _attn_ref(q, k, v, scale, causal, key_mask):
 
 @pytest.mark.parametrize("B,H,S,hd,causal,masked", [(2, 4, 11, 16, True, True), (1, 2, 5, 16, False, False), (2, 3, 257, 64, False, False),
                                                     (2, 2, 291, 128, True, True), (1, 2, 643, 128, True, False), (1, 1, 196, 80, False, False),
-                                                    (1, 2, 1024, 128, True, False)])
+                                                    (1, 2, 1024, 128, True, False), (2, 2, 1500, 128, True, True),
+                                                    (1, 1, 2048, 128, True, False)])
 def test_attention(B, H, S, hd, causal, masked):
     ops = pkg("ops")
     D = H * hd
@@ -240,6 +241,31 @@ def test_attention(B, H, S, hd, causal, masked):
         valid = km.bool().reshape(-1)
         got, ref = got[valid], ref[valid]
     assert_close_bf16(got, ref, ulps=2.0, what=f"attention S={S} hd={hd}", outlier_frac=1e-3, outlier_floor=float(v.float().abs().max()))
+
+
+@pytest.mark.parametrize("Sq,Sk,left_pad", [(1, 70, 0), (1, 700, 13), (3, 1024, 0), (2, 2000, 100), (16, 4096, 0)])
+def test_attention_decode_step_shapes(Sq, Sk, left_pad):
+    """<= 16 new queries against a longer key cache (KV-cached generation incl. left-padded prompts; few-query split-key kernel up to
+    4096 keys): causal offset Sk - Sq, key mask, K / V^T read by cache strides."""
+    ops = pkg("ops")
+    B, H, hd = 2, 4, 128
+    D = H * hd
+    q, k, v = _rand(B, H, Sq, hd, seed=60 + Sk), _rand(B, H, Sk, hd, seed=61 + Sk), _rand(B, H, Sk, hd, seed=62 + Sk)
+    km = torch.ones(B, Sk, dtype=torch.int32)
+    if left_pad:
+        km[1, :left_pad] = 0
+    ref = _attn_ref(q, k, v, hd ** -0.5, True, km)                                   # [B, H, Sq, hd]
+    smax = ((Sk + 63) // 64) * 64 + 64
+    kc = torch.zeros(B, H, smax, hd, dtype=BF)
+    kc[:, :, :Sk] = k
+    vsrc = v.transpose(1, 2).reshape(B * Sk, D).to(DEV)                              # [B*Sk, H*hd] token-major
+    vtc = ops.transpose_v(vsrc, Sk * D, D, B, Sk, H, hd, pitch=smax)
+    qd = q.transpose(1, 2).reshape(B * Sq, D).contiguous().to(DEV)                   # [B*Sq, H*hd]
+    out = torch.empty(B * Sq, D, device=DEV, dtype=BF)
+    ops.attention(qd, kc.to(DEV), vtc, out, B, H, Sq, Sk, hd, (Sq * D, hd, D), (H * smax * hd, smax * hd, hd), (Sq * D, hd, D), km.to(DEV),
+                  causal=True, scale_mode=1, scale=hd ** -0.5)
+    got = out.cpu().view(B, Sq, H, hd).transpose(1, 2)
+    assert_close_bf16(got, ref, ulps=2.0, what=f"decode attention {Sq}x{Sk}", outlier_frac=2e-3, outlier_floor=float(v.float().abs().max()))
 
 
 def test_patch_embed_and_clip_pre_ln():
