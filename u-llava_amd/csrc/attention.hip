@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
 //   is one grid row, so rel_h is ONE value per (query, tile) and the 16 rel_w values of a lane are the same for every tile:
 //   they live in registers and the per-score table lookups / index arithmetic / LDS bias rows disappear; without the mask
 //   bytes and bias rows a block needs 64 KiB of LDS and two blocks share a CU.
-template <int HDP, int FL, bool HOIST>
+template <int HDP, int FL, int HOIST>
 __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NWV = 8, BQ = 16 * NWV;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             const int d = ks * 32 + fg * 8;
             qf[ks] = (qi < p.Sq && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
         }
-        if constexpr (!HOIST) {
+        if constexpr (HOIST == 0) {
             for (int j = tid; j < nkt * KT; j += 512) {
                 unsigned char m = 2;
                 if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
@@ -659,7 +659,8 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     int bh_off = 0, bw_off = 0;
     float rw[16];                                              // HOIST: rel_w of this lane's 16 key columns
     const bf16_t* rh_row = nullptr;                            // HOIST: rel_h row of this lane's query
-    if constexpr (HOIST) {
+    float gh[4][4];                                            // HOIST 2: rel_h of this wave's 16 queries, see below
+    if constexpr (HOIST == 1) {
         const long row = (long)head * p.Sq + qic;
         const bf16_t* wrow = p.rel_w + row * p.KW;
 #pragma unroll
@@ -669,6 +670,49 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             rw[ns * 4 + 2] = bf2f((bf16_t)(v.y & 0xffff)); rw[ns * 4 + 3] = bf2f((bf16_t)(v.y >> 16));
         }
         rh_row = p.rel_h + row * p.KH;
+    } else if constexpr (HOIST == 2) {
+        // raw rel_pos_h / rel_pos_w [127, hd] (64 x 64 grid): G[q][t] = bf16(q . rel_pos[t]) on the MFMA (A = table rows, B = the
+        // UNSCALED query fragments), rel_w[q][kw] = Gw[q][qx - kw + 63], rel_h[q][kh] = Gh[q][qy - kh + 63] (image_encoder.py:354-392).
+        // Gw: all 127 rows -> this wave's 4-KiB LDS pad (aliases the tile buffers, which are not in use yet) -> 16 registers.
+        bf16_t* gw = (bf16_t*)(smem + wave * 4096);            // [16 queries][128]
+#pragma unroll 2
+        for (int st = 0; st < 8; ++st) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const bf16_t* tr = p.rel_w + (long)min(st * 16 + fr, 126) * hd + fg * 8;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks * 32 < hd) {
+                    const uint4 a = (ks * 32 + fg * 8 < hd) ? *(const uint4*)(tr + ks * 32) : make_uint4(0, 0, 0, 0);
+                    acc = mfma16(a, qf[ks], acc);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gw[fr * 128 + st * 16 + fg * 4 + r] = f2bf(acc[r]);      // G[t = st*16 + 4*fg + r][query fr]
+        }
+        // Gh: the 16 queries of a wave share qy, so the 64 table rows they need are qy - kh + 63; group g (kh = 16g .. 16g+15) is
+        // rows base_g .. base_g + 15 with base_g = qy - 16g + 48, one MFMA chain per group, kept in registers: lane (fr, fg')
+        // holds gh[g][r] = Gh[query fr][base_g + 4*fg' + r]; tile kh = 16g + j needs row index 15 - j.
+        const int qy = (q0 + wave * 16) >> 6;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const bf16_t* tr = p.rel_h + (long)min(max(qy - 16 * g + 48 + fr, 0), 126) * hd + fg * 8;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks * 32 < hd) {
+                    const uint4 a = (ks * 32 + fg * 8 < hd) ? *(const uint4*)(tr + ks * 32) : make_uint4(0, 0, 0, 0);
+                    acc = mfma16(a, qf[ks], acc);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gh[g][r] = rbf(acc[r]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own pad only
+        const int qx = qic & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rw[i] = bf2f(gw[fr * 128 + qx - ((i >> 2) * 16 + fg * 4 + (i & 3)) + 63]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // every wave is done with its pad before tile 0 is DMA'd over it
     } else if (p.rel_h != nullptr) {
         const int bp = bias_pitch(p);
         stage_rel_bias<NKS>(p, biasb + wave * 16 * bp, bp, qf, q0 + wave * 16, head, lane, bh_off, bw_off, hd);
@@ -712,15 +756,11 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
-    float rh = 0.f;
-    if constexpr (HOIST) rh = bf2f(rh_row[0]);
-    issue(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    // one 64-key tile: scores (+ bias), running max, P, P*V
+    auto tile = [&](int kt, float rh) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         issue(kt + 1);
-        float rh_next = 0.f;
-        if constexpr (HOIST) rh_next = bf2f(rh_row[min(kt + 1, p.KH - 1)]);
         const char* tb = smem + (kt & 1) * (2 * TILE);
         float sv[16];
 #pragma unroll
@@ -734,7 +774,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                     acc = mfma16(kf, qf[ks], acc);
                 }
             }
-            if constexpr (HOIST) {
+            if constexpr (HOIST != 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sv[ns * 4 + r] = rbf(rbf(rbf(acc[r]) + rh) + rw[ns * 4 + r]);
             } else {
@@ -780,7 +820,30 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                 }
             }
         }
-        rh = rh_next;
+    };
+    issue(0);
+    if constexpr (HOIST == 2) {
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            float cur[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cur[r] = g == 0 ? gh[0][r] : g == 1 ? gh[1][r] : g == 2 ? gh[2][r] : gh[3][r];
+#pragma unroll 1
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int src = fr + 16 * (3 - a4);            // the lane group that holds row index 15 - j, j = 4*a4 + b
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) tile(16 * g + 4 * a4 + b4, __shfl(cur[3 - b4], src, 64));
+            }
+        }
+    } else if constexpr (HOIST == 1) {
+        float rh = bf2f(rh_row[0]);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const float rh_next = bf2f(rh_row[min(kt + 1, p.KH - 1)]);
+            tile(kt, rh);
+            rh = rh_next;
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) tile(kt, 0.f);
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -1104,12 +1167,12 @@ int launch_long(const AttnArgs& a, hipStream_t st) {
     return ull_check_launch();
 }
 
-template <int HDP, int FL, bool HOIST>
+template <int HDP, int FL, int HOIST>
 int launch_stream(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2;
     const int nt = (a.Sk + KT - 1) / KT;
     int lds = 4 * TILE;
-    if (!HOIST) lds += ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
+    if (HOIST == 0) lds += ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     if (lds > 160 * 1024) return ULL_ERR_LDS;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1177,8 +1240,9 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
         if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
         static const bool two_pass = getenv("ULL_ATTN_TWO_PASS") != nullptr;     // A/B switch: the exact two-pass kernel
         if (fl == FL_SAM_ENC && nt > 16 && !two_pass) {
-            if (a.rel_mode == 1 && a.KW == KT && (a.Sk % KT) == 0) return launch_stream<128, FL_SAM_ENC, true>(a, st);
-            return launch_stream<128, FL_SAM_ENC, false>(a, st);
+            if (a.rel_mode == 1 && a.KW == KT && (a.Sk % KT) == 0) return launch_stream<128, FL_SAM_ENC, 1>(a, st);
+            if (a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0) return launch_stream<128, FL_SAM_ENC, 2>(a, st);
+            return launch_stream<128, FL_SAM_ENC, 0>(a, st);
         }
         if (fl == FL_SAM_ENC && nt > 16) return launch_long<128, FL_SAM_ENC>(a, st);
     }

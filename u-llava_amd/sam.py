@@ -109,6 +109,9 @@ def build_sam_holder(cfg: SamConfig, device=None, dtype=BF16) -> nn.Module:
     return sam
 
 
+_GLOBAL_TABLES = bool(__import__("os").environ.get("ULL_SAM_GLOBAL_TABLES"))     # A/B switch: rel-pos tables from relpos_kernel
+
+
 class SamEngine:
     """Runs the SAM sub-models of a `build_sam_holder` tree on the HIP path (weights re-laid out once)."""
 
@@ -174,14 +177,14 @@ class SamEngine:
             strides = (S * 3 * C, hd, 3 * C)
             vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
             att = torch.empty(NB * S, C, device=x.device, dtype=BF16)
-            if glob:
-                # 64x64 grid: 2 x 127 table rows per wave would be rebuilt by every one of the 32 query blocks of a head
-                # (measured +1.9 ms per layer at B=8), so the per-query tables are computed once by their own kernel
+            if glob and (side != 64 or _GLOBAL_TABLES):
+                # other grid sizes: per-query bias tables from their own kernel, looked up by the attention kernel
                 rel_h, rel_w = ops.sam_relpos(qkv, strides, blk.attn.rel_pos_h, blk.attn.rel_pos_w, NB, nH, side, side, hd)
                 ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
                               scale_mode=0, q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
             else:
-                # 14x14 windows: the 2 x 27-row tables are built inside the attention kernel (Toeplitz product on the MFMA)
+                # the attention kernels build the rel-pos bias themselves from the raw rel_pos_h / rel_pos_w parameters (Toeplitz
+                # product on the MFMA): 14x14 windows in the register kernel, the 64x64 global grid in the streaming kernel
                 ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
                               scale_mode=0, q_scale=hd ** -0.5, rel_h=blk.attn.rel_pos_h, rel_w=blk.attn.rel_pos_w,
                               rel_pos_hw=(side, side))
