@@ -104,6 +104,39 @@ ULL_DEV void stage_rel_bias(const AttnArgs& p, bf16_t* dst, int bp, const uint4 
         bw_off = p.KH + p.KW - 1;
     } else {
         const int nth = 2 * p.KH - 1, ntw = 2 * p.KW - 1;
+        if (nth <= 32 && ntw <= 32) {
+            // window-sized tables (14 x 14 -> 27 rows each): all 4 x NKS table fragments are requested before the first MFMA, so the
+            // block pays one memory round trip here instead of four dependent ones (this prologue was ~1/4 of a window block's time)
+            uint4 a[2][2][NKS];
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const bf16_t* tab = which ? p.rel_w : p.rel_h;
+                    const int nt = which ? ntw : nth;
+                    const int t = min(st * 16 + fr, nt - 1);
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        const int d = ks * 32 + fg * 8;
+                        a[which][st][ks] = (d < hd) ? *(const uint4*)(tab + (long)t * hd + d) : make_uint4(0, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int nt = which ? ntw : nth, base = which ? nth : 0;
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks)
+                        if (ks * 32 < hd) acc = mfma16(a[which][st][ks], qf0[ks], acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int tt = st * 16 + fg * 4 + r;
+                        if (tt < nt) dst[fr * bp + base + tt] = f2bf(acc[r]);
+                    }
+                }
+        } else
 #pragma unroll 1
         for (int which = 0; which < 2; ++which) {
             const bf16_t* tab = which ? p.rel_w : p.rel_h;

@@ -78,7 +78,9 @@ def register_tiled(w: torch.Tensor) -> None:
     """Keep a tile-major copy of a weight for the prefill-shape GEMM (the row-major original still feeds the decode GEMV)."""
     import weakref
     if w.dim() == 2 and w.shape[1] % 64 == 0 and w.shape[0] >= 512 and w.shape[1] >= 128 and w.is_contiguous():
-        _TILED[w.data_ptr()] = (weakref.ref(w), tile_major(w))
+        ptr = w.data_ptr()
+        _TILED[ptr] = (weakref.ref(w, lambda _r, _p=ptr: _TILED.pop(_p, None) if (_TILED.get(_p) or (None,))[0] is _r else None),
+                       tile_major(w))                     # the copy is dropped when the weight tensor dies
 
 
 def _tiled_of(w: torch.Tensor):
