@@ -20,7 +20,7 @@ def _tiny_core_cfg():
 def _randomize(m, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
-        for p in m.parameters():
+        for p in m.state_dict().values():                   # parameters AND buffers (module buffers are allocated uninitialised)
             p.copy_(torch.randn(p.shape, generator=g).to(p.dtype))
 
 
