@@ -14,9 +14,15 @@ namespace {
 // Fast path (even patch size, W % 8 == 0): one thread per 8-pixel chunk of an image row -> one coalesced 16-byte load and four
 // 4-byte stores (a dword never straddles a patch because ps and the chunk start are even).
 __global__ __launch_bounds__(256) void im2col_vec_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int C, int Hh, int Ww, int ps,
-                                                         int gw, int Kp, long total_chunks) {
+                                                         int gw, int Kp, long total_chunks, int K, long pad_dwords) {
     const int cpr = Ww >> 3;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (long)gridDim.x * 256) {
+    const int padw = (Kp - K) >> 1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_chunks + pad_dwords; i += (long)gridDim.x * 256) {
+        if (i >= total_chunks) {                             // zero tail [K, Kp) of every row (same launch as the copy)
+            const long z = i - total_chunks;
+            *(uint32_t*)(out + (z / padw) * Kp + K + (z % padw) * 2) = 0u;
+            continue;
+        }
         const int x0 = (int)(i % cpr) * 8;
         long t = i / cpr;
         const int y = (int)(t % Hh);
@@ -35,12 +41,6 @@ __global__ __launch_bounds__(256) void im2col_vec_kernel(const bf16_t* __restric
             *(uint32_t*)(out + (rowbase + px) * Kp + kbase + kx) = d[j];
         }
     }
-}
-
-__global__ __launch_bounds__(256) void im2col_zero_pad_kernel(bf16_t* __restrict__ out, int K, int Kp, long rows) {
-    const int padw = Kp - K;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * padw; i += (long)gridDim.x * 256)
-        out[(i / padw) * Kp + K + (i % padw)] = 0;
 }
 
 __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int C, int Hh, int Ww, int ps,
@@ -174,11 +174,11 @@ extern "C" int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_
         const long chunks = n_img * C * H * (W >> 3);
         const long rows = n_img * gh * gw;
         const int K = (int)(C * ps * ps);
-        hipLaunchKernelGGL(im2col_vec_kernel, dim3((unsigned)((chunks + 255) / 256 < 16384 ? (chunks + 255) / 256 : 16384)), dim3(256), 0,
-                           (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, (int)C, (int)H, (int)W, (int)ps, gw, (int)Kp, chunks);
-        if (Kp > K)
-            hipLaunchKernelGGL(im2col_zero_pad_kernel, dim3((unsigned)((rows * (Kp - K) + 255) / 256 < 4096 ? (rows * (Kp - K) + 255) / 256 : 4096)),
-                               dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, K, (int)Kp, rows);
+        const long pad_dwords = rows * ((Kp - K) >> 1);                      // K and Kp are even: the zero tail is whole dwords
+        const long work = chunks + pad_dwords;
+        hipLaunchKernelGGL(im2col_vec_kernel, dim3((unsigned)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384)), dim3(256), 0,
+                           (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, (int)C, (int)H, (int)W, (int)ps, gw, (int)Kp, chunks, K,
+                           pad_dwords);
         return ull_check_launch();
     }
     hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, (int)C, (int)H, (int)W,
