@@ -174,6 +174,16 @@ int ull_u8_lut_chw(const void* src, int64_t H, int64_t W, int64_t C, int64_t top
  * [n, hw], target uint8 [n, hw]; counts int32 [n, 6] += {inter0, inter1, out0, out1, tgt0, tgt1}, ignore_index pixels dropped. */
 int ull_mask_iou_counts(const void* logits, const void* target, int64_t n_masks, int64_t hw, int ignore_index, void* counts, void* stream);
 
+/* ---- forward values of the training losses (models/loss.py; combined by models/ullava.py:283-312) ------------------------------ */
+
+/* Per mask and per 1/64th of its pixels: {sum BCE-with-logits, sum (sigmoid/scale)*t, sum sigmoid/scale, sum t/scale} ->
+ * part float [n_masks, 64, 4].  The host adds the 64 partials and forms sigmoid_ce_loss (loss.py:72-89) and dice_loss (:45-69). */
+int ull_mask_loss_sums_f32(const void* logits, const void* target, int64_t n_masks, int64_t hw, float scale, void* part, void* stream);
+
+/* bbox_l1_loss / bbox_giou_loss numerators (loss.py:92-110): out float[2] = {sum |pred - gt|, sum (1 - GIoU(pred_i, gt_i)) over
+ * predictions with x1 >= x0 and y1 >= y0}.  pred [n,4] bf16 or fp32, gt [n,4] fp32, xyxy. */
+int ull_box_losses_f32(const void* pred, int pred_is_bf16, const void* gt, int64_t n, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

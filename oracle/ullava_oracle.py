@@ -565,7 +565,88 @@ def ullava_forward(sd, cfg: dict, images_sam: Tensor, images: Tensor, input_ids:
     pred_masks, low_res = _decode_masks(sd, cfg, image_embeddings, seg_emb, resize_list, size_list)
     pred_boxes = [det_decoder(sd, e) for e in loc_emb]
     return dict(pred_masks=pred_masks, pred_boxes=pred_boxes, logits=out["logits"], low_res_masks=low_res,
-                image_embeddings=image_embeddings, last_hidden_state=last)
+                image_embeddings=image_embeddings, last_hidden_state=last, ce_loss=out["loss"])
+
+
+# ---- training losses (forward values), models/loss.py + models/ullava.py:268-333 ------------------------------------------------
+def dice_loss(inputs: Tensor, targets: Tensor, num_masks: float, scale=1000, eps=1e-6) -> Tensor:
+    """models/loss.py:45-69."""
+    inputs = inputs.sigmoid().flatten(1, 2)
+    targets = targets.flatten(1, 2)
+    numerator = 2 * (inputs / scale * targets).sum(-1)
+    denominator = (inputs / scale).sum(-1) + (targets / scale).sum(-1)
+    loss = 1 - (numerator + eps) / (denominator + eps)
+    return loss.sum() / (num_masks + 1e-8)
+
+
+def sigmoid_ce_loss(inputs: Tensor, targets: Tensor, num_masks: float) -> Tensor:
+    """models/loss.py:72-89."""
+    loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    return loss.flatten(1, 2).mean(1).sum() / (num_masks + 1e-8)
+
+
+def _box_area(b: Tensor) -> Tensor:
+    """torchvision.ops.boxes.box_area (third-party, absent here): (x1 - x0) * (y1 - y0)."""
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+
+def generalized_box_iou(b1: Tensor, b2: Tensor) -> Tensor:
+    """models/loss.py:6-42 (box_iou + generalized_box_iou), pairwise [N, M]."""
+    area1, area2 = _box_area(b1), _box_area(b2)
+    lt = torch.max(b1[:, None, :2], b2[:, :2])
+    rb = torch.min(b1[:, None, 2:], b2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    union = area1[:, None] + area2 - inter
+    iou = inter / union
+    lt = torch.min(b1[:, None, :2], b2[:, :2])
+    rb = torch.max(b1[:, None, 2:], b2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    area = wh[:, :, 0] * wh[:, :, 1]
+    return iou - (area - union) / area
+
+
+def bbox_l1_loss(src: Tensor, tgt: Tensor, num_boxes: float) -> Tensor:
+    """models/loss.py:92-95."""
+    return F.l1_loss(src, tgt, reduction="none").sum() / (num_boxes + 1e-8)
+
+
+def bbox_giou_loss(src: Tensor, tgt: Tensor, num_boxes: float) -> Tensor:
+    """models/loss.py:98-110: boxes whose x1 < x0 or y1 < y0 are dropped first."""
+    keep = (src[:, 2:] >= src[:, :2]).all(-1)
+    src, tgt = src[keep], tgt[keep]
+    return (1 - torch.diag(generalized_box_iou(src, tgt))).sum() / (num_boxes + 1e-8)
+
+
+def ullava_losses(pred_masks, pred_boxes, gt_masks, gt_boxes, ce_loss: Tensor, weights: dict) -> Dict[str, Tensor]:
+    """models/ullava.py:268-333: the dict UllavaForCausalLM.forward(inference=False) returns.
+    weights: ce_weight, bce_weight, dice_weight, l1_weight, iou_weight (UllavaConfig)."""
+    ce_loss = ce_loss * weights["ce_weight"]
+    loss = ce_loss
+    mask_bce, mask_dice, num_masks = 0, 0, 0
+    box_l1, box_giou, num_boxes = 0, 0, 0
+    for i in range(len(pred_masks)):
+        gm, pm = gt_masks[i], pred_masks[i]
+        assert gm.shape[0] == pm.shape[0]
+        mask_bce = mask_bce + sigmoid_ce_loss(pm, gm, num_masks=gm.shape[0]) * gm.shape[0]
+        mask_dice = mask_dice + dice_loss(pm, gm, num_masks=gm.shape[0]) * gm.shape[0]
+        num_masks += gm.shape[0]
+        gb, pb = gt_boxes[i], pred_boxes[i]
+        assert gb.shape[0] == pb.shape[0]
+        box_l1 = box_l1 + bbox_l1_loss(pb, gb, gb.shape[0])
+        box_giou = box_giou + bbox_giou_loss(pb, gb, gb.shape[0])
+        num_boxes += gb.shape[0]
+    mask_bce = weights["bce_weight"] * mask_bce / (num_masks + 1e-8)
+    mask_dice = weights["dice_weight"] * mask_dice / (num_masks + 1e-8)
+    mask_loss = mask_bce + mask_dice
+    box_l1 = weights["l1_weight"] * box_l1 / (num_boxes + 1e-8)
+    box_giou = weights["iou_weight"] * box_giou / (num_boxes + 1e-8)
+    bbox_loss = box_l1 + box_giou
+    # the reference accumulates IN PLACE into the tensor that `ce_loss` also names (ullava.py:271-272,323-324), so the returned
+    # "ce_loss" is the total loss, not the weighted next-token loss: reproduced, not corrected
+    loss += mask_loss
+    loss += bbox_loss
+    return dict(loss=loss, ce_loss=ce_loss, mask_bce_loss=mask_bce, mask_dice_loss=mask_dice, mask_loss=mask_loss, bbox_loss=bbox_loss)
 
 
 def ullava_evaluate(sd, cfg: dict, images_sam: Tensor, images: Tensor, input_ids: Tensor, raw_size_list,

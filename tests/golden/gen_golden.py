@@ -38,7 +38,7 @@ def _na(*a, **k):
     raise NotImplementedError
 
 
-_boxes.box_area = _na
+_boxes.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])   # torchvision.ops.boxes.box_area, used by models/loss.py
 _boxes.batched_nms = _na
 _ops.box_iou = _na
 _ops.boxes = _boxes
@@ -280,8 +280,8 @@ SAM_TINY = dict(embed_dim=64, depth=2, num_heads=2, global_attn_indexes=[1], win
                 out_chans=256)
 
 
-def gen_full(name, dtype, seed):
-    print(f"[{name}]")
+def _full_setup(dtype, seed):
+    """tiny UllavaForCausalLM (shrunk SAM encoder) + a 2-sample batch: sample 0 has two [SEG] + one [LOC], sample 1 one [SEG] + two [LOC]."""
     from models.segment_anything.build_sam import _build_sam
     ref_ullava.build_sam_vit_h = lambda checkpoint=None: _build_sam(
         encoder_embed_dim=SAM_TINY["embed_dim"], encoder_depth=SAM_TINY["depth"], encoder_num_heads=SAM_TINY["num_heads"],
@@ -310,10 +310,16 @@ def gen_full(name, dtype, seed):
     images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(dtype)
     size_list = [(480, 640), (333, 500)]
     resize_list = [(768, 1024), (682, 1024)]
+    ocfg = dict(llm=cd, sam=SAM_TINY, seg_token_idx=SEG, loc_token_idx=LOC)
+    return m, cfg, shapes, sd, ocfg, ids, mask, images, images_sam, size_list, resize_list
+
+
+def gen_full(name, dtype, seed):
+    print(f"[{name}]")
+    m, cfg, shapes, sd, ocfg, ids, mask, images, images_sam, size_list, resize_list = _full_setup(dtype, seed)
     with torch.no_grad():
         r = m(images_sam=images_sam, images=images, input_ids=ids, labels=None, attention_mask=mask,
               mask_list=[None, None], size_list=size_list, resize_list=resize_list, bbox_list=[None, None], inference=True)
-    ocfg = dict(llm=cd, sam=SAM_TINY, seg_token_idx=SEG, loc_token_idx=LOC)
     o = O.ullava_forward(sd, ocfg, images_sam, images, ids, mask, size_list, resize_list)
     eq(o["logits"], r["logits"], "full logits")
     for i in range(2):
@@ -328,6 +334,35 @@ def gen_full(name, dtype, seed):
                     pred_mask_sums=[t.double().sum().item() for t in r["pred_masks"]],
                     pred_mask_shapes=[tuple(t.shape) for t in r["pred_masks"]],
                     image_embeddings_sample=o["image_embeddings"][:, ::16, ::4, ::4].contiguous(),
+                    dict_keys=sorted(r.keys())))
+
+
+def gen_losses(name, dtype, seed):
+    """G10: UllavaForCausalLM.forward(inference=False) -> the training-loss dict (models/ullava.py:268-333, models/loss.py)."""
+    print(f"[{name}]")
+    m, cfg, shapes, sd, ocfg, ids, mask, images, images_sam, size_list, resize_list = _full_setup(dtype, seed)
+    g = torch.Generator().manual_seed(seed + 23)
+    n_seg, n_loc = [2, 1], [1, 2]
+    gt_masks = [(torch.rand(n_seg[i], *size_list[i], generator=g) > 0.7).float() for i in range(2)]
+    xy = [torch.rand(n_loc[i], 2, generator=g) * 0.5 for i in range(2)]
+    gt_boxes = [torch.cat([xy[i], xy[i] + 0.1 + torch.rand(n_loc[i], 2, generator=g) * 0.4], dim=1) for i in range(2)]
+    labels = ids.clone()
+    labels[:, :7] = -100                                   # image span + BOS are not supervised
+    labels[mask == 0] = -100
+    with torch.no_grad():
+        r = m(images_sam=images_sam, images=images, input_ids=ids, labels=labels, attention_mask=mask, mask_list=gt_masks,
+              size_list=size_list, resize_list=resize_list, bbox_list=gt_boxes, inference=False)
+    o = O.ullava_forward(sd, ocfg, images_sam, images, ids, mask, size_list, resize_list, labels=labels)
+    w = dict(ce_weight=cfg.ce_weight, bce_weight=cfg.bce_weight, dice_weight=cfg.dice_weight, l1_weight=cfg.l1_weight, iou_weight=cfg.iou_weight)
+    ol = O.ullava_losses(o["pred_masks"], o["pred_boxes"], gt_masks, gt_boxes, o["ce_loss"], w)
+    assert sorted(r.keys()) == sorted(ol.keys()), (sorted(r.keys()), sorted(ol.keys()))
+    for k in r:
+        print("   ", k, float(ol[k]), float(r[k]))
+    for k in r:
+        eq(ol[k], r[k], f"loss[{k}]")
+    save(name, dict(cfg=ocfg, weights=w, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=ids, attention_mask=mask, labels=labels,
+                    images=images, images_sam_seed=seed + 19, gt_seed=seed + 23, size_list=size_list, resize_list=resize_list,
+                    gt_boxes=gt_boxes, gt_mask_sums=[t.sum().item() for t in gt_masks], losses={k: v.float() for k, v in r.items()},
                     dict_keys=sorted(r.keys())))
 
 
@@ -350,4 +385,7 @@ if __name__ == "__main__":
     if want("full"):
         gen_full("g8_full_tiny_fp32.pt", torch.float32, 8)
         gen_full("g8_full_tiny_bf16.pt", torch.bfloat16, 8)
+    if want("losses"):
+        gen_losses("g10_train_losses_fp32.pt", torch.float32, 8)
+        gen_losses("g10_train_losses_bf16.pt", torch.bfloat16, 8)
     print("all fixtures bit-exact between reference and oracle")

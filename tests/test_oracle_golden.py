@@ -95,3 +95,23 @@ def test_full_forward_tiny_sam(name):
     # [SEG]/[LOC] shift: sample 0 has 2 [SEG] + 1 [LOC]; sample 1 has 1 [SEG] + 2 [LOC]
     assert [m.shape[0] for m in o["pred_masks"]] == [2, 1]
     assert [b.shape[0] for b in o["pred_boxes"]] == [1, 2]
+
+
+@pytest.mark.parametrize("name", ["g10_train_losses_fp32.pt", "g10_train_losses_bf16.pt"])
+def test_training_losses_g10(name):
+    """oracle forward + models/loss.py restatement == the reference's forward(inference=False) dict (incl. the in-place alias
+    that makes "ce_loss" equal the total)."""
+    fx = load_fixture(name)
+    dt = getattr(torch, fx["dtype"].split(".")[-1])
+    sd = fixture_state_dict(fx, dt)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(dt)
+    g2 = torch.Generator().manual_seed(fx["gt_seed"])
+    gt_masks = [(torch.rand(n, *fx["size_list"][i], generator=g2) > 0.7).float() for i, n in enumerate([2, 1])]
+    o = O.ullava_forward(sd, fx["cfg"], images_sam, fx["images"], fx["input_ids"], fx["attention_mask"], fx["size_list"], fx["resize_list"],
+                         labels=fx["labels"])
+    ol = O.ullava_losses(o["pred_masks"], o["pred_boxes"], gt_masks, fx["gt_boxes"], o["ce_loss"], fx["weights"])
+    assert sorted(ol.keys()) == fx["dict_keys"]
+    for k, ref in fx["losses"].items():
+        assert torch.equal(ol[k].float(), ref), k

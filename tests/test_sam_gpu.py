@@ -225,3 +225,48 @@ def test_evaluate_greedy_tiny():
     assert torch.equal(seq.cpu(), ref_seq), (seq.cpu().tolist(), ref_seq.tolist())
     n_seg = int((ref_seq[0, 1:] == fx["cfg"]["seg_token_idx"]).sum())
     assert masks[0].shape[0] == n_seg and tuple(masks[0].shape[1:]) == tuple(fx["size_list"][0])
+
+
+def test_loss_kernels_against_reference_formulas():
+    """mask_loss_sums / box_losses vs the reference's torch formulas (models/loss.py restated in the oracle), fp32."""
+    ops = pkg("ops")
+    g = torch.Generator().manual_seed(71)
+    for n, (h, w) in ((3, (48, 64)), (1, (333, 500)), (5, (7, 9))):
+        x = torch.randn(n, h, w, generator=g) * 4
+        t = (torch.rand(n, h, w, generator=g) > 0.6).float()
+        s = ops.mask_loss_sums(x.to(DEV), t.to(DEV)).cpu()
+        bce = (s[:, 0] / (h * w)).sum() / (n + 1e-8)
+        dice = (1 - (2 * s[:, 1] + 1e-6) / (s[:, 2] + s[:, 3] + 1e-6)).sum() / (n + 1e-8)
+        torch.testing.assert_close(bce, O.sigmoid_ce_loss(x, t, n), rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(dice, O.dice_loss(x, t, n), rtol=2e-5, atol=1e-6)
+    for dt in (torch.float32, BF):
+        xy = torch.rand(6, 2, generator=g) * 0.5
+        gt = torch.cat([xy, xy + 0.1 + torch.rand(6, 2, generator=g) * 0.4], 1)
+        pred = (gt + torch.randn(6, 4, generator=g) * 0.1).to(dt)
+        pred[2] = torch.tensor([0.6, 0.2, 0.5, 0.9]).to(dt)                      # x1 < x0: dropped from the GIoU term only
+        out = ops.box_losses(pred.to(DEV), gt.to(DEV)).cpu()
+        torch.testing.assert_close(out[0] / (6 + 1e-8), O.bbox_l1_loss(pred.float(), gt, 6), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out[1] / (6 + 1e-8), O.bbox_giou_loss(pred.float(), gt, 6), rtol=1e-5, atol=1e-6)
+
+
+def test_training_loss_dict_fixture_g10():
+    """UllavaForCausalLM.forward(inference=False): same keys as the reference, every loss within the bf16 path's tolerance of the
+    reference's bf16 run (G10), "ce_loss" aliased to the total like the reference's in-place accumulation."""
+    fx = load_fixture("g10_train_losses_bf16.pt")
+    model, sd = _full_model(fx)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(BF)
+    g2 = torch.Generator().manual_seed(fx["gt_seed"])
+    n_seg = [2, 1]
+    gt_masks = [(torch.rand(n_seg[i], *fx["size_list"][i], generator=g2) > 0.7).float() for i in range(2)]
+    assert [t.sum().item() for t in gt_masks] == fx["gt_mask_sums"]               # the seeded targets are the generator's
+    out = model(images_sam=images_sam.to(DEV), images=fx["images"].to(DEV), input_ids=fx["input_ids"].to(DEV), labels=fx["labels"].to(DEV),
+                attention_mask=fx["attention_mask"].to(DEV), mask_list=[m.to(DEV) for m in gt_masks], size_list=fx["size_list"],
+                resize_list=fx["resize_list"], bbox_list=[b.to(DEV) for b in fx["gt_boxes"]], inference=False)
+    assert sorted(out.keys()) == fx["dict_keys"]
+    assert out["ce_loss"] is out["loss"]
+    for k, ref in fx["losses"].items():
+        got = float(out[k])
+        print(f"{k}: {got:.5f} (reference bf16 run {float(ref):.5f})")
+        assert abs(got - float(ref)) <= 0.02 * abs(float(ref)) + 1e-3, k

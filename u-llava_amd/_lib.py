@@ -42,6 +42,8 @@ SIGNATURES = {
     "ull_resample_u8": [_ptr, _i64, _i64, _i64, _i32, _i64, _ptr, _ptr, _i64, _ptr, _ptr],
     "ull_u8_lut_chw": [_ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_mask_iou_counts": [_ptr, _ptr, _i64, _i64, _i32, _ptr, _ptr],
+    "ull_mask_loss_sums_f32": [_ptr, _ptr, _i64, _i64, _f32, _ptr, _ptr],
+    "ull_box_losses_f32": [_ptr, _i32, _ptr, _i64, _ptr, _ptr],
 }
 
 ERRORS = {-1: "ULL_ERR_ARG (null pointer / bad size)", -2: "ULL_ERR_SHAPE (alignment or shape constraint)",

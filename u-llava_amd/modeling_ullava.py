@@ -116,9 +116,8 @@ class UllavaForCausalLM(nn.Module):
     def forward(self, images_sam: torch.FloatTensor, images: torch.FloatTensor, input_ids: torch.LongTensor, labels: torch.LongTensor,
                 attention_mask: torch.LongTensor, mask_list: List[torch.FloatTensor], size_list: List[torch.Tensor],
                 resize_list: List[tuple], bbox_list: List[torch.FloatTensor], inference: bool = False):
-        """reference ullava.py:152-333."""
-        if not inference:
-            raise NotImplementedError("training losses are outside the forward hot path (SURVEY 8(a) row a16); pass inference=True")
+        """reference ullava.py:152-333.  inference=False returns the training-loss dict (forward values only: there is no backward
+        on this path yet)."""
         B = input_ids.shape[0]
         image_embeddings = self._visual_embs_tm(images_sam)
         pad = torch.zeros((B, 1), dtype=torch.bool, device=input_ids.device)
@@ -131,7 +130,56 @@ class UllavaForCausalLM(nn.Module):
         pred_loc_embeddings = self._select(last, loc_token_mask, self.det_projector)
         pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, size_list)
         pred_boxes = [self._run_mlp(self.det_decoder, e) if e.shape[0] else e.new_empty(0, 4) for e in pred_loc_embeddings]
-        return {"pred_masks": pred_masks, "pred_boxes": pred_boxes, "gt_masks": mask_list, "gt_boxes": bbox_list, "logits": output.logits}
+        if inference:
+            return {"pred_masks": pred_masks, "pred_boxes": pred_boxes, "gt_masks": mask_list, "gt_boxes": bbox_list, "logits": output.logits}
+        return self._losses(output.loss, pred_masks, pred_boxes, mask_list, bbox_list)
+
+    def _losses(self, ce, pred_masks, pred_boxes, gt_masks, gt_boxes):
+        """reference ullava.py:268-333 + models/loss.py.  The per-pixel / per-box sums are HIP kernels; the handful of scalar
+        combinations below run as 0-dim device ops.  Like the reference, the total is accumulated IN PLACE into the tensor that
+        `ce_loss` names, so the returned "ce_loss" equals "loss" (reproduced, not corrected)."""
+        cfg = self.config
+        if ce is None:
+            raise ValueError("forward(inference=False) needs `labels` (the reference multiplies output.loss by ce_weight)")
+        ce_loss = ce * cfg.ce_weight
+        loss = ce_loss
+        dev = ce_loss.device
+        mask_bce = torch.zeros((), device=dev)
+        mask_dice = torch.zeros((), device=dev)
+        box_l1 = torch.zeros((), device=dev)
+        box_giou = torch.zeros((), device=dev)
+        num_masks = num_boxes = 0
+        for i in range(len(pred_masks)):
+            gm, pm = gt_masks[i], pred_masks[i]
+            if gm.shape[0] != pm.shape[0]:
+                raise AssertionError(f"gt_mask.shape: {tuple(gm.shape)}, pred_mask.shape: {tuple(pm.shape)}")
+            n = gm.shape[0]
+            if n:
+                sums = ops.mask_loss_sums(pm.contiguous(), gm.to(device=dev, dtype=torch.float32).contiguous())     # [n, 4]
+                hw = pm[0].numel()
+                mask_bce = mask_bce + (sums[:, 0] / hw).sum() / (n + 1e-8) * n
+                dice = 1 - (2 * sums[:, 1] + 1e-6) / (sums[:, 2] + sums[:, 3] + 1e-6)
+                mask_dice = mask_dice + dice.sum() / (n + 1e-8) * n
+            num_masks += n
+            gb, pb = gt_boxes[i], pred_boxes[i]
+            if gb.shape[0] != pb.shape[0]:
+                raise AssertionError(f"gt_box.shape: {tuple(gb.shape)}, pred_box.shape: {tuple(pb.shape)}")
+            nb = gb.shape[0]
+            if nb:
+                bl = ops.box_losses(pb, gb.to(device=dev, dtype=torch.float32))
+                box_l1 = box_l1 + bl[0] / (nb + 1e-8)
+                box_giou = box_giou + bl[1] / (nb + 1e-8)
+            num_boxes += nb
+        mask_bce_loss = cfg.bce_weight * mask_bce / (num_masks + 1e-8)
+        mask_dice_loss = cfg.dice_weight * mask_dice / (num_masks + 1e-8)
+        mask_loss = mask_bce_loss + mask_dice_loss
+        box_l1_loss = cfg.l1_weight * box_l1 / (num_boxes + 1e-8)
+        box_giou_loss = cfg.iou_weight * box_giou / (num_boxes + 1e-8)
+        bbox_loss = box_l1_loss + box_giou_loss
+        loss += mask_loss
+        loss += bbox_loss
+        return {"loss": loss, "ce_loss": ce_loss, "mask_bce_loss": mask_bce_loss, "mask_dice_loss": mask_dice_loss, "mask_loss": mask_loss,
+                "bbox_loss": bbox_loss}
 
     __call__ = forward
 

@@ -370,3 +370,24 @@ def shifted_cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.T
     acc = torch.zeros(2, device=logits.device, dtype=torch.float32)
     _lib.call("ull_shifted_cross_entropy_bf16", _p(logits), logits.stride(1), _p(labels.contiguous()), B, S, V, _p(acc), _stream())
     return (acc[0] / acc[1]).to(BF16)
+
+
+def mask_loss_sums(logits: torch.Tensor, target: torch.Tensor, scale: float = 1000.0) -> torch.Tensor:
+    """fp32 [n, 4] = per mask {sum BCE-with-logits, sum (sigmoid/scale)*t, sum sigmoid/scale, sum t/scale} (models/loss.py)."""
+    _chk(logits, "mask logits", torch.float32); _chk(target, "mask target", torch.float32)
+    if logits.shape != target.shape or not logits.is_contiguous() or not target.is_contiguous():
+        raise RuntimeError("u-llava_amd.mask_loss_sums: logits / target must be contiguous and of the same shape")
+    n = logits.shape[0]
+    part = torch.empty(n, 64, 4, device=logits.device, dtype=torch.float32)
+    _lib.call("ull_mask_loss_sums_f32", _p(logits), _p(target), n, logits[0].numel(), float(scale), _p(part), _stream())
+    return part.sum(1)
+
+
+def box_losses(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """fp32 [2] = {sum |pred - gt|, sum (1 - GIoU) over well-formed predictions}; pred [n,4] bf16/fp32, gt [n,4] fp32."""
+    if pred.dtype not in (BF16, torch.float32):
+        raise RuntimeError("u-llava_amd.box_losses: pred must be bf16 or fp32")
+    _chk(pred, "pred boxes", pred.dtype); _chk(gt, "gt boxes", torch.float32)
+    out = torch.empty(2, device=pred.device, dtype=torch.float32)
+    _lib.call("ull_box_losses_f32", _p(pred.contiguous()), int(pred.dtype == BF16), _p(gt.contiguous()), pred.shape[0], _p(out), _stream())
+    return out
