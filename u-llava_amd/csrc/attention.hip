@@ -1145,23 +1145,34 @@ __global__ __launch_bounds__(256) void rope_append_kernel(bf16_t* __restrict__ q
 // have after the swapped QK^T MFMA -- so P*V needs no cross-lane movement.  64(s) x 64(d) tiles through LDS.
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, long v_bs, long v_ss, bf16_t* __restrict__ vt, int S,
                                                           int H, int hd, int pitch) {
-    __shared__ bf16_t t[64][66];
+    __shared__ __attribute__((aligned(16))) bf16_t t[64][68];            // [d][key]; 136-byte rows keep the 8-byte reads aligned
     const int b = blockIdx.z / H, h = blockIdx.z % H;
     const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
     const bf16_t* vp = v + (long)b * v_bs + (long)h * hd;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int s = i >> 6, d = i & 63;
-        bf16_t val = 0;
-        if (s0 + s < S && d0 + d < hd) val = vp[(long)(s0 + s) * v_ss + d0 + d];
-        t[s][d] = val;
+    // 16-byte loads along d (coalesced: 8 lanes cover one token's 64 dims), scattered 2-byte LDS writes
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        const int sl = c >> 3, dc = (c & 7) * 8;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (s0 + sl < S && d0 + dc < hd) val = *(const uint4*)(vp + (long)(s0 + sl) * v_ss + d0 + dc);
+        const uint32_t w[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[dc + 2 * j][sl] = (bf16_t)(w[j] & 0xffff);
+            t[dc + 2 * j + 1][sl] = (bf16_t)(w[j] >> 16);
+        }
     }
     __syncthreads();
     bf16_t* op = vt + ((long)b * H + h) * hd * pitch;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int d = i >> 6, s = i & 63;
-        // output slot s (within this 64-wide tile) takes the key at the permuted position
-        const int w = s & 31, key = (s & 32) + 16 * ((w >> 2) & 1) + 4 * (w >> 3) + (w & 3);
-        if (d0 + d < hd && s0 + s < pitch) op[(long)(d0 + d) * pitch + s0 + s] = t[key][d];
+    // output chunk oc = 8 consecutive slots 8g .. 8g+7 of a 32-key block = keys {4g..4g+3} and {16+4g..16+4g+3}: two 8-byte LDS reads
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        const int d = c >> 3, oc = c & 7;
+        const int kb = (oc >> 2) * 32 + (oc & 3) * 4;
+        const uint2 lo = *(const uint2*)&t[d][kb], hi = *(const uint2*)&t[d][kb + 16];
+        if (d0 + d < hd) *(uint4*)(op + (long)(d0 + d) * pitch + s0 + oc * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
 }
 
