@@ -154,6 +154,14 @@ int ull_mask_matmul_bf16(const void* hyper, const void* up, void* masks, int64_t
 int ull_bilinear_f32(const void* in, int in_is_bf16, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w, void* out,
                      int64_t n, int64_t out_h, int64_t out_w, void* stream);
 
+/* Fused ViT patch embedding: Conv2d(C, N, kernel = stride = ps) as one GEMM whose A tiles are LDS-DMA'd straight from the pixels
+ * (no im2col buffer).  hf CLIPVisionEmbeddings.patch_embedding (models/ullava_core.py:131-159) and SAM PatchEmbed
+ * (segment_anything/modeling/image_encoder.py:395-427).  img contiguous [n_img, C, H, W] bf16; Wp [N, Kp] packed as
+ * Wp[n][(c*ps + ky)*16 + kx] = w[n][c][ky][kx] (kx < ps), zero elsewhere, Kp = ceil(C*ps*16 / 64)*64; out [n_img*(H/ps)*(W/ps), N];
+ * zeros = 16 zero bytes; bias [N] or null.  Nothing behind the image buffer is read. */
+int ull_patchify_bf16(const void* img, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, const void* Wp, int64_t Kp,
+                      const void* bias, void* out, int64_t ldc, int64_t N, const void* zeros, void* stream);
+
 /* ---- image pre/post-processing either side of the path (byte / integer work, bit-exact against the host libraries) ------------- */
 
 /* One separable pass of Pillow's 8-bit resampler (libImaging/Resample.c ImagingResampleHorizontal_8bpc / Vertical_8bpc) over a

@@ -347,3 +347,21 @@ def test_gemm_tile_major_weight_is_bit_identical():
     small = ops.linear(xd[:8], wd, bd)                  # decode / small-M shapes keep using the row-major tensor
     assert_close_bf16(small, F.linear(x[:8].float(), w.float(), b.float()).to(BF), what="small-M with a registered tiled copy")
     ops._TILED.clear()
+
+
+@pytest.mark.parametrize("n,C,HW,ps,Dv,bias", [(3, 3, 56, 14, 64, False), (2, 3, 64, 16, 160, True), (1, 3, 336, 14, 1024, False), (5, 3, 28, 14, 200, True)])
+def test_fused_patchify_matches_conv2d(n, C, HW, ps, Dv, bias):
+    """ull_patchify_bf16 (A tiles DMA'd from the pixels, kx padded to 16) == F.conv2d, and nothing behind the image is read."""
+    ops = pkg("ops")
+    img = _rand(n, C, HW, HW, seed=80 + HW)
+    w = _rand(Dv, C, ps, ps, seed=81, scale=(C * ps * ps) ** -0.5)
+    b = _rand(Dv, seed=82) if bias else None
+    ref = F.conv2d(img.float(), w.float(), None if b is None else b.float(), stride=ps).flatten(2).transpose(1, 2).reshape(-1, Dv)
+    wp = ops.pack_patch_weight(w.to(DEV))
+    got = ops.patchify(img.to(DEV), wp, ps, None if b is None else b.to(DEV))
+    assert_close_bf16(got, ref.to(BF), ulps=1.0, what="fused patchify vs conv2d")
+    # poison the memory right behind a private copy of the image: the kernel must not consume it
+    buf = torch.full((img.numel() + 64,), float("nan"), dtype=BF, device=DEV)
+    buf[:img.numel()] = img.reshape(-1).to(DEV)
+    got2 = ops.patchify(buf[:img.numel()].view(n, C, HW, HW), wp, ps, None if b is None else b.to(DEV))
+    assert torch.equal(got, got2) and not bool(torch.isnan(got2.float()).any())

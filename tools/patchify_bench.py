@@ -12,8 +12,13 @@ for size, alg_mb, gf in ((224, 27.6, 9.87), (336, 60.6, 22.2)):
     img = torch.randn(B, 3, size, size, device=dev).to(torch.bfloat16)
     w = torch.zeros(D, Kp, device=dev, dtype=torch.bfloat16)
     w[:, :K] = torch.randn(D, K, device=dev).to(torch.bfloat16) * K ** -0.5
+    wp = ops.pack_patch_weight(w[:, :K].reshape(D, 3, ps, ps).contiguous())
+    fused = os.environ.get("UNFUSED") is None
     def run():
-        return ops.linear(ops.im2col(img, ps, Kp), w)
+        return ops.patchify(img, wp, ps) if fused else ops.linear(ops.im2col(img, ps, Kp), w)
+    ref = ops.linear(ops.im2col(img, ps, Kp), w).float()
+    got = ops.patchify(img, wp, ps).float()
+    print(f"   fused vs im2col+GEMM: max |d| = {float((got - ref).abs().max()):.4g} (max |ref| = {float(ref.abs().max()):.3g}), equal bits: {bool(torch.equal(got, ref))}")
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ull_im2col3x3_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
     "ull_mask_matmul_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
     "ull_bilinear_f32": [_ptr, _i32, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr],
+    "ull_patchify_bf16": [_ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr],
     "ull_resample_u8": [_ptr, _i64, _i64, _i64, _i32, _i64, _ptr, _ptr, _i64, _ptr, _ptr],
     "ull_u8_lut_chw": [_ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_mask_iou_counts": [_ptr, _ptr, _i64, _i64, _i32, _ptr, _ptr],

@@ -312,6 +312,120 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
 }
 
 
+// ---- fused ViT patchify: Conv2d(C, N, kernel = stride = ps) as a GEMM whose A tile is DMA'd straight from the image ----------
+// reference: transformers CLIPVisionEmbeddings.patch_embedding (models/ullava_core.py:131-159 encode_image) and SAM PatchEmbed
+// (segment_anything/modeling/image_encoder.py:395-427).  The old path materialised im2col(image) in HBM first (+24 us and +47 MB
+// at B=32, 336^2).  Here K is ordered (c, ky, kx) with kx padded to 16: K' = C*ps*16 (+ zero segments up to a multiple of 64).
+// One (c, ky) segment of a patch is 16 bf16 = two 16-byte LDS-DMA chunks read from img[b][c][py*ps+ky][px*ps .. +16): for ps = 14
+// the last two elements are the next patch's first pixels -- the packed weight W' is zero there, so they do not matter.
+// LDS-DMA takes 2-byte-aligned source addresses (tools/probes/dma_align.hip), so no thread ever touches the pixels.
+// The one chunk that would read past the end of the buffer (last image, last channel, last pixel row, last patch: 12 real bytes +
+// 4 beyond) goes through registers instead of the DMA.
+struct PatchArgs {
+    const bf16_t* img; const bf16_t* zeros; const bf16_t* img_end;
+    int C, H, W, ps, gw, gh;          // image geometry; gw x gh patches per image
+    int nseg;                         // C * ps real (c, ky) segments; segments >= nseg read zeros
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void patchify_gemm_kernel(GemmArgs p, PatchArgs q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int nwg = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + k;
+    }
+    const int per_group = GROUP_M * p.nbn;
+    const int gid = bid / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(p.nbm - first_m, GROUP_M);
+    const int bm = first_m + (bid % per_group) % gsz;
+    const int bn = (bid % per_group) / gsz;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;                 // logical 16-byte chunk of the 128-byte K-tile row this lane fetches
+    const int seg = schunk >> 1, half = schunk & 1;       // (c, ky) segment within the K-tile, first / second 8 kx
+    const bf16_t* xbase[4];                               // pixel (b, c = 0, y = py*ps, x = px*ps) of the patch this lane stages
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + srow;
+        const int m = min(m0 + r, p.M - 1);
+        const int px = m % q.gw, py = (m / q.gw) % q.gh, b = m / (q.gw * q.gh);
+        xbase[i] = q.img + (((long)b * q.C * q.H + (long)py * q.ps) * q.W + px * q.ps) + half * 8;
+        wsrc[i] = p.W + (long)min(n0 + r, p.N - 1) * p.ldw + schunk * 8;
+    }
+    const int stage_off = wave * 4 * 8 * (BK * 2);
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    auto stage = [&](int buf, int kt) {
+        const uint32_t bx = lds_base + buf * BUF_BYTES + stage_off;
+        const uint32_t bw = bx + TILE_BYTES;
+        const int idx = kt * 4 + seg;                     // global (c, ky) segment index of this lane's chunk
+        const int c = idx / q.ps, ky = idx - c * q.ps;
+        const long xoff = ((long)c * q.H + ky) * q.W;
+        const bool real = idx < q.nseg;
+        const long ko = (long)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* sp = real ? xbase[i] + xoff : q.zeros;
+            if (real && sp + 8 > q.img_end) {
+                // the one chunk that would read past the buffer (last image / channel / pixel row / patch, second half): its 6 real
+                // pixels come through registers, the 2 pad slots are zero (W' is zero there anyway, but garbage could be NaN bits)
+                const uint32_t* s32 = (const uint32_t*)sp;
+                const uint4 v = make_uint4(s32[0], s32[1], s32[2], 0u);
+                *(uint4*)(smem + buf * BUF_BYTES + stage_off + i * 1024 + lane * 16) = v;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                glds16(sp, bx + i * 1024);
+            }
+            glds16(wsrc[i] + ko, bw + i * 1024);
+        }
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    int swz[2];
+    swz[0] = ((0 + fgrp) ^ (lane & 7)) << 4;
+    swz[1] = ((4 + fgrp) ^ (lane & 7)) << 4;
+    const int xrow_off = (wm * 64 + frow) * (BK * 2);
+    const int wrow_off = TILE_BYTES + (wn * 64 + frow) * (BK * 2);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* base = smem + cur * BUF_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 wf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *(const uint4*)(base + wrow_off + i * 16 * (BK * 2) + swz[kk]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[j] = *(const uint4*)(base + xrow_off + j * 16 * (BK * 2) + swz[kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    staged_epilogue<false, 4>(p, acc, smem + wave * (64 * 144), lane, m0 + wm * 64, n0 + wn * 64);
+}
+
 // =============================================================================================================
 // Large-shape kernel: 256x256 block tile, BK = 64, two 64-KiB LDS slots (128 KiB), 512 threads = 8 waves (2 x 4),
 // 128(m) x 64(n) per wave = 32 accumulators (128 VGPR).  Measured motivation (profiles/r01_gemm_notes.md): ablating the
@@ -629,5 +743,34 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
+    return ull_check_launch();
+}
+
+// out[(b, py, px), n] = bias[n] + sum_{c,ky,kx} img[b, c, py*ps+ky, px*ps+kx] * w[n, c, ky, kx]   (bf16 in / out, fp32 accumulate)
+// Wp: packed weight [N, Kp], Kp = ceil(C*ps*16 / 64) * 64, Wp[n][(c*ps+ky)*16 + kx] = w[n][c][ky][kx] for kx < ps, zero elsewhere.
+// img: contiguous [n_img, C, H, W] bf16 (nothing behind it is read); zeros: >= 16 zero bytes.  ps even, <= 16, H % ps == W % ps == 0,
+// W >= 16.
+extern "C" int ull_patchify_bf16(const void* img, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, const void* Wp, int64_t Kp,
+                                 const void* bias, void* out, int64_t ldc, int64_t N, const void* zeros, void* stream) {
+    if (!img || !Wp || !out || !zeros || n_img <= 0 || C <= 0 || H <= 0 || W < 16 || N <= 0) return ULL_ERR_ARG;
+    if (ps <= 0 || ps > 16 || (ps & 1) || H % ps || W % ps || Kp % BK || Kp < C * ps * 16 || (ldc & 7)) return ULL_ERR_SHAPE;
+    GemmArgs a;
+    PatchArgs q;
+    q.img = (const bf16_t*)img; q.zeros = (const bf16_t*)zeros;
+    q.img_end = (const bf16_t*)img + n_img * C * H * W;
+    q.C = (int)C; q.H = (int)H; q.W = (int)W; q.ps = (int)ps; q.gw = (int)(W / ps); q.gh = (int)(H / ps); q.nseg = (int)(C * ps);
+    const int64_t M = n_img * q.gw * q.gh;
+    if (M > (1 << 30)) return ULL_ERR_SHAPE;
+    a.X = nullptr; a.W = (const bf16_t*)Wp; a.C = out; a.bias = (const bf16_t*)bias; a.R = nullptr;
+    a.ldx = 0; a.ldw = Kp; a.ldc = ldc; a.ldr = 0;
+    a.M = (int)M; a.N = (int)N; a.K = (int)Kp; a.flags = bias ? EPI_BIAS : 0;
+    a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
+    a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)patchify_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(patchify_gemm_kernel<0>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a, q);
     return ull_check_launch();
 }

@@ -244,6 +244,8 @@ class UllavaCoreForCausalLM(nn.Module):
         wp = torch.zeros(w.shape[0], Kp, device=w.device, dtype=w.dtype)
         wp[:, :K] = w.reshape(w.shape[0], K)
         pk["patch_w"], pk["patch_Kp"] = wp, Kp
+        # fused patchify (A tiles DMA'd from the pixels): (c, ky) segments of 16, see ops.pack_patch_weight
+        pk["patch_wp"] = ops.pack_patch_weight(w) if (vc.patch_size <= 16 and vc.patch_size % 2 == 0 and vc.image_size >= 16) else None
         # tile-major copies for the prefill-shape GEMM (+13.5 GB for LLaMA-7B; sized for 288 GB of HBM).  The row-major
         # tensors stay: they feed the decode GEMV, which streams whole rows.
         for d in pk["llama"]:
@@ -287,8 +289,10 @@ class UllavaCoreForCausalLM(nn.Module):
         P = (vc.image_size // vc.patch_size) ** 2
         Dv, H = vc.hidden_size, vc.num_attention_heads
         hd = Dv // H
-        cols = ops.im2col(x, vc.patch_size, pk["patch_Kp"])
-        patches = ops.linear(cols, pk["patch_w"])
+        if pk["patch_wp"] is not None:
+            patches = ops.patchify(x, pk["patch_wp"], vc.patch_size)
+        else:
+            patches = ops.linear(ops.im2col(x, vc.patch_size, pk["patch_Kp"]), pk["patch_w"])
         S = P + 1
         h = ops.clip_embed_ln(patches, ve.embeddings.class_embedding, ve.embeddings.position_embedding.weight,
                               ve.pre_layrnorm.weight, ve.pre_layrnorm.bias, n, S, vc.layer_norm_eps).view(n * S, Dv)

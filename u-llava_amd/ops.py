@@ -244,6 +244,31 @@ def im2col(img: torch.Tensor, ps: int, Kp: int) -> torch.Tensor:
     return out
 
 
+def pack_patch_weight(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d weight [N, C, ps, ps] -> the [N, Kp] layout of ull_patchify_bf16: (c, ky) segments of 16 with kx >= ps zero, zero
+    segments up to a multiple of 64."""
+    N, C, ps, ps2 = w.shape
+    if ps != ps2 or ps > 16 or ps % 2:
+        raise NotImplementedError("patch sizes on the path: 14 (CLIP) and 16 (SAM)")
+    K = C * ps * 16
+    Kp = (K + 63) // 64 * 64
+    out = torch.zeros(N, Kp, device=w.device, dtype=w.dtype)
+    out[:, :K].view(N, C * ps, 16)[:, :, :ps] = w.reshape(N, C * ps, ps)
+    return out
+
+
+def patchify(img: torch.Tensor, wp: torch.Tensor, ps: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Conv2d(kernel = stride = ps) patch embedding straight from the pixels: img [n, C, H, W] bf16 -> [n*(H/ps)*(W/ps), N]."""
+    _chk(img, "img"); _chk(wp, "packed patch weight")
+    if not img.is_contiguous():
+        raise RuntimeError("u-llava_amd.patchify: image batch must be contiguous NCHW")
+    n, C, H, W = img.shape
+    N, Kp = wp.shape
+    out = torch.empty(n * (H // ps) * (W // ps), N, device=img.device, dtype=BF16)
+    _lib.call("ull_patchify_bf16", _p(img), n, C, H, W, ps, _p(wp), Kp, _p(bias), _p(out), N, N, _zeros(img.device).data_ptr(), _stream())
+    return out
+
+
 def mm_spans(ids: torch.Tensor, img_start: int, img_end: int, vid_start: int, vid_end: int) -> torch.Tensor:
     _chk(ids, "input_ids", torch.int64)
     B, S = ids.shape

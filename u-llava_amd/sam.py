@@ -131,6 +131,7 @@ class SamEngine:
         pk = {}
         w = enc.patch_embed.proj.weight
         pk["patch_w"] = w.reshape(C, -1).contiguous()                        # K = 3*16*16 = 768 (multiple of 64)
+        pk["patch_wp"] = ops.pack_patch_weight(w) if (cfg.patch_size <= 16 and cfg.patch_size % 2 == 0) else None
         pk["pos"] = enc.pos_embed.reshape(-1, C).contiguous()
         pk["neck0"] = enc.neck[0].weight.reshape(D, C).contiguous()
         pk["neck2"] = enc.neck[2].weight.permute(0, 2, 3, 1).reshape(D, 9 * D).contiguous()   # (ky,kx,ci) columns
@@ -159,8 +160,11 @@ class SamEngine:
         C, nH = cfg.embed_dim, cfg.num_heads
         hd = C // nH
         g = cfg.img_size // cfg.patch_size
-        cols = ops.im2col(pixel_values.to(BF16).contiguous(), cfg.patch_size, pk["patch_w"].shape[1])
-        x = ops.linear(cols, pk["patch_w"], enc.patch_embed.proj.bias)           # [B*g*g, C]
+        if pk["patch_wp"] is not None:                                       # fused: A tiles DMA'd straight from the pixels
+            x = ops.patchify(pixel_values.to(BF16).contiguous(), pk["patch_wp"], cfg.patch_size, enc.patch_embed.proj.bias)
+        else:
+            cols = ops.im2col(pixel_values.to(BF16).contiguous(), cfg.patch_size, pk["patch_w"].shape[1])
+            x = ops.linear(cols, pk["patch_w"], enc.patch_embed.proj.bias)       # [B*g*g, C]
         x = ops.add_rows(x, pk["pos"])
         for i, blk in enumerate(enc.blocks):
             glob = i in cfg.global_attn_indexes
