@@ -63,3 +63,23 @@ if __name__ == "__main__":
     plain("llama S=643 B=32", 32, 32, 643, 128, True)
     plain("clip S=577 B=32", 32, 16, 577, 64, False)
     plain("clip S=257 B=32", 32, 16, 257, 64, False)
+
+
+def decode(B, H, Sk, hd, masked):
+    D = H * hd
+    smax = ((Sk + 63) // 64) * 64 + 64
+    q = (torch.randn(B, 3 * D, device=dev) * 0.5).to(BF)
+    kc = (torch.randn(B, H, smax, hd, device=dev) * 0.5).to(BF)
+    vtc = (torch.randn(B, H, hd, smax, device=dev) * 0.5).to(BF)
+    att = torch.empty(B, D, device=dev, dtype=BF)
+    km = torch.ones(B, Sk, device=dev, dtype=torch.int32) if masked else None
+    f = lambda: ops.attention(q, kc, vtc, att, B, H, 1, Sk, hd, (3 * D, hd, 3 * D), (H * smax * hd, smax * hd, hd), (D, hd, D), km,
+                              causal=True, scale_mode=1, scale=hd ** -0.5)
+    us = timeit(f, 50)
+    print(f"decode B={B} Sk={Sk} mask={masked}: {us:7.1f} us  (K+V {2 * B * H * Sk * hd * 2 / 1e6:.1f} MB -> {2 * B * H * Sk * hd * 2 / us / 1e6:.2f} TB/s)")
+
+
+if __name__ == "__main__" and os.environ.get("DECODE"):
+    for masked in (True, False):
+        decode(1, 32, 676, 128, masked)
+        decode(4, 32, 676, 128, masked)
