@@ -18,6 +18,9 @@ from .modeling_core import BF16, Linear, UllavaCoreForCausalLM, _Holder
 from .sam import SamEngine, build_sam_holder
 
 
+_SINGLE_STREAM = bool(__import__("os").environ.get("ULL_SINGLE_STREAM"))     # A/B switch: SAM encoder on the main stream
+
+
 def _mlp_seq(dims, device, dtype, dropout_tail=False):
     """nn.Sequential(Linear, ReLU, Linear, ...) with the reference's child indices (ReLU / Dropout hold no parameters)."""
     mods = []
@@ -69,6 +72,14 @@ class UllavaForCausalLM(nn.Module):
         self._sam.invalidate()
         return self.visual_model.load_state_dict(sd, strict=False)
 
+    def _side_stream(self):
+        if _SINGLE_STREAM:
+            return torch.cuda.current_stream()
+        st = getattr(self, "_side", None)
+        if st is None:
+            st = self._side = torch.cuda.Stream()
+        return st
+
     # -- SAM image encoder -------------------------------------------------------------------------------------------
     def _visual_embs_tm(self, pixel_values: torch.Tensor) -> torch.Tensor:
         return self._sam.encode(pixel_values)                       # [B, g*g, 256] token-major
@@ -119,13 +130,21 @@ class UllavaForCausalLM(nn.Module):
         """reference ullava.py:152-333.  inference=False returns the training-loss dict (forward values only: there is no backward
         on this path yet)."""
         B = input_ids.shape[0]
-        image_embeddings = self._visual_embs_tm(images_sam)
+        # the SAM image encoder does not depend on the LLM: it runs on a second HIP stream and fills the gaps (tile-quantisation
+        # tails, small kernels, launch latency) of the CLIP + LLaMA stream; joined before the mask decoder
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            image_embeddings = self._visual_embs_tm(images_sam)
         pad = torch.zeros((B, 1), dtype=torch.bool, device=input_ids.device)
         seg_token_mask = torch.cat([input_ids[:, 1:] == self.config.seg_token_idx, pad], dim=1)    # row t selected iff ids[t+1]==[SEG]
         loc_token_mask = torch.cat([input_ids[:, 1:] == self.config.loc_token_idx, pad], dim=1)
         output = self.llm.forward(images=images, attention_mask=attention_mask, input_ids=input_ids, labels=labels,
                                   output_hidden_states=True)
         last = output.hidden_states[-1]
+        main.wait_stream(side)
+        image_embeddings.record_stream(main)
         pred_embeddings = self._select(last, seg_token_mask, self.seg_projector)
         pred_loc_embeddings = self._select(last, loc_token_mask, self.det_projector)
         pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, size_list)
@@ -187,6 +206,11 @@ class UllavaForCausalLM(nn.Module):
     def evaluate(self, images_sam, images, input_ids, raw_size_list, resize_list, max_new_tokens=32, temperature=0.2, top_p=None,
                  num_beams=1, no_repeat_ngram_size=None, stopping_criteria=None):
         """reference ullava.py:335-434 -> (output_ids, pred_masks, pred_boxes)."""
+        main = torch.cuda.current_stream()                          # SAM image encoder on the second stream, under the generation loop
+        side = self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            image_embeddings = self._visual_embs_tm(images_sam)
         outputs = self.llm.generate(input_ids=input_ids, images=images, max_new_tokens=max_new_tokens, num_beams=num_beams, top_p=top_p,
                                     do_sample=True if temperature > 0 else False, temperature=temperature, output_hidden_states=True,
                                     return_dict_in_generate=True, no_repeat_ngram_size=no_repeat_ngram_size,
@@ -198,7 +222,8 @@ class UllavaForCausalLM(nn.Module):
         L1 = last.shape[1]
         pred_embeddings = self._select(last, seg_token_mask[:, :L1], self.seg_projector)
         pred_loc_embeddings = self._select(last, loc_token_mask[:, :L1], self.det_projector)
-        image_embeddings = self._visual_embs_tm(images_sam)
+        main.wait_stream(side)
+        image_embeddings.record_stream(main)
         pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, raw_size_list)
         pred_boxes = [self._run_mlp(self.det_decoder, e) if e.shape[0] else e.new_empty(0, 4) for e in pred_loc_embeddings]
         return output_ids, pred_masks, pred_boxes
