@@ -112,16 +112,24 @@ class UllavaForCausalLM(nn.Module):
         return out
 
     def _decode(self, image_embeddings_tm, pred_embeddings, resize_list, size_list):
-        pred_masks = []
-        for i, e in enumerate(pred_embeddings):
-            n = e.shape[0]
+        """prompt encoder + mask decoder + postprocess.  The reference decodes one image at a time (ullava.py:228-252); every op of
+        the decoder is independent per prompt, so all prompts of the batch go through one chain of launches here (the per-image
+        chains were host-launch-bound: ~70 small kernels each) and only the two resizes of postprocess_masks stay per image."""
+        counts = [int(e.shape[0]) for e in pred_embeddings]
+        dev = image_embeddings_tm.device
+        low_all = None
+        if sum(counts):
+            idx = torch.tensor([i for i, c in enumerate(counts) for _ in range(c)], dtype=torch.int64, device=dev)
+            masks, _iou = self._sam.decode(image_embeddings_tm, torch.cat([e for e in pred_embeddings if e.shape[0]], dim=0).contiguous(), idx)
+            low_all = masks[:, 0].contiguous()                      # multimask_output=False -> mask 0
+        pred_masks, o = [], 0
+        for i, c in enumerate(counts):
             H, W = int(size_list[i][0]), int(size_list[i][1])
-            if n == 0:
-                pred_masks.append(torch.empty(0, H, W, device=e.device, dtype=torch.float32))
+            if c == 0:
+                pred_masks.append(torch.empty(0, H, W, device=dev, dtype=torch.float32))
                 continue
-            masks, _iou = self._sam.decode(image_embeddings_tm[i], e.contiguous())
-            low = masks[:, 0].contiguous()                          # multimask_output=False -> mask 0
-            pred_masks.append(self._sam.postprocess(low, resize_list[i], (H, W)))
+            pred_masks.append(self._sam.postprocess(low_all[o:o + c], resize_list[i], (H, W)))
+            o += c
         return pred_masks
 
     def forward(self, images_sam: torch.FloatTensor, images: torch.FloatTensor, input_ids: torch.LongTensor, labels: torch.LongTensor,

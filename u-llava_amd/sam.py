@@ -245,19 +245,26 @@ class SamEngine:
             x = ops.linear(x, l.weight, l.bias, act="relu" if i < nl - 1 else None)
         return x
 
-    def decode(self, image_embedding_tm: torch.Tensor, text_embeds: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def decode(self, image_embedding_tm: torch.Tensor, text_embeds: torch.Tensor,
+               image_index: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """image_embedding_tm [g*g, D] (one image), text_embeds [n, D] -> (masks [n, nm, 4g, 4g] bf16, iou [n, nm]).
-        Covers PromptEncoder.forward with text_embeds only (sparse = text, dense = no_mask_embed) + MaskDecoder.predict_masks."""
+        Covers PromptEncoder.forward with text_embeds only (sparse = text, dense = no_mask_embed) + MaskDecoder.predict_masks.
+        With image_index (int64 [n]) image_embedding_tm is [B, g*g, D] and prompt j decodes against image image_index[j]: the
+        prompts of a whole batch go through ONE chain of launches (every op below is independent per prompt, so the results are
+        the per-image results)."""
         md, tr, pk = self.sam.mask_decoder, self.sam.mask_decoder.transformer, self.pk()
         n, D = text_embeds.shape
-        P = image_embedding_tm.shape[0]
+        P = image_embedding_tm.shape[-2]
         g = int(math.isqrt(P))
         nm = md.mask_tokens.weight.shape[0]
         out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], dim=0)                  # [1+nm, D]
         tokens = torch.cat([out_tok.unsqueeze(0).expand(n, -1, -1), text_embeds.unsqueeze(1)], dim=1).contiguous()   # [n, T, D]
         T = tokens.shape[1]
-        src = ops.add_rows(image_embedding_tm, self.sam.prompt_encoder.no_mask_embed.weight)     # + dense (no-mask) embedding
-        keys = src.unsqueeze(0).expand(n, -1, -1).contiguous().view(n * P, D)                    # repeat_interleave over prompts
+        src = ops.add_rows(image_embedding_tm.reshape(-1, D), self.sam.prompt_encoder.no_mask_embed.weight)   # + dense (no-mask) embedding
+        if image_index is None:
+            keys = src.unsqueeze(0).expand(n, -1, -1).contiguous().view(n * P, D)                # repeat_interleave over prompts
+        else:
+            keys = ops.gather_rows(src.view(-1, P * D), image_index).view(n * P, D)              # each prompt's own image
         pos = self.dense_pe()
         qpe = tokens.view(n * T, D)
         queries = qpe
