@@ -42,6 +42,10 @@ extern "C" {
 int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                   int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
+/* Host policy knob: K below which ull_gemm_bf16 does not split a partial last round of tiles along K (default 2048).  The model
+ * raises it while a second stream shares the GPU (RES forward), where the idle CUs of a partial round are not idle. */
+int ull_gemm_set_streamk_min_k(int64_t min_k);
+
 /* The same Linear for decode steps (M <= 4 rows, K % 8 == 0): a pure weight stream, one wave per output feature, no LDS/MFMA.
  * Same flags, layouts and rounding points as ull_gemm_bf16.  Reached from generate() after the prefill
  * (models/ullava_core.py:357-395 keeps only the last token once a KV cache exists). */

@@ -670,6 +670,16 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
 
 }  // namespace
 
+// Smallest K for which a partial last round of tiles is split along K (stream-K tail).  The split pays for itself when the GEMM has
+// the GPU to itself (C4: +5 %); when a second stream is filling the idle CUs anyway (RES forward: SAM encoder || LLaMA) it does not.
+static long g_streamk_min_k = getenv("ULL_GEMM_SK_MINK") ? atol(getenv("ULL_GEMM_SK_MINK")) : 2048;
+
+extern "C" int ull_gemm_set_streamk_min_k(int64_t min_k) {
+    if (min_k < 0) return ULL_ERR_ARG;
+    g_streamk_min_k = (long)min_k;
+    return ULL_OK;
+}
+
 extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
                              const void* bias, const void* R, int64_t ldr,
                              int64_t M, int64_t N, int64_t K, int flags, void* stream) {
@@ -700,6 +710,7 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         static int n_cu = 0;
         static float* ws = nullptr;
         static const bool no_sk = getenv("ULL_GEMM_NO_STREAMK") != nullptr;
+        const long sk_min_k = g_streamk_min_k;
         constexpr int MAX_SLABS = 256;
         if (!n_cu) {
             hipDeviceProp_t prop;
@@ -711,7 +722,9 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
         const int T = a.nbm * a.nbn;
         const int rem = T % n_cu;
         int sk = 1;
-        if (!no_sk && ws && T > n_cu && rem > 0 && rem <= n_cu / 2) {
+        // (short K: the fp32 slab round trip + finalize launch cost more than the partial round they replace -- SAM's K = 1280
+        //  GEMMs measured 1.5 % slower end-to-end with the tail split)
+        if (!no_sk && ws && T > n_cu && rem > 0 && rem <= n_cu / 2 && K >= sk_min_k) {
             sk = n_cu / rem;
             if (sk > 16) sk = 16;
             const int nk = (int)(K / big::BK);

@@ -143,6 +143,9 @@ class UllavaForCausalLM(nn.Module):
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
+        overlap = side is not main
+        if overlap:
+            ops.set_gemm_streamk_min_k(8192)                        # no K-split of partial tile rounds while the streams overlap
         with torch.cuda.stream(side):
             image_embeddings = self._visual_embs_tm(images_sam)
         pad = torch.zeros((B, 1), dtype=torch.bool, device=input_ids.device)
@@ -153,6 +156,8 @@ class UllavaForCausalLM(nn.Module):
         last = output.hidden_states[-1]
         main.wait_stream(side)
         image_embeddings.record_stream(main)
+        if overlap:
+            ops.set_gemm_streamk_min_k(2048)
         pred_embeddings = self._select(last, seg_token_mask, self.seg_projector)
         pred_loc_embeddings = self._select(last, loc_token_mask, self.det_projector)
         pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, size_list)

@@ -154,6 +154,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def set_gemm_streamk_min_k(min_k: int) -> None:
+    """see ull_gemm_set_streamk_min_k: 2048 by default; raised while two streams share the GPU."""
+    _lib.call("ull_gemm_set_streamk_min_k", int(min_k))
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(x, "x"); _chk(w, "w")
     rows, ldx = _rows(x)
