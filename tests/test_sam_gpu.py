@@ -296,3 +296,28 @@ def test_full_width_sam_encoder_against_oracle():
     e_ref, e_hip = rel_err(ref, truth), rel_err(got, truth)
     print(f"SAM encoder (full width, 2 blocks): HIP err vs fp32 {e_hip:.4f}, oracle bf16 {e_ref:.4f}, HIP vs oracle {rel_err(got, ref):.4f}")
     assert e_hip <= max(3.0 * e_ref, 2.0 ** -6)
+
+
+def test_forward_with_no_seg_or_loc_tokens():
+    """edge case: a batch in which one sample (or every sample) has no [SEG] / [LOC] token -> empty [0, H, W] / [0, 4] predictions,
+    like the reference's empty gathers (ullava.py:214-256), and no kernel launch on empty inputs."""
+    fx = load_fixture("g8_full_tiny_bf16.pt")
+    model, sd = _full_model(fx)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(BF).to(DEV)
+    seg, loc = fx["cfg"]["seg_token_idx"], fx["cfg"]["loc_token_idx"]
+    for wipe in ("second", "both"):
+        ids = fx["input_ids"].clone()
+        rows = [1] if wipe == "second" else [0, 1]
+        for r in rows:
+            ids[r][(ids[r] == seg) | (ids[r] == loc)] = 17
+        out = model(images_sam=images_sam, images=fx["images"].to(DEV), input_ids=ids.to(DEV), labels=None,
+                    attention_mask=fx["attention_mask"].to(DEV), mask_list=[None, None], size_list=fx["size_list"],
+                    resize_list=fx["resize_list"], bbox_list=[None, None], inference=True)
+        for r in rows:
+            assert tuple(out["pred_masks"][r].shape) == (0, *fx["size_list"][r]) and out["pred_masks"][r].dtype == torch.float32
+            assert tuple(out["pred_boxes"][r].shape) == (0, 4)
+        if wipe == "second":
+            assert out["pred_masks"][0].shape[0] == 2 and out["pred_boxes"][0].shape[0] == 1
+            assert bool(torch.isfinite(out["pred_masks"][0]).all())
