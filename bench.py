@@ -264,7 +264,7 @@ def main():
         flops_img = llama_flops(S, cfg.vocab_size) + clip_flops(P) + 2 * (P + 1) * 1024 * 4096
         if res:
             flops_img += 5.96e12 + 3 * 3.61e9          # SAM ViT-H encoder + 3 mask-decoder passes
-        line = {"metric": "images/sec (ViT-L/14 + projector + LLaMA-7B" + (" + SAM ViT-H RES" if res else "") + " multimodal forward)", "value": round(value, 3), "unit": "images/sec",
+        line = {"metric": "images/sec (ViT-L-%d + LLaMA-7B%s forward)" % (image_size, " + SAM RES" if res else ""), "value": round(value, 3), "unit": "images/sec",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": desc, "per_gpu_batch": batch, "global_batch": batch * world, "seq_len": S, "image": image_size,
