@@ -81,6 +81,24 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
     hi = pack2bf(o[2], o[3]);
 }
 
+// The same for a quad whose four keys are all attendable for every lane of the wave (no padding, below the causal diagonal, no
+// bias): only the scale + the two roundings remain.  ~85 % of the LLaMA / CLIP score quads take this path.
+template <int FL>
+ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& lo, uint32_t& hi) {
+    const bool do_mul = FL == FL_RUNTIME ? p.scale_mode == 1 : (FL == FL_LLAMA || FL == FL_CLIP);
+    const bool do_div = FL == FL_RUNTIME ? p.scale_mode == 2 : (FL == FL_SAM_DEC);
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sv = rbf(acc[r]);
+        if (do_mul) sv = rbf(sv * p.scale);
+        if (do_div) sv = rbf(sv / p.scale);
+        o[r] = sv;
+    }
+    lo = pack2bf(o[0], o[1]);
+    hi = pack2bf(o[2], o[3]);
+}
+
 
 // Stage this wave's 16 relative-position bias rows in LDS (`dst`, row pitch `bp` elements, see bias_pitch()).
 //   rel_mode 1: copy the precomputed per-query tables (stored reversed so both modes index the same way);
@@ -344,7 +362,14 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                         }
                     }
                     const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
-                    score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
+                    const int j0 = kt * KT + ns * 16 + fg * 4;
+                    bool fast = false;
+                    if constexpr (FL == FL_LLAMA || FL == FL_CLIP) {
+                        const bool dirty = mk != 0x01010101u || (FL == FL_LLAMA && j0 + 3 > qi + koff);
+                        fast = __builtin_amdgcn_ballot_w64(dirty) == 0;     // wave-uniform
+                    }
+                    if (fast) score_quad_clean<FL>(p, acc, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
+                    else score_quad<FL>(p, acc, j0, mk, qi, koff, brow, bh_off, bw_off, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
                     if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
                 }
             }
