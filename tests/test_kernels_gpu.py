@@ -365,3 +365,37 @@ def test_fused_patchify_matches_conv2d(n, C, HW, ps, Dv, bias):
     buf[:img.numel()] = img.reshape(-1).to(DEV)
     got2 = ops.patchify(buf[:img.numel()].view(n, C, HW, HW), wp, ps, None if b is None else b.to(DEV))
     assert torch.equal(got, got2) and not bool(torch.isnan(got2.float()).any())
+
+
+def test_attention_fuzz_shapes():
+    """random self-attention shapes across the dispatch table (register kernels with 5 / 11 / 16 tiles, two-pass long kernel, few-query
+    kernel; head dims 16..128 incl. 80; causal / padded / plain) against the eager bf16 reference."""
+    ops = pkg("ops")
+    rs = __import__("random").Random(77)
+    for trial in range(24):
+        hd = rs.choice([16, 32, 64, 80, 128])
+        H, B = rs.choice([1, 2, 3]), rs.choice([1, 2])
+        S = rs.choice([1, 2, 15, 16, 17, 63, 64, 65, 130, 257, 320, 321, 640, 704, 705, 1023, 1025, 1100])
+        causal = rs.random() < 0.5
+        masked = rs.random() < 0.4 and S > 4
+        D = H * hd
+        qkv = _rand(B * S, 3 * D, seed=1000 + trial)
+        km = None
+        if masked:
+            km = torch.ones(B, S, dtype=torch.int32)
+            km[-1, S - max(1, S // 4):] = 0
+        q = qkv[:, :D].view(B, S, H, hd).transpose(1, 2)
+        k = qkv[:, D:2 * D].view(B, S, H, hd).transpose(1, 2)
+        v = qkv[:, 2 * D:].view(B, S, H, hd).transpose(1, 2)
+        ref = _attn_ref(q, k, v, hd ** -0.5, causal, km).transpose(1, 2).reshape(B * S, D)
+        g = qkv.to(DEV)
+        vt = ops.transpose_v(g[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
+        out = torch.empty(B * S, D, device=DEV, dtype=BF)
+        ops.attention(g, g[:, D:], vt, out, B, H, S, S, hd, (S * 3 * D, hd, 3 * D), (S * 3 * D, hd, 3 * D), (S * D, hd, D),
+                      None if km is None else km.to(DEV), causal=causal, scale_mode=1, scale=hd ** -0.5)
+        got = out.cpu()
+        if masked:
+            valid = km.bool().reshape(-1)
+            got, ref = got[valid], ref[valid]
+        assert_close_bf16(got, ref, ulps=2.0, what=f"attention fuzz B={B} H={H} S={S} hd={hd} causal={causal} masked={masked}", outlier_frac=2e-3,
+                          outlier_floor=float(v.float().abs().max()))
