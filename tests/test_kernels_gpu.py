@@ -399,3 +399,43 @@ def test_attention_fuzz_shapes():
             got, ref = got[valid], ref[valid]
         assert_close_bf16(got, ref, ulps=2.0, what=f"attention fuzz B={B} H={H} S={S} hd={hd} causal={causal} masked={masked}", outlier_frac=2e-3,
                           outlier_floor=float(v.float().abs().max()))
+
+
+def test_linear_fuzz_shapes_and_epilogues():
+    """random Linear shapes over all three kernels (GEMV M <= 4, 128x128, 256x256 + stream-K tail) with ragged M / N, K that needs the
+    zero-pad path, odd output pitch, and every epilogue combination (bias, quick_gelu / gelu / relu, residual, fp32 out, SwiGLU)."""
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    rs = __import__("random").Random(99)
+    acts = {None: lambda t: t, "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t), "gelu": F.gelu, "relu": F.relu}
+    for trial in range(28):
+        M = rs.choice([1, 3, 4, 5, 63, 129, 300, 1024, 1100, 1500, 2049])
+        N = rs.choice([8, 40, 97, 128, 520, 777, 1031, 2048])
+        K = rs.choice([64, 72, 192, 320, 1088])
+        swiglu = rs.random() < 0.2
+        if swiglu:
+            N = rs.choice([32, 96, 352, 1024])
+        x = _rand(M, K, seed=2000 + trial)
+        w = _rand(2 * N if swiglu else N, K, seed=2100 + trial, scale=K ** -0.5)
+        if swiglu:
+            wg, wu = w[:N], w[N:]
+            got = ops.linear(x.to(DEV), M_.interleave_gate_up(wg, wu).to(DEV), swiglu=True)
+            ref = F.silu(_mm_ref(x, wg)) * _mm_ref(x, wu)
+            assert_close_bf16(got, ref, what=f"fuzz swiglu M={M} N={N} K={K}")
+            continue
+        act = rs.choice([None, "quick_gelu", "gelu", "relu"])
+        use_b, use_r, f32 = rs.random() < 0.6, rs.random() < 0.4, rs.random() < 0.25
+        b = _rand(N, seed=2200 + trial) if use_b else None
+        r = _rand(M, N, seed=2300 + trial) if use_r else None
+        t = F.linear(x.float(), w.float(), None if b is None else b.float())
+        if act is not None or use_r or not f32:
+            t = t.to(BF)
+        t = acts[act](t)
+        if use_r:
+            t = r + t.to(BF)
+        got = ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), act=act, residual=None if r is None else r.to(DEV), out_f32=f32)
+        assert got.dtype == (torch.float32 if f32 else BF) and tuple(got.shape) == (M, N)
+        # a one-ulp flip inside the activation chain (fast exp vs libm) survives a cancelling residual add as an absolute error:
+        # allow 1e-4 of the elements to meet the 2-ulp bound at the tensor's scale instead of their own
+        want = t.float() if f32 else t.to(BF)
+        assert_close_bf16(got, want, ulps=2.0, what=f"fuzz M={M} N={N} K={K} act={act} bias={use_b} res={use_r} f32={f32}", outlier_frac=1e-4,
+                          outlier_floor=float(want.float().abs().max()))
