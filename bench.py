@@ -1,17 +1,25 @@
 #!/usr/bin/env python
-"""bench.py -- images/sec of the u-LLaVA multimodal forward (CLIP ViT-L/14-336 -> projector -> LLaMA-7B -> lm_head)
-on MI355X through the HIP path, with the roofline of the dominant kernel and a CPU-oracle baseline.
+"""bench.py -- images/sec of the u-LLaVA multimodal forward on MI355X through the HIP path, with the roofline of the dominant
+kernel and a CPU-oracle baseline.
 
-  python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]
 
-A "step" = one forward of the per-GPU batch (BASELINE.json config C4: 336x336 synthetic images, 64-token prompts,
-S = 643, per-GPU batch 32, weak scaling).  Inputs and random-init weights are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.
+N > 1: this script launches N ranks itself (re-exec under `torch.distributed.run`, one rank per GPU, RCCL over xGMI) unless it
+is already running inside such a launch (WORLD_SIZE set by the driver's own `python -m torch.distributed.run ... bench.py`).
+
+A "step" = one forward of the per-GPU batch.  Headline workload = BASELINE.json config C4 (336x336 synthetic images, 64-token
+prompts, S = 643, per-GPU batch 32, weak scaling); the same JSON line carries a `res` sub-record = config C3 (full RES forward:
++ SAM ViT-H encoder at 1024x1024, 3 [SEG]/[LOC] per image, MaskDecoder, postprocess; batch 8) timed with the same protocol, so
+both halves of BASELINE.json's metric ("ViT-L-336 + LLaMA-7B + SAM RES forward") are measured in the driver's run.
+Inputs and random-init weights are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -20,15 +28,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+METRIC = "images/sec/GPU (ViT-L-336 + LLaMA-7B + SAM RES forward) at 1/2/4/8 MI355X"      # BASELINE.json, verbatim
 MM = dict(IMG_START=32001, IMG_END=32002, IMG_PATCH=32003, VID_START=32004, VID_END=32005, VID_PATCH=32006)
 WORKLOADS = {
     # name: (image_size, prompt_tokens, per_gpu_batch, description)
     "c4": (336, 64, 32, "C4: ViT-L/14-336 + LLaMA-7B instruct forward, 336x336 image + 64-token prompt (S=643), batch 32/GPU"),
-    "c2": (224, 64, 16, "C2: ViT-L/14-224 + LLaMA-7B VQA forward, 224x224 image + 64-token prompt (S=323), batch 16"),
+    "c2": (224, 64, 16, "C2: ViT-L/14-224 + LLaMA-7B VQA forward, 224x224 image + 32..64-token prompts right-padded to S=323, batch 16"),
     # full RES path: + SAM ViT-H encoder on 1024x1024, 3 [SEG]+[LOC] rounds per sample, prompt-encoder + mask decoder + postprocess
     "res": (224, 120, 8, "C3: full RES forward (ViT-L/14-224 + LLaMA-7B + SAM ViT-H 1024x1024 + MaskDecoder, 3 [SEG]/[LOC] per image), batch 8"),
+    "c5": (224, 32, 8, "C5: video forward, 8-frame 224x224 clips (per-frame ViT-L, 8+256 pooled tokens) + 32-token prompt (S=299), 8 clips/GPU"),
 }
 PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+SEG, LOC = 32007, 32008
 
 
 def llama_flops(S, V, D=4096, I=11008, L=32):
@@ -53,9 +64,6 @@ def init_random_(model, seed):
             p.data.normal_(0.0, 0.02, generator=g)
 
 
-SEG, LOC = 32007, 32008
-
-
 def build_model(image_size, device, seed=0, with_sam=False):
     C = importlib.import_module("u-llava_amd.configuration")
     llm = dict(vision_config=dict(image_size=image_size, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
@@ -77,14 +85,36 @@ def build_model(image_size, device, seed=0, with_sam=False):
     return model, cfg
 
 
-def make_inputs(cfg, batch, prompt_tokens, device, seed):
+def make_inputs(cfg, batch, prompt_tokens, device, seed, ragged=False, video=False):
     g = torch.Generator(device="cuda").manual_seed(1000 + seed)
-    P = (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2
-    images = torch.randn(batch, 3, cfg.vision_config.image_size, cfg.vision_config.image_size, device=device, generator=g).to(torch.bfloat16)
+    isz = cfg.vision_config.image_size
+    P = (isz // cfg.vision_config.patch_size) ** 2
     txt = torch.randint(5, 32000, (batch, prompt_tokens), device=device, generator=g)
-    head = torch.tensor([1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * P + [MM["IMG_END"]], device=device).expand(batch, -1)
+    if video:
+        T = 8
+        vis = torch.randn(batch, 3, T, isz, isz, device=device, generator=g).to(torch.bfloat16)
+        head = torch.tensor([1, MM["VID_START"]] + [MM["VID_PATCH"]] * (T + P) + [MM["VID_END"]], device=device).expand(batch, -1)
+    else:
+        vis = torch.randn(batch, 3, isz, isz, device=device, generator=g).to(torch.bfloat16)
+        head = torch.tensor([1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * P + [MM["IMG_END"]], device=device).expand(batch, -1)
     ids = torch.cat([head, txt], dim=1).contiguous()
-    return images, ids, torch.ones_like(ids)
+    mask = torch.ones_like(ids)
+    if ragged:        # C2: prompts of 32..64 tokens, right-padded with the pad id (0) and masked, like the reference's collator
+        lens = torch.linspace(prompt_tokens // 2, prompt_tokens, batch).round().long().tolist()
+        for b, n in enumerate(lens):
+            ids[b, head.shape[1] + n:] = 0
+            mask[b, head.shape[1] + n:] = 0
+    return vis, ids, mask
+
+
+def gemm_sources_sha():
+    """sha256 (first 16 hex digits) of the GEMM kernel source: ties a committed PMC traffic record to the kernel it measured."""
+    h = hashlib.sha256()
+    for n in ("gemm.hip", "ull_common.h"):
+        p = os.path.join(ROOT, "u-llava_amd", "csrc", n)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def gemm_roofline(cfg, tokens, device, iters=5):
@@ -98,6 +128,7 @@ def gemm_roofline(cfg, tokens, device, iters=5):
     for name, N, K, sw in shapes:
         x = (torch.randn(tokens, K, device=device, generator=g)).to(torch.bfloat16)
         w = (torch.randn(N, K, device=device, generator=g) * 0.02).to(torch.bfloat16)
+        ops.register_tiled(w)
         out = torch.empty(tokens, N // 2 if sw else N, device=device, dtype=torch.bfloat16)
         for _ in range(2):
             ops.linear(x, w, swiglu=sw, out=out)
@@ -113,22 +144,34 @@ def gemm_roofline(cfg, tokens, device, iters=5):
         tot_t += ms
         tot_f += fl
     achieved = tot_f / tot_t / 1e9
+    # HBM-side traffic comes from separate rocprofv3 --pmc passes (they cannot run inside this process); the committed record is
+    # only quoted while it describes THIS kernel source (sha of csrc/gemm.hip), otherwise traffic is null
     traffic, detail = None, None
-    try:   # PMC passes are recorded separately (rocprofv3 --pmc cannot run inside this process): profiles/r01_gemm_traffic.json
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")))
-        traffic = tj["traffic_bytes_per_launch"]
-        detail = {"kernel": tj["kernel"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"], "note": tj["note"],
-                  "mfma_pipe_busy_fraction": tj.get("mfma", {}).get("mfma_pipe_busy_fraction_of_simd_cycles")}
-    except Exception:
-        pass
+    sha = gemm_sources_sha()
+    for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if fn.endswith("gemm_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            except Exception:
+                continue
+            if tj.get("kernel_source_sha") == sha:
+                traffic = tj["traffic_bytes_per_launch"]
+                detail = {"record": "profiles/" + fn, "kernel": tj["kernel"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
+                          "l2_hit_rate": tj.get("l2", {}).get("hit_rate"), "note": tj["note"],
+                          "mfma_pipe_busy_fraction": tj.get("mfma", {}).get("mfma_pipe_busy_fraction_of_simd_cycles")}
+            else:
+                detail = {"record": "profiles/" + fn, "stale": True,
+                          "note": f"PMC record was taken on kernel source {tj.get('kernel_source_sha')}, current source is {sha}: not quoted"}
+            break
     return dict(bound="mfma", kernel="big::gemm256_kernel (LLaMA-7B layer: qkv, o, gate/up+SwiGLU, down; 2*M*N*K flop per launch)",
                 achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                 traffic=traffic, traffic_detail=detail, per_launch=per)
 
 
 def cpu_baseline(image_size, prompt_tokens):
-    """Oracle (CPU restatement of the reference path, torch bf16) on a bounded sample: ONE image at the benchmark shape
-    through 2 of 23 CLIP layers and 2 of 32 LLaMA layers + lm_head, extrapolated linearly in layer count."""
+    """Oracle (CPU restatement of the reference path, torch bf16) on a bounded sample: ONE image at the benchmark shape through
+    1 of 23 CLIP layers and 1 of 32 LLaMA layers + lm_head, each timed as 1 warm-up + 3 runs (median), extrapolated linearly in
+    layer count (core count stated)."""
     from oracle import ullava_oracle as O
     W = importlib.import_module("u-llava_amd.weights")
     # pick the thread count on a probe matmul: 256-thread hosts are often slower with every hardware thread in use
@@ -174,12 +217,14 @@ def cpu_baseline(image_size, prompt_tokens):
     img = torch.randn(1, 3, image_size, image_size).to(torch.bfloat16)
     emb = torch.randn(1, S, D).to(torch.bfloat16)
 
-    def t(fn, n=1):
-        fn()
-        t0 = time.perf_counter()
-        for _ in range(n):
+    def t(fn, n=3):
+        fn()                                           # 1 warm-up
+        ts = []
+        for _ in range(n):                             # 3 timed, median
+            t0 = time.perf_counter()
             fn()
-        return (time.perf_counter() - t0) / n
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
     with torch.no_grad():
         t_clip = t(lambda: O.clip_vision_hidden_states(sd, vcfg, img, n_layers_to_run=nv))
         t_clip0 = t(lambda: O.clip_vision_hidden_states(sd, vcfg, img, n_layers_to_run=0))
@@ -188,11 +233,77 @@ def cpu_baseline(image_size, prompt_tokens):
         t_llm0 = t(lambda: O.llama_model(sd, lcfg0, emb))
         hs = O.llama_model(sd, lcfg0, emb)[0][-1]
         t_head = t(lambda: torch.nn.functional.linear(hs, sd["lm_head.weight"]))
-    per_img = t_clip0 + (t_clip - t_clip0) / nv * 23 + t_llm0 + (t_llm - t_llm0) / nl * 32 + t_head
+    per_img = t_clip0 + max(t_clip - t_clip0, 0.0) / nv * 23 + t_llm0 + max(t_llm - t_llm0, 0.0) / nl * 32 + t_head
     return dict(value=round(1.0 / per_img, 4), unit="images/sec", cores=best_n, kind="port",
                 sample=f"oracle (torch-CPU bf16 restatement of the reference path), 1 image {image_size}x{image_size} S={S}: "
-                       f"{nv}/23 CLIP layers + {nl}/32 LLaMA-7B layers + lm_head timed, extrapolated linearly in layer count "
-                       f"({per_img:.2f} s/image; {best_n} of {os.cpu_count()} host threads, fastest on a probe matmul)")
+                       f"{nv}/23 CLIP layers + {nl}/32 LLaMA-7B layers + lm_head, each 1 warm-up + 3 timed (median), extrapolated "
+                       f"linearly in layer count ({per_img:.2f} s/image; {best_n} of {os.cpu_count()} host threads, fastest on a probe matmul)")
+
+
+def timed_steps(step, steps, warmup, dist, batch, device):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX elapsed over ranks and
+    SUM of images over ranks through the path's only collective (u-llava_amd.dist.global_rate)."""
+    D = importlib.import_module("u-llava_amd.dist")
+    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    return D.global_rate(float(batch * steps), elapsed, device=device)        # (images/s whole job, images, max elapsed)
+
+
+def workload_step(name, dev, rank, batch_override=None):
+    """Build model + inputs of a workload; returns (step callable, per-GPU batch, S, cfg, description, flops per image)."""
+    image_size, prompt, batch, desc = WORKLOADS[name]
+    batch = batch_override or batch
+    res, video = name == "res", name == "c5"
+    model, cfg = build_model(image_size, dev, seed=rank, with_sam=res)
+    vis, ids, mask = make_inputs(cfg, batch, prompt, dev, rank, ragged=(name == "c2"), video=video)
+    S = ids.shape[1]
+    P = (image_size // 14) ** 2
+    flops_img = llama_flops(S, cfg.vocab_size) + (8 if video else 1) * clip_flops(P) + 2 * ((8 + P) if video else (P + 1)) * 1024 * 4096
+    if res:
+        # three rounds per sample, each ending "... [SEG] ... [LOC]" (RefCOCO-shaped: valid region 768x1024 -> original 480x640)
+        for r in range(3):
+            ids[:, S - 10 - 40 * r] = SEG
+            ids[:, S - 5 - 40 * r] = LOC
+        g = torch.Generator(device="cuda").manual_seed(2000 + rank)
+        images_sam = torch.randn(batch, 3, 1024, 1024, device=dev, generator=g).to(torch.bfloat16)
+        sizes, resizes = [(480, 640)] * batch, [(768, 1024)] * batch
+        flops_img += 5.96e12 + 3 * 3.61e9          # SURVEY 8(d): SAM ViT-H encoder + 3 mask-decoder passes
+
+        def step():
+            return model.forward(images_sam=images_sam, images=vis, input_ids=ids, labels=None, attention_mask=mask,
+                                 mask_list=[None] * batch, size_list=sizes, resize_list=resizes, bbox_list=[None] * batch, inference=True)
+    elif video:
+        def step():
+            return model.forward(input_ids=ids, attention_mask=mask, videos=vis)
+    else:
+        def step():
+            return model.forward(input_ids=ids, attention_mask=mask, images=vis)
+    return step, batch, S, cfg, desc, flops_img, model
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside a distributed launch: start N ranks (one per GPU) under torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvp(cmd[0], cmd)
 
 
 def main():
@@ -204,67 +315,77 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-res", action="store_true", help="skip the C3 RES sub-record of the default (c4) run")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks (only with --stub)")
+    ap.add_argument("--stub", action="store_true", help="replace the model step by a fixed host-side delay (tests the N-rank protocol without a GPU)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                                           # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
+    if a.stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        if a.backend == "nccl":
+            dist_.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        else:
+            dist_.init_process_group("gloo")
         dist = dist_
-    image_size, prompt, batch, desc = WORKLOADS[a.workload]
-    batch = a.batch or batch
 
-    res = a.workload == "res"
-    model, cfg = build_model(image_size, dev, seed=rank, with_sam=res)
-    images, ids, mask = make_inputs(cfg, batch, prompt, dev, rank)
-    S = ids.shape[1]
-    if res:
-        # three rounds per sample, each ending "... [SEG] ... [LOC]" (RefCOCO-shaped: valid region 768x1024 -> original 480x640)
-        for r in range(3):
-            ids[:, S - 10 - 40 * r] = SEG
-            ids[:, S - 5 - 40 * r] = LOC
-        g = torch.Generator(device="cuda").manual_seed(2000 + rank)
-        images_sam = torch.randn(batch, 3, 1024, 1024, device=dev, generator=g).to(torch.bfloat16)
-        sizes, resizes = [(480, 640)] * batch, [(768, 1024)] * batch
+    if a.stub:
+        image_size, prompt, batch, desc = WORKLOADS[a.workload]
+        batch = a.batch or batch
 
         def step():
-            return model.forward(images_sam=images_sam, images=images, input_ids=ids, labels=None, attention_mask=mask,
-                                 mask_list=[None] * batch, size_list=sizes, resize_list=resizes, bbox_list=[None] * batch, inference=True)
-    else:
-        def step():
-            return model.forward(input_ids=ids, attention_mask=mask, images=images)
+            time.sleep(0.01 * (1 + rank))                        # rank r is (r+1)x slower: the MAX over ranks must show
+        value, total_images, elapsed = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": round(value, 3), "unit": "images/sec (whole job)", "n_gpus": world, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "stub", "total_images": total_images,
+                              "config": {"workload": "stub step (host-side delay), " + desc, "per_gpu_batch": batch,
+                                         "global_batch": batch * world, "parallelism": f"dp{world}"}}), flush=True)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     with torch.no_grad():
-        for _ in range(a.warmup):
-            step()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    D = importlib.import_module("u-llava_amd.dist")
-    # the path's only collective: scalar MAX(elapsed) / SUM(images) over RCCL/xGMI
-    value, total_images, elapsed = D.global_rate(float(batch * a.steps), elapsed, device=dev)
+        step, batch, S, cfg, desc, flops_img, model = workload_step(a.workload, dev, rank, a.batch)
+        value, total_images, elapsed = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
+        image_size, prompt = WORKLOADS[a.workload][:2]
+        res_rec = None
+        roof = None
+        if rank == 0 and not a.no_roofline:
+            roof = gemm_roofline(cfg, batch * S, dev)
+        if a.workload == "c4" and not a.no_res:
+            # second half of BASELINE.json's metric: the full RES forward (C3), same timing protocol, same process
+            del step, model
+            torch.cuda.empty_cache()
+            rstep, rbatch, rS, rcfg, rdesc, rflops, rmodel = workload_step("res", dev, rank)
+            rsteps = max(3, min(a.steps, 10))
+            rvalue, rimgs, relapsed = timed_steps(rstep, rsteps, max(1, min(a.warmup, 2)), dist, rbatch, dev)
+            res_rec = {"value": round(rvalue, 3), "unit": "images/sec (whole job)", "steps": rsteps, "ms_per_step": round(relapsed / rsteps * 1e3, 3),
+                       "images_per_sec_per_gpu": round(rvalue / world, 3),
+                       "config": {"workload": rdesc, "per_gpu_batch": rbatch, "global_batch": rbatch * world, "seq_len": rS,
+                                  "sam_input": "1024x1024 (valid 768x1024 -> 480x640 masks)", "prompts_per_image": 3},
+                       "model_tflops_per_image": round(rflops / 1e12, 3),
+                       "frac_of_bf16_peak_end_to_end": round(rflops * rvalue / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            del rstep, rmodel
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        P = (image_size // 14) ** 2
-        flops_img = llama_flops(S, cfg.vocab_size) + clip_flops(P) + 2 * (P + 1) * 1024 * 4096
-        if res:
-            flops_img += 5.96e12 + 3 * 3.61e9          # SAM ViT-H encoder + 3 mask-decoder passes
-        line = {"metric": "images/sec (ViT-L-%d + LLaMA-7B%s forward)" % (image_size, " + SAM RES" if res else ""), "value": round(value, 3), "unit": "images/sec",
+        line = {"metric": METRIC, "value": round(value, 3), "unit": "images/sec (whole job, all GPUs)",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": desc, "per_gpu_batch": batch, "global_batch": batch * world, "seq_len": S, "image": image_size,
@@ -273,9 +394,10 @@ def main():
                 "model_tflops_per_image": round(flops_img / 1e12, 3),
                 "model_tflops_per_sec_per_gpu": round(flops_img * value / world / 1e12, 1),
                 "frac_of_bf16_peak_end_to_end": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
-        if not a.no_roofline:
-            with torch.no_grad():
-                line["roofline"] = gemm_roofline(cfg, batch * S, dev)
+        if res_rec is not None:
+            line["res"] = res_rec
+        if roof is not None:
+            line["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(image_size, prompt)
         print(json.dumps(line), flush=True)

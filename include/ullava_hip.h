@@ -38,13 +38,19 @@ extern "C" {
  * common.py:13-26, transformer.py:220-242, mask_decoder.py:169-191. */
 /* flags also accepts ULL_EPI_W_TILED (64) / ULL_EPI_X_TILED (128): that operand is stored tile-major
  * [rows/256][K/64][256][64] (rows zero-padded to a multiple of 256; every 256 x 64 K-tile = 32 contiguous KiB, which makes an L2
- * miss cheaper: +4 % on the LLaMA layer GEMMs).  Only with M >= 1024, N >= 512, K >= 128 (the 256 x 256 kernel); ldw / ldx ignored. */
+ * miss cheaper: +4 % on the LLaMA layer GEMMs).  Only with M >= 1024, N >= 512, K >= 128 (the 256 x 256 kernel); ldw / ldx ignored.
+ * ws / ws_bytes: caller-owned scratch for the stream-K tail (a partial last round of 256x256 tiles is split along K into fp32
+ * slabs of 256 KiB there and summed by a finalize launch on the same stream).  NULL / 0 = never split.  The library keeps no
+ * buffer and no per-stream state of its own: concurrent calls on different streams are independent as long as each passes its own
+ * workspace (ull_gemm_streamk_ws_bytes() is enough for any shape).  Whether to split at all is the caller's policy.
+ * Bits 16..20 of flags are per-call tuning overrides for tools/ (ULL_GEMM_TUNE_*); 0 = shipped heuristics. */
+#define ULL_GEMM_TUNE_GROUP_M(g) (((g) & 15) << 16) /* tile raster: M-tiles walked before the next N-tile */
+#define ULL_GEMM_TUNE_SMALL_KERNEL (1 << 20)        /* force the 128x128 kernel */
 int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
-                  int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+                  int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream);
 
-/* Host policy knob: K below which ull_gemm_bf16 does not split a partial last round of tiles along K (default 2048).  The model
- * raises it while a second stream shares the GPU (RES forward), where the idle CUs of a partial round are not idle. */
-int ull_gemm_set_streamk_min_k(int64_t min_k);
+/* Bytes of stream-K workspace that cover every shape ull_gemm_bf16 may split (256 slabs of 256 x 256 fp32 = 64 MiB). */
+int64_t ull_gemm_streamk_ws_bytes(void);
 
 /* The same Linear for decode steps (M <= 4 rows, K % 8 == 0): a pure weight stream, one wave per output feature, no LDS/MFMA.
  * Same flags, layouts and rounding points as ull_gemm_bf16.  Reached from generate() after the prefill
@@ -108,16 +114,18 @@ int ull_transpose_v_bf16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, in
 int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp, void* stream);
 
 /* models/ullava_core.py:205-226,248-251: per-sample start/end token counts, first start position, running feature index.
- * spans int32 [B,4] = {kind 0 text / 1 image / 2 video, first start pos, feature index, error(counts differ)}. */
+ * spans int32 [B,4] = {kind 0 text / 1 image / 2 video, first start pos, feature index, error bits}: bit 0 = start/end counts
+ * differ (the reference's assert, :209-211), bit 1 = an id outside [0, vocab) (nn.Embedding's IndexError, :191; vocab <= 0: unchecked). */
 int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_start, int64_t img_end, int64_t vid_start, int64_t vid_end,
-                 void* spans, void* stream);
+                 int64_t vocab, void* spans, void* stream);
 
 /* models/ullava_core.py:191,243-245,266-268: token-embedding lookup with the projected visual tokens spliced in after
  * the first start token (the torch.cat of the reference, done as one gather).  Image i's n_img_tok feature rows start
- * at row i*img_pitch + img_off of img_feat (pitch = patches + 1, off = 1 skips the CLS row without a copy). */
+ * at row i*img_pitch + img_off of img_feat (pitch = patches + 1, off = 1 skips the CLS row without a copy).
+ * ids outside [0, vocab) are clamped (no out-of-bounds read; ull_mm_spans reports them). */
 int ull_embed_splice_bf16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch,
                           int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B, int64_t S,
-                          int64_t D, void* stream);
+                          int64_t D, int64_t vocab, void* stream);
 
 /* models/ullava_core.py:173-178: f[b,t,tok_pitch,d] (patches = tokens tok_off..tok_off+N) -> concat([mean over n (temporal), mean over t (spatial)], dim=1). */
 int ull_video_pool_bf16(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch, int64_t tok_off,

@@ -290,13 +290,21 @@ def core_forward(sd, cfg: dict, input_ids: Tensor, attention_mask: Optional[Tens
 
 
 def greedy_generate(sd, cfg: dict, input_ids: Tensor, images=None, videos=None, max_new_tokens: int = 8,
-                    eos_token_id: Optional[int] = None):
+                    eos_token_id: Optional[int] = None, attention_mask: Optional[Tensor] = None):
     """Greedy decode through core_forward WITHOUT a KV cache (the configuration the reference
-    checkpoints run: use_cache=False).  Returns (sequences, last-step hidden_states[-1])."""
+    checkpoints run: use_cache=False).  Returns (sequences, last-step hidden_states[-1]).
+    With an attention_mask (left-padded batches) every step derives position_ids = cumsum(mask) - 1 with
+    pad positions set to 1, as prepare_inputs_for_generation does (models/ullava_core.py:371-377)."""
     seq = input_ids.clone()
     last_h = None
     for _ in range(max_new_tokens):
-        o = core_forward(sd, cfg, seq, torch.ones_like(seq), images, videos)
+        if attention_mask is None:
+            mask, pos = torch.ones_like(seq), None
+        else:
+            mask = torch.cat([attention_mask, attention_mask.new_ones(seq.shape[0], seq.shape[1] - attention_mask.shape[1])], dim=1)
+            pos = mask.long().cumsum(-1) - 1
+            pos.masked_fill_(mask == 0, 1)
+        o = core_forward(sd, cfg, seq, mask, images, videos, position_ids=pos)
         last_h = o["hidden_states"][-1]
         nxt = o["logits"][:, -1].float().argmax(-1, keepdim=True)
         seq = torch.cat([seq, nxt], dim=1)

@@ -183,8 +183,17 @@ def gen_core(name, cd, dtype, seed, with_greedy):
                 pkv = out.past_key_values
                 toks.append(out.logits[:, -1].float().argmax(-1, keepdim=True))
         seq_kv = torch.cat([one] + toks, dim=1)
+        # left-padded prompt through HF generate: position_ids come from the attention mask (ullava_core.py:371-377)
+        ids_lp = torch.cat([torch.zeros(1, 3, dtype=one.dtype), one], dim=1)
+        mask_lp = torch.cat([torch.zeros(1, 3, dtype=one.dtype), torch.ones_like(one)], dim=1)
+        with torch.no_grad():
+            gen_lp = m.generate(input_ids=ids_lp, attention_mask=mask_lp, images=images[:1], do_sample=False, use_cache=False,
+                                max_new_tokens=6, pad_token_id=0, eos_token_id=None)
+        seq_lp, _ = O.greedy_generate(sd, cd, ids_lp, images[:1], None, 6, attention_mask=mask_lp)
+        assert torch.equal(gen_lp, seq_lp), (gen_lp, seq_lp)
         fx.update(greedy_prompt=one, greedy_sequences=gen, greedy_last_hidden=rh, greedy_sequences_kvcache=seq_kv,
-                  greedy_kv_equal=bool(torch.equal(seq_kv, gen)))
+                  greedy_kv_equal=bool(torch.equal(seq_kv, gen)), leftpad_ids=ids_lp, leftpad_mask=mask_lp, leftpad_sequences=gen_lp)
+        print("   left-padded greedy:", gen_lp[0, ids_lp.shape[1]:].tolist())
         print("   greedy:", gen[0, one.shape[1]:].tolist(), "kv-cache equal:", fx["greedy_kv_equal"])
     save(name, fx)
 
@@ -236,7 +245,7 @@ def gen_mixed(name, dtype, seed):
 
 
 # --------------------------------------------------------------------------- G7 SAM prompt-enc + mask decoder (full dims)
-def gen_sam_decoder(name, dtype, seed, n_list=(1, 3)):
+def gen_sam_decoder(name, dtype, seed, n_list=(1, 3, 10)):
     print(f"[{name}]")
     sam = ref_build_sam(checkpoint=None)
     dec_sd_ref = {"visual_model." + k: v for k, v in sam.state_dict().items() if not k.startswith("image_encoder.")}
@@ -269,8 +278,11 @@ def gen_sam_decoder(name, dtype, seed, n_list=(1, 3)):
         eq(olr, lr, f"low_res_masks n={n}")
         eq(oiou, iou, f"iou n={n}")
         eq(O.postprocess_masks(olr, (768, 1024), (480, 640)), pm, f"postprocess n={n}")
-        # full-res masks are big: keep the low-res logits + a strided sample of the final masks
-        fx["cases"].append(dict(n=n, text_embeds=text, low_res_masks=lr, iou=iou, post_sample=pm[:, :, ::8, ::8].contiguous(),
+        # full-res masks are big: keep the low-res logits + a strided sample of the final masks; for the 10-prompt case
+        # (val-time maximum, res_dataset.py:20,163) every second row / column of the logits
+        st = 1 if n <= 3 else 2
+        fx["cases"].append(dict(n=n, text_embeds=text, low_res_masks=lr[:, :, ::st, ::st].contiguous(), low_res_stride=st,
+                                low_res_max=lr.float().abs().max().item(), iou=iou, post_sample=pm[:, :, ::8, ::8].contiguous(),
                                 post_sum=pm.double().sum().item(), post_abs_sum=pm.double().abs().sum().item()))
     save(name, fx)
 
@@ -366,6 +378,95 @@ def gen_losses(name, dtype, seed):
                     dict_keys=sorted(r.keys())))
 
 
+# --------------------------------------------------------------------------- G9 SAM encoder blocks at ViT-H width
+def gen_sam_blocks(name, dtype, seed):
+    """One windowed (14x14) + one global (64x64, rel-pos bias) block of the ViT-H image encoder at d=1280 / 16 heads on a
+    1024x1024 image, incl. patch embed, pos embed and neck (image_encoder.py:110-125)."""
+    print(f"[{name}]")
+    from models.segment_anything.modeling.image_encoder import ImageEncoderViT
+    from functools import partial
+    enc = ImageEncoderViT(depth=2, embed_dim=1280, img_size=1024, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                          num_heads=16, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=[1], window_size=14,
+                          out_chans=256).eval()
+    shapes = {"visual_model.image_encoder." + k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    sd32 = W.seeded_state_dict(shapes, seed, torch.float32)
+    enc.load_state_dict({k[len("visual_model.image_encoder."):]: v for k, v in sd32.items()}, strict=True)
+    enc.to(dtype)
+    sd = {k: v.to(dtype) for k, v in sd32.items()}
+    g = torch.Generator().manual_seed(seed + 29)
+    img = torch.randn(1, 3, 1024, 1024, generator=g).to(dtype)
+    with torch.no_grad():
+        r = enc(img)
+    scfg = dict(patch_size=16, depth=2, global_attn_indexes=[1], window_size=14, num_heads=16)
+    o = O.sam_image_encoder(sd, scfg, img)
+    eq(o, r, "SAM encoder blocks (d=1280)")
+    save(name, dict(seed=seed, dtype=str(dtype), shapes=shapes, cfg=scfg, image_seed=seed + 29,
+                    embedding_sample=r[:, ::2, ::2, ::2].contiguous(), embedding_sum=r.double().sum().item(),
+                    embedding_abs_sum=r.double().abs().sum().item(), embedding_max=r.float().abs().max().item()))
+
+
+# --------------------------------------------------------------------------- G11 evaluate(): ids + masks + boxes
+def gen_evaluate(name, dtype, seed):
+    """UllavaForCausalLM.evaluate cannot run under transformers 5.15 (generate drops output_hidden_states), so the
+    reference outputs are assembled from reference calls exactly as evaluate() does (models/ullava.py:350-432): HF greedy
+    generate(use_cache=False) -> reference forward on sequences[:, :-1] for hidden_states[-1] -> the reference's own projectors,
+    prompt encoder, mask decoder, postprocess and det_decoder modules."""
+    print(f"[{name}]")
+    m, cfg, shapes, sd, ocfg, ids, mask, images, images_sam, size_list, resize_list = _full_setup(dtype, seed)
+    one, img1, sam1 = ids[:1], images[:1], images_sam[:1]
+    SEG, LOC = ocfg["seg_token_idx"], ocfg["loc_token_idx"]
+    with torch.no_grad():
+        # make the greedy continuation emit [SEG] / [LOC]: bias the lm_head rows of those two tokens (a weight edit, stored as such)
+        seq = m.llm.generate(input_ids=one, images=img1, do_sample=False, use_cache=False, max_new_tokens=6, pad_token_id=0, eos_token_id=None)
+        hs = m.llm(input_ids=seq[:, :-1], images=img1, output_hidden_states=True).hidden_states[-1]
+        seg_mask = seq[:, 1:] == SEG
+        loc_mask = seq[:, 1:] == LOC
+        emb_seg = m.seg_projector(hs)[seg_mask]
+        emb_loc = m.det_projector(hs)[loc_mask]
+        image_embeddings = m.get_visual_embs(sam1)
+        sp, de = m.visual_model.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=emb_seg.unsqueeze(1))
+        sp = sp.to(emb_seg.dtype)
+        low, _ = m.visual_model.mask_decoder(image_embeddings=image_embeddings[0].unsqueeze(0),
+                                             image_pe=m.visual_model.prompt_encoder.get_dense_pe(), sparse_prompt_embeddings=sp,
+                                             dense_prompt_embeddings=de, multimask_output=False)
+        pm = m.visual_model.postprocess_masks(low, input_size=resize_list[0], original_size=size_list[0])[:, 0]
+        boxes = m.det_decoder(emb_loc)
+    oseq, omasks, oboxes = O.ullava_evaluate(sd, ocfg, sam1, img1, one, [size_list[0]], [resize_list[0]], max_new_tokens=6)
+    assert torch.equal(oseq, seq), (oseq, seq)
+    eq(omasks[0], pm, "evaluate masks")
+    eq(oboxes[0], boxes, "evaluate boxes")
+    print("   evaluate ids:", seq[0, one.shape[1]:].tolist(), "n_seg", int(seg_mask.sum()), "n_loc", int(loc_mask.sum()))
+    save(name, dict(cfg=ocfg, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=one, images=img1, images_sam_seed=seed + 19,
+                    size=size_list[0], resize=resize_list[0], sequences=seq, low_res_masks=low, pred_mask_sample=pm[:, ::4, ::4].contiguous(),
+                    pred_mask_max=pm.abs().max().item(), pred_boxes=boxes))
+
+
+def gen_signatures(name):
+    """inspect.signature of the reference's public model surface: parameter names, order and defaults."""
+    import inspect
+    import json
+
+    def sig(fn):
+        out = []
+        for p_ in inspect.signature(fn).parameters.values():
+            d = None if p_.default is inspect.Parameter.empty else repr(p_.default)
+            out.append([p_.name, str(p_.kind), d])
+        return out
+    table = {}
+    for cls, names in ((UllavaCoreForCausalLM, ["__init__", "forward", "prepare_inputs_for_generation", "encode_image", "encode_video",
+                                                "embed_images_videos", "init_mm_tokens", "get_input_embeddings", "get_output_embeddings",
+                                                "build_vision_projector"]),
+                       (UllavaForCausalLM, ["__init__", "forward", "evaluate", "get_visual_embs", "load_visual_checkpoint"]),
+                       (UllavaCoreConfig, ["__init__"]), (UllavaConfig, ["__init__"])):
+        for n in names:
+            table[f"{cls.__name__}.{n}"] = sig(getattr(cls, n))
+    table["registered_model_types"] = [UllavaCoreConfig.model_type, UllavaConfig.model_type]
+    path = os.path.join(OUT, name)
+    with open(path, "w") as f:
+        json.dump(dict(signatures=table, meta=META), f, indent=1, sort_keys=True)
+    print(f"  wrote {name}")
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:])
 
@@ -382,9 +483,17 @@ if __name__ == "__main__":
     if want("samdec"):
         gen_sam_decoder("g7_sam_decoder_fp32.pt", torch.float32, 7)
         gen_sam_decoder("g7_sam_decoder_bf16.pt", torch.bfloat16, 7)
+        gen_sam_decoder("g7_sam_decoder_fp16.pt", torch.float16, 7)
     if want("full"):
         gen_full("g8_full_tiny_fp32.pt", torch.float32, 8)
         gen_full("g8_full_tiny_bf16.pt", torch.bfloat16, 8)
+        gen_full("g8_full_tiny_fp16.pt", torch.float16, 8)
+    if want("samblocks"):
+        gen_sam_blocks("g9_sam_blocks_bf16.pt", torch.bfloat16, 9)
+    if want("evaluate"):
+        gen_evaluate("g11_evaluate_bf16.pt", torch.bfloat16, 8)
+    if want("signatures"):
+        gen_signatures("reference_signatures.json")
     if want("losses"):
         gen_losses("g10_train_losses_fp32.pt", torch.float32, 8)
         gen_losses("g10_train_losses_bf16.pt", torch.bfloat16, 8)

@@ -55,3 +55,31 @@ def test_single_process_rate_needs_no_group():
     D = importlib.import_module("u-llava_amd.dist")
     assert D.global_rate(64.0, 2.0) == (32.0, 64.0, 2.0)
     assert [D.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_bench_launches_n_ranks_itself_gloo_stub():
+    """`python bench.py --gpus 2` must start 2 ranks on its own (no external torchrun), run the barrier-bracketed timing protocol
+    over them and report n_gpus = 2 with the MAX-over-ranks time and the SUM-over-ranks images (stub step, gloo, CPU)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                     # rank 0 only, ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["total_images"] == 2 * 32 * 3 and rec["config"]["global_batch"] == 64
+    assert rec["ms_per_step"] >= 20.0                    # rank 1 sleeps 20 ms per step: the MAX over ranks
+    assert abs(rec["value"] - rec["total_images"] / (rec["ms_per_step"] * 3e-3)) < 0.05 * rec["value"]
+
+
+def test_bench_rejects_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--backend", "gloo"], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "launcher started 1 rank" in (r.stderr + r.stdout)

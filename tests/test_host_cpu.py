@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
     L = pkg("_lib")
     lib = L.load()
     header = open(os.path.join(ROOT, "include", "ullava_hip.h")).read()
-    declared = set(re.findall(r"\bint (ull_[a-z0-9_]+)\(", header))
+    declared = set(re.findall(r"\bint(?:64_t)? (ull_[a-z0-9_]+)\(", header))
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
@@ -56,3 +56,40 @@ def test_config_to_dict_keys():
               "loc_token_idx", "train_mask_decoder", "model_type"):
         assert k in d
     assert d["llm_config"]["vision_config"]["hidden_size"] == 32 and d["seg_token_idx"] == 32007
+
+
+def test_public_signatures_match_reference_fixture():
+    """constructor / forward / evaluate / generate-prep signatures of the two model classes and the two configs
+    carry the reference's parameter names in the reference's order (tests/golden/reference_signatures.json is generated from the
+    reference with inspect.signature by gen_golden.py).  Extra trailing keyword parameters (device=, dtype=) are allowed."""
+    import inspect
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))["signatures"]
+    C, MC, MU = pkg("configuration"), pkg("modeling_core"), pkg("modeling_ullava")
+    classes = {"UllavaCoreForCausalLM": MC.UllavaCoreForCausalLM, "UllavaForCausalLM": MU.UllavaForCausalLM,
+               "UllavaCoreConfig": C.UllavaCoreConfig, "UllavaConfig": C.UllavaConfig}
+    checked = 0
+    for key, want in ref.items():
+        if key == "registered_model_types":
+            assert [C.UllavaCoreConfig.model_type, C.UllavaConfig.model_type] == want
+            continue
+        cname, mname = key.split(".")
+        got = list(inspect.signature(getattr(classes[cname], mname)).parameters.values())
+        want_named = [w for w in want if "VAR_" not in w[1]]
+        if cname.endswith("Config"):
+            # configs: every reference keyword must be accepted by name (ours spell out LLaMA fields the reference gets via **kwargs)
+            names = {p.name for p in got}
+            has_kwargs = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in got)
+            for w in want_named:
+                assert w[0] in names or has_kwargs, (key, w[0])
+            for w in want_named:
+                if w[0] in names and w[2] is not None and w[0] != "self":
+                    assert repr(next(p.default for p in got if p.name == w[0])) == w[2], (key, w[0])
+        else:
+            got_named = [p for p in got if p.kind not in (inspect.Parameter.VAR_KEYWORD, inspect.Parameter.VAR_POSITIONAL)]
+            assert [p.name for p in got_named[:len(want_named)]] == [w[0] for w in want_named], (key, [p.name for p in got_named])
+            for p, w in zip(got_named, want_named):
+                if w[2] is not None:
+                    assert repr(p.default) == w[2], (key, p.name, repr(p.default), w[2])
+        checked += 1
+    assert checked >= 16

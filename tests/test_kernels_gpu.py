@@ -439,3 +439,41 @@ def test_linear_fuzz_shapes_and_epilogues():
         want = t.float() if f32 else t.to(BF)
         assert_close_bf16(got, want, ulps=2.0, what=f"fuzz M={M} N={N} K={K} act={act} bias={use_b} res={use_r} f32={f32}", outlier_frac=1e-4,
                           outlier_floor=float(want.float().abs().max()))
+
+
+def test_gemm_streamk_two_streams_concurrently():
+    """Re-entrancy of the C-ABI (include/ullava_hip.h): two stream-K GEMMs in flight on two HIP streams use two caller-owned
+    workspaces and must both equal their single-stream results bit for bit (a shared workspace corrupts one of them)."""
+    ops = pkg("ops")
+    M, N, K = 256 * 9, 256 * 32, 2048                      # 288 tiles: 32 tail tiles split 8 ways along K
+    xs = [_rand(M, K, seed=51 + i).to(DEV) for i in range(2)]
+    ws = [_rand(N, K, seed=61 + i, scale=K ** -0.5).to(DEV) for i in range(2)]
+    alone = [ops.linear(xs[i], ws[i]) for i in range(2)]
+    torch.cuda.synchronize()
+    assert_close_bf16(alone[0][:300, :600], _mm_ref(xs[0][:300].cpu(), ws[0][:600].cpu()), what="stream-K GEMM vs oracle")
+    assert_close_bf16(alone[1][-300:, -600:], _mm_ref(xs[1][-300:].cpu(), ws[1][-600:].cpu()), what="stream-K GEMM vs oracle")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[torch.empty_like(alone[i]) for _ in range(6)] for i in range(2)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    for it in range(6):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                ops.linear(xs[i], ws[i], out=outs[i][it])
+    torch.cuda.synchronize()
+    assert len({k for k in ops._SK_WS if k[0] == 0}) >= 2, "each stream must own a workspace"
+    for i in range(2):
+        for it in range(6):
+            assert torch.equal(outs[i][it], alone[i]), f"stream {i} iteration {it} differs from the single-stream result"
+
+
+def test_gemm_without_workspace_never_splits():
+    """ws = NULL is legal (no K-split) and gives the same values up to the fp32 summation order of the split."""
+    ops = pkg("ops")
+    M, N, K = 256 * 9, 256 * 32, 2048
+    x, w = _rand(M, K, seed=71).to(DEV), _rand(N, K, seed=72, scale=K ** -0.5).to(DEV)
+    with ops.streamk_policy(None):
+        y0 = ops.linear(x, w)
+    y1 = ops.linear(x, w)
+    assert_close_bf16(y0, y1.cpu(), ulps=1.0, what="split vs unsplit")
+    assert torch.equal(y0[: 256 * 8], y1[: 256 * 8])         # whole-tile rounds do not depend on the policy

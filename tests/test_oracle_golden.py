@@ -35,6 +35,10 @@ def test_greedy_ids(name):
     assert torch.equal(seq, fx["greedy_sequences"])
     assert torch.equal(seq, fx["greedy_sequences_kvcache"]) == fx["greedy_kv_equal"]
     _eq(last_h, fx["greedy_last_hidden"])
+    # left-padded prompt: position_ids from the attention mask (what HF generate feeds the reference)
+    seq, _ = O.greedy_generate(sd, fx["cfg"], fx["leftpad_ids"], fx["images"][:1], None, 6, attention_mask=fx["leftpad_mask"])
+    assert torch.equal(seq, fx["leftpad_sequences"])
+    assert torch.equal(seq[:, 3:], fx["greedy_sequences"][:, :seq.shape[1] - 3])      # padding does not change the continuation
 
 
 def test_video_branch():
@@ -53,7 +57,7 @@ def test_text_only_and_mixed_batch():
     _eq(o["hidden_states"][-1], fx["last_hidden"])
 
 
-@pytest.mark.parametrize("name", ["g7_sam_decoder_fp32.pt", "g7_sam_decoder_bf16.pt"])
+@pytest.mark.parametrize("name", ["g7_sam_decoder_fp32.pt", "g7_sam_decoder_bf16.pt", "g7_sam_decoder_fp16.pt"])
 def test_sam_prompt_encoder_mask_decoder(name):
     fx = load_fixture(name)
     sd = fixture_state_dict(fx)
@@ -67,7 +71,9 @@ def test_sam_prompt_encoder_mask_decoder(name):
         sp, de = O.prompt_encoder_text(sd, case["text_embeds"], (64, 64))
         assert sp.dtype == torch.float32          # the fp32 detour (prompt_encoder.py:165-177)
         lr, iou = O.mask_decoder(sd, emb, pe, sp.to(dt), de, False)
-        _eq(lr, case["low_res_masks"])
+        st = case["low_res_stride"]
+        _eq(lr[:, :, ::st, ::st].contiguous(), case["low_res_masks"])
+        assert lr.float().abs().max().item() == case["low_res_max"]
         _eq(iou, case["iou"])
         pm = O.postprocess_masks(lr, (768, 1024), (480, 640))
         assert pm.dtype == torch.float32 and tuple(pm.shape) == (case["n"], 1, 480, 640)
@@ -75,7 +81,7 @@ def test_sam_prompt_encoder_mask_decoder(name):
         assert pm.double().sum().item() == case["post_sum"]
 
 
-@pytest.mark.parametrize("name", ["g8_full_tiny_fp32.pt", "g8_full_tiny_bf16.pt"])
+@pytest.mark.parametrize("name", ["g8_full_tiny_fp32.pt", "g8_full_tiny_bf16.pt", "g8_full_tiny_fp16.pt"])
 def test_full_forward_tiny_sam(name):
     fx = load_fixture(name)
     sd = fixture_state_dict(fx)
@@ -115,3 +121,29 @@ def test_training_losses_g10(name):
     assert sorted(ol.keys()) == fx["dict_keys"]
     for k, ref in fx["losses"].items():
         assert torch.equal(ol[k].float(), ref), k
+
+
+def test_sam_encoder_blocks_g9():
+    """one windowed + one global ViT-H block at d=1280 on a 1024x1024 image (patch embed, pos embed, rel-pos bias, neck)."""
+    fx = load_fixture("g9_sam_blocks_bf16.pt")
+    sd = fixture_state_dict(fx)
+    g = torch.Generator().manual_seed(fx["image_seed"])
+    img = torch.randn(1, 3, 1024, 1024, generator=g).to(torch.bfloat16)
+    torch.set_num_threads(8)
+    o = O.sam_image_encoder(sd, fx["cfg"], img)
+    _eq(o[:, ::2, ::2, ::2].contiguous(), fx["embedding_sample"])
+    assert o.double().sum().item() == fx["embedding_sum"]
+
+
+def test_evaluate_g11():
+    """evaluate(temperature=0): ids, masks and boxes assembled from reference calls (gen_golden.gen_evaluate)."""
+    fx = load_fixture("g11_evaluate_bf16.pt")
+    sd = fixture_state_dict(fx)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(torch.bfloat16)[:1]
+    seq, masks, boxes = O.ullava_evaluate(sd, fx["cfg"], images_sam, fx["images"], fx["input_ids"], [fx["size"]], [fx["resize"]],
+                                          max_new_tokens=6)
+    assert torch.equal(seq, fx["sequences"])
+    _eq(masks[0][:, ::4, ::4].contiguous(), fx["pred_mask_sample"])
+    _eq(boxes[0], fx["pred_boxes"])

@@ -19,7 +19,7 @@ def tile(a):
 
 
 def run(x, w, out, flags, M, N, K):
-    _lib.call("ull_gemm_bf16", x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), out.stride(0), None, None, 0, M, N, K, flags,
+    _lib.call("ull_gemm_bf16", x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), out.stride(0), None, None, 0, M, N, K, flags, None, 0,
               torch.cuda.current_stream().cuda_stream)
 
 

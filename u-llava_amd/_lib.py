@@ -12,10 +12,10 @@ LIB_PATH = os.environ.get("ULL_LIB_PATH", os.path.join(_HERE, "csrc", "libullava
 
 _i64, _i32, _f32, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
-# name -> argtypes (restype is always int)
+# name -> argtypes (restype is int = ULL_OK / ULL_ERR_* unless listed in VALUE_RETURNING)
 SIGNATURES = {
-    "ull_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
-    "ull_gemm_set_streamk_min_k": [_i64],
+    "ull_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _ptr],
+    "ull_gemm_streamk_ws_bytes": [],
     "ull_gemv_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_gemv_rmsnorm_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
@@ -28,8 +28,8 @@ SIGNATURES = {
     "ull_rope_append_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr],
     "ull_transpose_v_bf16": [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_im2col_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
-    "ull_mm_spans": [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
-    "ull_embed_splice_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "ull_mm_spans": [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    "ull_embed_splice_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
     "ull_video_pool_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_gather_rows_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "ull_add_rows_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
@@ -47,6 +47,8 @@ SIGNATURES = {
     "ull_mask_loss_sums_f32": [_ptr, _ptr, _i64, _i64, _f32, _ptr, _ptr],
     "ull_box_losses_f32": [_ptr, _i32, _ptr, _i64, _ptr, _ptr],
 }
+
+VALUE_RETURNING = {"ull_gemm_streamk_ws_bytes": _i64}      # plain queries: the return value is the answer, not a status
 
 ERRORS = {-1: "ULL_ERR_ARG (null pointer / bad size)", -2: "ULL_ERR_SHAPE (alignment or shape constraint)",
           -3: "ULL_ERR_LAUNCH (HIP launch failed)", -4: "ULL_ERR_LDS (does not fit the LDS budget)"}
@@ -67,7 +69,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = VALUE_RETURNING.get(name, ctypes.c_int)
     _lib = lib
     return lib
 
@@ -76,3 +78,8 @@ def call(name: str, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"u-llava_amd: {name} failed: {ERRORS.get(rc, rc)}")
+
+
+def query(name: str, *args):
+    """A VALUE_RETURNING entry point: returns its value."""
+    return getattr(load(), name)(*args)

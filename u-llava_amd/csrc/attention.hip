@@ -1207,11 +1207,9 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     const int lds = (EXACT ? 2 * NT : 2) * TILE + NT * KT +
                     (a.rel_h ? NWV * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     if (lds > 160 * 1024) return ULL_ERR_LDS;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static UllOncePerDevice once;
+    if (lds > 64 * 1024 && once.first())
         (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
@@ -1225,11 +1223,8 @@ int launch_long(const AttnArgs& a, hipStream_t st) {
     const int nt = (a.Sk + KT - 1) / KT;
     const int lds = 4 * TILE + ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     if (lds > 160 * 1024) return ULL_ERR_LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_long_kernel<HDP, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static UllOncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)attn_long_kernel<HDP, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nq = (a.Sq + 127) / 128;
     const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
     hipLaunchKernelGGL((attn_long_kernel<HDP, FL>), grid, dim3(512), lds, st, a);
@@ -1243,11 +1238,8 @@ int launch_stream(const AttnArgs& a, hipStream_t st) {
     int lds = 4 * TILE;
     if (HOIST == 0) lds += ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     if (lds > 160 * 1024) return ULL_ERR_LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_stream_kernel<HDP, FL, HOIST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static UllOncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)attn_stream_kernel<HDP, FL, HOIST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nq = (a.Sq + 127) / 128;
     const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
     hipLaunchKernelGGL((attn_stream_kernel<HDP, FL, HOIST>), grid, dim3(512), lds, st, a);
@@ -1257,11 +1249,8 @@ int launch_stream(const AttnArgs& a, hipStream_t st) {
 template <int HDP, int FL, int TPW>
 int launch_fewq_t(const AttnArgs& a, int nwv, hipStream_t st) {
     const int lds = 2 * 16 * 16 * 4 + nwv * HDP * 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fewq_kernel<HDP, FL, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static UllOncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)attn_fewq_kernel<HDP, FL, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((attn_fewq_kernel<HDP, FL, TPW>), dim3(a.B * a.H), dim3(nwv * 64), lds, st, a);
     return ull_check_launch();
 }
@@ -1290,8 +1279,7 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     if ((fl == FL_LLAMA || fl == FL_CLIP) && a.hd != HDP) fl = FL_RUNTIME;
     if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
     // <= 16 queries (decode steps, mask-decoder tokens): split the keys over the waves of one block per head
-    static const bool no_fewq = getenv("ULL_ATTN_NO_FEWQ") != nullptr;                  // A/B switch
-    if (a.Sq <= 16 && !a.rel_h && nt >= 2 && nt <= 64 && !no_fewq) {
+    if (a.Sq <= 16 && !a.rel_h && nt >= 2 && nt <= 64) {
         if constexpr (HDP == 128) {
             if (fl == FL_LLAMA) return launch_fewq<HDP, FL_LLAMA>(a, st);
         }
@@ -1302,23 +1290,19 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     }
     // specialised instantiations exist for the shapes on the u-LLaVA path; everything else takes the run-time-flag kernels
     if constexpr (HDP == 128) {
-        static const bool w8 = getenv("ULL_ATTN_8WAVES") != nullptr;          // A/B switch
-        if (fl == FL_LLAMA && nt <= 11) return w8 ? launch_attn<128, 11, FL_LLAMA, 8>(a, st) : launch_attn<128, 11, FL_LLAMA, 4>(a, st);
+        if (fl == FL_LLAMA && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4>(a, st);
         if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
         if (fl == FL_SAM_ENC && nt == 4 && a.Sq <= 208) return launch_attn<128, 4, FL_SAM_ENC, 13, true>(a, st);   // 14 x 14 windows
         if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
-        static const bool two_pass = getenv("ULL_ATTN_TWO_PASS") != nullptr;     // A/B switch: the exact two-pass kernel
-        if (fl == FL_SAM_ENC && nt > 16 && !two_pass) {
+        if (fl == FL_SAM_ENC && nt > 16) {
             if (a.rel_mode == 1 && a.KW == KT && (a.Sk % KT) == 0) return launch_stream<128, FL_SAM_ENC, 1>(a, st);
             if (a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0) return launch_stream<128, FL_SAM_ENC, 2>(a, st);
             return launch_stream<128, FL_SAM_ENC, 0>(a, st);
         }
-        if (fl == FL_SAM_ENC && nt > 16) return launch_long<128, FL_SAM_ENC>(a, st);
     }
     if constexpr (HDP == 64) {
         if (fl == FL_CLIP && nt <= 5) return launch_attn<64, 5, FL_CLIP>(a, st);
-        static const bool w8c = getenv("ULL_ATTN_8WAVES") != nullptr;
-        if (fl == FL_CLIP && nt <= 11) return w8c ? launch_attn<64, 11, FL_CLIP, 8>(a, st) : launch_attn<64, 11, FL_CLIP, 4>(a, st);
+        if (fl == FL_CLIP && nt <= 11) return launch_attn<64, 11, FL_CLIP, 4>(a, st);
     }
     if constexpr (HDP == 32) {
         if (fl == FL_SAM_DEC && nt <= 5) return launch_attn<32, 5, FL_SAM_DEC>(a, st);

@@ -670,73 +670,75 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
 
 }  // namespace
 
-// Smallest K for which a partial last round of tiles is split along K (stream-K tail).  The split pays for itself when the GEMM has
-// the GPU to itself (C4: +5 %); when a second stream is filling the idle CUs anyway (RES forward: SAM encoder || LLaMA) it does not.
-static long g_streamk_min_k = getenv("ULL_GEMM_SK_MINK") ? atol(getenv("ULL_GEMM_SK_MINK")) : 2048;
-
-extern "C" int ull_gemm_set_streamk_min_k(int64_t min_k) {
-    if (min_k < 0) return ULL_ERR_ARG;
-    g_streamk_min_k = (long)min_k;
+// Per-device launch state (function attributes are per device; the CU count sizes the stream-K tail).  No allocation, no stream
+// state: the only scratch the GEMM needs -- the fp32 slabs of the stream-K tail -- is the caller's (`ws`), so two streams
+// never share anything.
+static int gemm_device_state(int* n_cu_out) {
+    constexpr int MAX_DEV = 64;
+    static int n_cu[MAX_DEV];            // 0 = not yet initialised
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return ULL_ERR_LAUNCH;
+    if (!n_cu[dev]) {
+        hipDeviceProp_t prop;
+        const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)patchify_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        n_cu[dev] = n;                   // last: a racing first call on another thread repeats the (idempotent) attribute calls
+    }
+    *n_cu_out = n_cu[dev];
     return ULL_OK;
 }
 
+extern "C" int64_t ull_gemm_streamk_ws_bytes(void) { return (int64_t)256 * big::BM * big::BN * sizeof(float); }
+
 extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
                              const void* bias, const void* R, int64_t ldr,
-                             int64_t M, int64_t N, int64_t K, int flags, void* stream) {
-    if (!X || !W || !C || M <= 0 || N <= 0 || K <= 0) return ULL_ERR_ARG;
+                             int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream) {
+    if (!X || !W || !C || M <= 0 || N <= 0 || K <= 0 || ws_bytes < 0) return ULL_ERR_ARG;
     if (K % BK != 0 || (ldx & 7) || (ldw & 7)) return ULL_ERR_SHAPE;          // 16-byte DMA pieces
     if ((flags & EPI_BIAS) && !bias) return ULL_ERR_ARG;
     if ((flags & EPI_RESID) && !R) return ULL_ERR_ARG;
     if ((flags & EPI_SWIGLU) && ((N & 31) || (flags & (EPI_BIAS | EPI_ACT_MASK)))) return ULL_ERR_SHAPE;
     if (M > (1 << 30) || N > (1 << 30)) return ULL_ERR_SHAPE;
+    int n_cu = 0;
+    if (const int rc = gemm_device_state(&n_cu)) return rc;
+    // per-call tuning overrides (tools/ only; 0 = the shipped policy)
+    const int tune_group_m = (flags >> 16) & 15;
+    const bool force_small = flags & (1 << 20);
+    flags &= 0xffff;
     GemmArgs a;
     a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.C = C;
     a.bias = (const bf16_t*)bias; a.R = (const bf16_t*)R;
     a.ldx = ldx; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags;
-    static bool attr_set = false;
-    static const bool force_small = getenv("ULL_GEMM_SMALL") != nullptr;
     // short K and fewer than two rounds of 256x256 tiles (ViT patchify: K = 640, 128 / 288 tiles): the 128x128 kernel's 4x finer
     // tiles fill the chip better (measured 61 vs 70 us at B=32, 336^2)
     const bool short_and_few = K <= 768 && ((M + 255) / 256) * ((N + 255) / 256) < 512 && !(flags & (EPI_W_TILED | EPI_X_TILED));
     if (!force_small && !short_and_few && M >= 1024 && N >= 512 && K >= 128) {   // nk >= 2
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
-
-        }
         a.nbm = (int)((M + big::BM - 1) / big::BM); a.nbn = (int)((N + big::BN - 1) / big::BN);
-        // stream-K tail: whole rounds of one tile per CU, the remainder split along K (needs >= 2 K-steps per slice)
-        static int n_cu = 0;
-        static float* ws = nullptr;
-        static const bool no_sk = getenv("ULL_GEMM_NO_STREAMK") != nullptr;
-        const long sk_min_k = g_streamk_min_k;
-        constexpr int MAX_SLABS = 256;
-        if (!n_cu) {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-            if (hipMalloc(&ws, (size_t)MAX_SLABS * big::BM * big::BN * sizeof(float)) != hipSuccess) ws = nullptr;   // 64 MiB, once
-        }
+        // stream-K tail: whole rounds of one tile per CU, the remainder split along K (needs >= 2 K-steps per slice) into fp32
+        // slabs in the CALLER's workspace (ws == NULL: no split; the caller owns the policy -- see ops.py -- and one workspace per
+        // stream keeps concurrent GEMMs on different streams independent)
+        constexpr long SLAB = (long)big::BM * big::BN * sizeof(float);
+        const int max_slabs = ws ? (int)(ws_bytes / SLAB < 4096 ? ws_bytes / SLAB : 4096) : 0;
         const int T = a.nbm * a.nbn;
         const int rem = T % n_cu;
         int sk = 1;
-        // (short K: the fp32 slab round trip + finalize launch cost more than the partial round they replace -- SAM's K = 1280
-        //  GEMMs measured 1.5 % slower end-to-end with the tail split)
-        if (!no_sk && ws && T > n_cu && rem > 0 && rem <= n_cu / 2 && K >= sk_min_k) {
+        if (max_slabs && T > n_cu && rem > 0 && rem <= n_cu / 2 && rem <= max_slabs) {
             sk = n_cu / rem;
             if (sk > 16) sk = 16;
             const int nk = (int)(K / big::BK);
             while (sk > 1 && nk / sk < 2) --sk;
-            if (rem * sk > MAX_SLABS) sk = MAX_SLABS / rem;
+            if (rem * sk > max_slabs) sk = max_slabs / rem;
         }
         a.sk = sk > 1 ? sk : 1;
         a.t_full = sk > 1 ? T - rem : T;
-        a.ws = ws;
+        a.ws = (float*)ws;
         // measured sweep at M=20576 (profiles/r01_gemm_notes.md): 4 M-tiles x 8 N-tiles per XCD wave beats 8 x 4 by ~5 %
-        static const int group_m = getenv("ULL_GEMM_GROUP_M") ? atoi(getenv("ULL_GEMM_GROUP_M")) : 4;
-        a.group_m = group_m;
+        a.group_m = tune_group_m ? tune_group_m : 4;
         const int grid = a.sk > 1 ? a.t_full + rem * a.sk : T;
         if (flags & EPI_SWIGLU)
             hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
@@ -747,11 +749,7 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
     }
     if (flags & (EPI_W_TILED | EPI_X_TILED)) return ULL_ERR_SHAPE;      // tile-major operands: 256x256 kernel only
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        attr_set = true;
-    }
+    a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
     if (flags & EPI_SWIGLU)
         hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
     else
@@ -779,11 +777,8 @@ extern "C" int ull_patchify_bf16(const void* img, int64_t n_img, int64_t C, int6
     a.M = (int)M; a.N = (int)N; a.K = (int)Kp; a.flags = bias ? EPI_BIAS : 0;
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)patchify_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        attr_set = true;
-    }
+    int n_cu = 0;
+    if (const int rc = gemm_device_state(&n_cu)) return rc;
     hipLaunchKernelGGL(patchify_gemm_kernel<0>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a, q);
     return ull_check_launch();
 }

@@ -97,6 +97,20 @@ ULL_DEV float act_quick_gelu_bf16(float t) {
 #define ULL_ERR_LAUNCH (-3)
 #define ULL_ERR_LDS (-4)
 
+// hipFuncSetAttribute is per device: one of these per kernel instantiation remembers which devices already have it
+// (a racing first call repeats an idempotent attribute call; nothing else is shared between host threads or streams).
+struct UllOncePerDevice {
+    unsigned long long seen = 0;
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        const unsigned long long bit = 1ull << dev;
+        if (seen & bit) return false;
+        seen |= bit;
+        return true;
+    }
+};
+
 static inline int ull_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ULL_OK : ULL_ERR_LAUNCH;

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
 // Per sample: count start/end tokens, first start position, running index into the feature batches.
 // spans[b] = {kind (0 text, 1 image, 2 video), first start pos, feature index, error flag}
 __global__ void mm_spans_kernel(const int64_t* __restrict__ ids, int B, int S, int img_start, int img_end, int vid_start, int vid_end,
-                                int32_t* __restrict__ spans) {
+                                long vocab, int32_t* __restrict__ spans) {
     // single block; thread b scans sample b, then an in-block prefix count assigns feature indices
     __shared__ int kind_s[1024];
     const int b = threadIdx.x;
@@ -76,8 +76,9 @@ __global__ void mm_spans_kernel(const int64_t* __restrict__ ids, int B, int S, i
             if (t == img_end) ++nie;
             if (t == vid_start) { if (pv < 0) pv = s; ++nvs; }
             if (t == vid_end) ++nve;
+            if (vocab > 0 && (t < 0 || t >= vocab)) err |= 2;   // nn.Embedding raises IndexError (ullava_core.py:191)
         }
-        if (nis != nie || nvs != nve) err = 1;     // reference asserts (ullava_core.py:209-211)
+        if (nis != nie || nvs != nve) err |= 1;    // reference asserts (ullava_core.py:209-211)
         if (nis > 0) { kind = 1; pos = pi; }
         else if (nvs > 0) { kind = 2; pos = pv; }
     }
@@ -98,14 +99,16 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __rest
                                                            const bf16_t* __restrict__ img_feat, int n_img_tok, int img_pitch, int img_off,
                                                            const bf16_t* __restrict__ vid_feat, int n_vid_tok,
                                                            const int32_t* __restrict__ spans, bf16_t* __restrict__ out, int S, int D,
-                                                           long rows) {
+                                                           long rows, long vocab) {
     const int cpr = D >> 3;                      // 16-byte chunks per row
     const int rows_per_block = 256 / min(cpr, 256);
     const int lanes_per_row = min(cpr, 256);
     const long row = (long)blockIdx.x * rows_per_block + threadIdx.x / lanes_per_row;
     if (row >= rows || (int)(threadIdx.x / lanes_per_row) >= rows_per_block) return;
     const int b = (int)(row / S), s = (int)(row % S);
-    const bf16_t* src = table + (long)ids[row] * D;
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);     // never read outside the table (ull_mm_spans reports such ids)
+    const bf16_t* src = table + id * D;
     if (spans != nullptr) {
         const int kind = spans[b * 4], pos = spans[b * 4 + 1], idx = spans[b * 4 + 2];
         if (kind == 1 && img_feat != nullptr && s > pos && s <= pos + n_img_tok) src = img_feat + ((long)idx * img_pitch + img_off + (s - pos - 1)) * D;
@@ -187,19 +190,19 @@ extern "C" int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_
 }
 
 extern "C" int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_start, int64_t img_end, int64_t vid_start, int64_t vid_end,
-                            void* spans, void* stream) {
+                            int64_t vocab, void* spans, void* stream) {
     if (!ids || !spans || B <= 0 || S <= 0) return ULL_ERR_ARG;
     if (B > 1024) return ULL_ERR_SHAPE;
     const int threads = (int)((B + 63) / 64) * 64;
     hipLaunchKernelGGL(mm_spans_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, (const int64_t*)ids, (int)B, (int)S, (int)img_start,
-                       (int)img_end, (int)vid_start, (int)vid_end, (int32_t*)spans);
+                       (int)img_end, (int)vid_start, (int)vid_end, (long)vocab, (int32_t*)spans);
     return ull_check_launch();
 }
 
 extern "C" int ull_embed_splice_bf16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch,
                                      int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B,
-                                     int64_t S, int64_t D, void* stream) {
-    if (!ids || !table || !out || B <= 0 || S <= 0) return ULL_ERR_ARG;
+                                     int64_t S, int64_t D, int64_t vocab, void* stream) {
+    if (!ids || !table || !out || B <= 0 || S <= 0 || vocab <= 0) return ULL_ERR_ARG;
     if (D & 7) return ULL_ERR_SHAPE;
     const long rows = B * S;
     const int cpr = (int)(D >> 3);
@@ -207,7 +210,7 @@ extern "C" int ull_embed_splice_bf16(const void* ids, const void* table, const v
     const unsigned blocks = (unsigned)((rows + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(embed_splice_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, (const bf16_t*)table,
                        (const bf16_t*)img_feat, (int)n_img_tok, (int)img_pitch, (int)img_off, (const bf16_t*)vid_feat, (int)n_vid_tok, (const int32_t*)spans,
-                       (bf16_t*)out, (int)S, (int)D, rows);
+                       (bf16_t*)out, (int)S, (int)D, rows, (long)vocab);
     return ull_check_launch();
 }
 

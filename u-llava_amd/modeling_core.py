@@ -344,14 +344,19 @@ class UllavaCoreForCausalLM(nn.Module):
             v = self.encode_video(videos)
             vid_feat = self._project(v.view(-1, v.shape[-1])).view(v.shape[0], v.shape[1], -1)
         spans = None
-        if mm is not None:
-            spans = ops.mm_spans(ids, mm["IMG_START"], mm["IMG_END"], mm["VID_START"], mm["VID_END"])
+        if mm is not None or self.strict_checks:
+            m_ = mm or {"IMG_START": -1, "IMG_END": -1, "VID_START": -1, "VID_END": -1}
+            spans = ops.mm_spans(ids, m_["IMG_START"], m_["IMG_END"], m_["VID_START"], m_["VID_END"], self.model.embed_tokens.weight.shape[0])
             if self.strict_checks:
                 sp = spans.cpu()
-                assert int(sp[:, 3].sum()) == 0, "Number of image/video start and end tokens should be the same."
+                if int((sp[:, 3] & 2).sum()):
+                    raise IndexError("index out of range in self")         # nn.Embedding on an out-of-vocabulary id
+                assert int((sp[:, 3] & 1).sum()) == 0, "Number of image/video start and end tokens should be the same."
                 if int((sp[:, 0] == 1).sum()) > (0 if img_feat is None else img_feat.shape[0]) or \
                         int((sp[:, 0] == 2).sum()) > (0 if vid_feat is None else vid_feat.shape[0]):
                     raise IndexError("fewer images/videos than samples that reference one")
+            if mm is None:
+                spans = None
         emb = ops.embed_splice(ids, self.model.embed_tokens.weight, img_feat, vid_feat, spans, img_tokens, img_pitch, img_off)
         return None, emb
 
@@ -449,8 +454,9 @@ class UllavaCoreForCausalLM(nn.Module):
         if labels is not None:
             loss = ops.shifted_cross_entropy(logits, labels)      # forward-only (no autograd on this path)
         if not return_dict:
-            out = (logits,) + ((all_h,) if all_h is not None else ())
-            return out
+            # reference :346-348: (loss,) + (logits,) + LlamaModel outputs[1:] = past_key_values / hidden_states when requested
+            out = (logits,) + ((cache,) if cache is not None else ()) + ((all_h,) if all_h is not None else ())
+            return ((loss,) + out) if loss is not None else out
         return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=all_h, attentions=None)
 
     __call__ = forward
@@ -474,36 +480,47 @@ class UllavaCoreForCausalLM(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids=None, images=None, videos=None, attention_mask=None, max_new_tokens=32, do_sample=False,
                  temperature=1.0, top_p=None, num_beams=1, no_repeat_ngram_size=None, stopping_criteria=None, eos_token_id=None,
-                 output_hidden_states=False, return_dict_in_generate=False, use_cache=None, keep_last_step_only=False, **kwargs):
-        """Token-by-token decoding.  use_cache=False reproduces the reference checkpoints' behaviour (config.use_cache=False:
-        every step re-runs the multimodal prefill); use_cache=True (config default) prefills once and then streams
-        the weights once per token through the GEMV kernels with a KV cache.  Greedy (`do_sample=False`) is deterministic;
-        sampling draws from torch's RNG on softmax(logits / temperature) with optional nucleus filtering."""
+                 pad_token_id=None, output_hidden_states=False, return_dict_in_generate=False, use_cache=None,
+                 keep_last_step_only=False, **kwargs):
+        """Token-by-token decoding with HF GenerationMixin's greedy / sampling semantics (the reference inherits `generate`):
+        every step goes through `prepare_inputs_for_generation` (position_ids = cumsum(attention_mask) - 1, so left-padded batches
+        get the reference's RoPE positions); `eos_token_id` defaults to `config.eos_token_id` (int or list); rows that have emitted
+        EOS are tracked per row, keep receiving `pad_token_id` (default: the EOS id, as HF does for open-ended generation) and the
+        loop ends when every row is finished or a stopping criterion fires.
+        use_cache=False reproduces the reference checkpoints' behaviour (config.use_cache=False: every step re-runs the multimodal
+        prefill); use_cache=True prefills once and then streams the weights once per token through the GEMV kernels
+        with a KV cache.  Greedy (`do_sample=False`) is deterministic; sampling draws from torch's RNG on
+        softmax(logits / temperature) with optional nucleus filtering."""
         if num_beams != 1:
             raise NotImplementedError("beam search is not used by the reference callers (num_beams=1)")
         use_cache = self.config.use_cache if use_cache is None else use_cache
         seq = input_ids
+        B = seq.shape[0]
+        eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
+        eos_ids = None
+        if eos is not None:
+            eos_ids = torch.as_tensor([eos] if isinstance(eos, int) else list(eos), device=seq.device, dtype=seq.dtype)
+        pad = pad_token_id if pad_token_id is not None else getattr(self.config, "pad_token_id", None)
+        if pad is None and eos_ids is not None:
+            pad = int(eos_ids[0])
+        unfinished = torch.ones(B, dtype=torch.bool, device=seq.device)
         steps_hidden = []
-        eos = eos_token_id
         cache = None
         self._cache_headroom = max_new_tokens + 1
         for step in range(max_new_tokens):
             mask = torch.ones_like(seq) if attention_mask is None else torch.cat(
-                [attention_mask, attention_mask.new_ones(seq.shape[0], seq.shape[1] - attention_mask.shape[1])], dim=1)
+                [attention_mask, attention_mask.new_ones(B, seq.shape[1] - attention_mask.shape[1])], dim=1)
+            inputs = self.prepare_inputs_for_generation(input_ids=seq, attention_mask=mask, images=images, videos=videos,
+                                                        past_key_values=cache if use_cache else None, use_cache=use_cache)
             if use_cache:
                 # KV-cached decoding (SURVEY 8(f) row 1): prefill once, then one token per step; vision runs once
-                if step == 0:
-                    out = self.forward(input_ids=seq, attention_mask=mask, images=images, videos=videos, use_cache=True)
-                else:
-                    out = self.forward(input_ids=seq[:, -1:], attention_mask=mask, past_key_values=cache, use_cache=True)
+                if step > 0:
+                    inputs["images"] = inputs["videos"] = None
+                out = self.forward(**inputs)
                 cache = out.past_key_values
-                if output_hidden_states:
-                    # same tensor the no-cache path returns at this step: last-layer states of ALL positions so far
-                    steps_hidden = [(torch.cat(cache.last_hidden, dim=1),)]
             else:
                 # the reference's released checkpoints run with use_cache=False: every step re-runs the multimodal prefill
-                out = self.forward(input_ids=seq, attention_mask=mask, images=images, videos=videos,
-                                   output_hidden_states=output_hidden_states)
+                out = self.forward(**inputs, output_hidden_states=output_hidden_states)
                 if output_hidden_states:
                     if keep_last_step_only:
                         steps_hidden = [out.hidden_states]      # evaluate() only reads hidden_states[-1] (the last step)
@@ -521,13 +538,20 @@ class UllavaCoreForCausalLM(nn.Module):
                 nxt = torch.multinomial(probs, 1)
             else:
                 nxt = logits.argmax(-1, keepdim=True)
+            if pad is not None:
+                nxt = torch.where(unfinished.unsqueeze(1), nxt, torch.full_like(nxt, pad))      # finished rows: pad fill
             seq = torch.cat([seq, nxt], dim=1)
-            if eos is not None and bool((nxt == eos).all()):
-                break
+            if eos_ids is not None:
+                unfinished = unfinished & ~torch.isin(nxt.squeeze(1), eos_ids)
+                if not bool(unfinished.any()):
+                    break
             if stopping_criteria is not None:
                 crit = stopping_criteria if isinstance(stopping_criteria, (list, tuple)) else [stopping_criteria]
-                if any(bool(c(seq, None)) for c in crit):
+                if any(bool(torch.as_tensor(c(seq, None)).all()) for c in crit):
                     break
+        if output_hidden_states and use_cache and cache is not None:
+            # same tensor the no-cache path returns at its last step: last-layer states of ALL positions fed so far, joined once
+            steps_hidden = [(torch.cat(cache.last_hidden, dim=1),)]
         if return_dict_in_generate:
             return GenerateOutput(sequences=seq, hidden_states=tuple(steps_hidden) if output_hidden_states else None)
         return seq

@@ -18,8 +18,6 @@ from .modeling_core import BF16, Linear, UllavaCoreForCausalLM, _Holder
 from .sam import SamEngine, build_sam_holder
 
 
-_SINGLE_STREAM = bool(__import__("os").environ.get("ULL_SINGLE_STREAM"))     # A/B switch: SAM encoder on the main stream
-
 
 def _mlp_seq(dims, device, dtype, dropout_tail=False):
     """nn.Sequential(Linear, ReLU, Linear, ...) with the reference's child indices (ReLU / Dropout hold no parameters)."""
@@ -47,6 +45,7 @@ class UllavaForCausalLM(nn.Module):
         self.det_projector = _mlp_seq([D, D, O], device, dtype, dropout_tail=True)            # ullava.py:86-91
         self.det_decoder = _mlp_seq([O, O, O // 2, 4], device, dtype)                         # ullava.py:96-102
         self._sam = SamEngine(self.visual_model, config.sam_config)
+        self.overlap_sam_encoder = True     # SAM image encoder on a second HIP stream beside CLIP + LLaMA (False: same stream)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=None, device=None, **kwargs):
@@ -68,12 +67,12 @@ class UllavaForCausalLM(nn.Module):
     def load_visual_checkpoint(self, checkpoint):
         """reference ullava.py:134-137."""
         with open(checkpoint, "rb") as f:
-            sd = torch.load(f, map_location="cpu")
+            sd = torch.load(f, map_location="cpu", weights_only=True)      # a plain tensor state-dict (sam_vit_h_4b8939.pth)
         self._sam.invalidate()
         return self.visual_model.load_state_dict(sd, strict=False)
 
     def _side_stream(self):
-        if _SINGLE_STREAM:
+        if not self.overlap_sam_encoder:
             return torch.cuda.current_stream()
         st = getattr(self, "_side", None)
         if st is None:
@@ -139,25 +138,23 @@ class UllavaForCausalLM(nn.Module):
         on this path yet)."""
         B = input_ids.shape[0]
         # the SAM image encoder does not depend on the LLM: it runs on a second HIP stream and fills the gaps (tile-quantisation
-        # tails, small kernels, launch latency) of the CLIP + LLaMA stream; joined before the mask decoder
+        # tails, small kernels, launch latency) of the CLIP + LLaMA stream; joined before the mask decoder.  Each stream has its own
+        # stream-K workspace (ops._streamk_ws); while both are busy the K-split of partial tile rounds is limited to K >= 8192 because the
+        # CUs it would fill are not idle (policy only -- correctness does not depend on it).
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
-        overlap = side is not main
-        if overlap:
-            ops.set_gemm_streamk_min_k(8192)                        # no K-split of partial tile rounds while the streams overlap
-        with torch.cuda.stream(side):
-            image_embeddings = self._visual_embs_tm(images_sam)
-        pad = torch.zeros((B, 1), dtype=torch.bool, device=input_ids.device)
-        seg_token_mask = torch.cat([input_ids[:, 1:] == self.config.seg_token_idx, pad], dim=1)    # row t selected iff ids[t+1]==[SEG]
-        loc_token_mask = torch.cat([input_ids[:, 1:] == self.config.loc_token_idx, pad], dim=1)
-        output = self.llm.forward(images=images, attention_mask=attention_mask, input_ids=input_ids, labels=labels,
-                                  output_hidden_states=True)
+        with ops.streamk_policy(8192 if side is not main else 2048):
+            with torch.cuda.stream(side):
+                image_embeddings = self._visual_embs_tm(images_sam)
+            pad = torch.zeros((B, 1), dtype=torch.bool, device=input_ids.device)
+            seg_token_mask = torch.cat([input_ids[:, 1:] == self.config.seg_token_idx, pad], dim=1)    # row t selected iff ids[t+1]==[SEG]
+            loc_token_mask = torch.cat([input_ids[:, 1:] == self.config.loc_token_idx, pad], dim=1)
+            output = self.llm.forward(images=images, attention_mask=attention_mask, input_ids=input_ids, labels=labels,
+                                      output_hidden_states=True)
         last = output.hidden_states[-1]
         main.wait_stream(side)
         image_embeddings.record_stream(main)
-        if overlap:
-            ops.set_gemm_streamk_min_k(2048)
         pred_embeddings = self._select(last, seg_token_mask, self.seg_projector)
         pred_loc_embeddings = self._select(last, loc_token_mask, self.det_projector)
         pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, size_list)
@@ -223,7 +220,7 @@ class UllavaForCausalLM(nn.Module):
         side = self._side_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            image_embeddings = self._visual_embs_tm(images_sam)
+            image_embeddings = self._visual_embs_tm(images_sam)     # its GEMMs use the side stream's own stream-K workspace
         outputs = self.llm.generate(input_ids=input_ids, images=images, max_new_tokens=max_new_tokens, num_beams=num_beams, top_p=top_p,
                                     do_sample=True if temperature > 0 else False, temperature=temperature, output_hidden_states=True,
                                     return_dict_in_generate=True, no_repeat_ngram_size=no_repeat_ngram_size,

@@ -61,7 +61,6 @@ def _rows(t: torch.Tensor):
 
 
 EPI_W_TILED = 64
-_NO_TILED = bool(__import__("os").environ.get("ULL_NO_TILED"))
 _TILED = {}          # data_ptr of a row-major weight -> (weakref to it, its tile-major copy)
 
 
@@ -84,8 +83,6 @@ def register_tiled(w: torch.Tensor) -> None:
 
 
 def _tiled_of(w: torch.Tensor):
-    if _NO_TILED:
-        return None
     e = _TILED.get(w.data_ptr())
     if e is None:
         return None
@@ -95,11 +92,47 @@ def _tiled_of(w: torch.Tensor):
     return e[1]
 
 
+# ---- stream-K workspace: one fp32 scratch buffer per (device, stream) ---------------------------------------------------
+# ull_gemm_bf16 splits a partial last round of 256x256 tiles along K into fp32 slabs in a CALLER-owned workspace.  Each HIP
+# stream gets its own buffer here, so GEMMs running concurrently on two streams (RES forward / evaluate: SAM encoder beside
+# CLIP + LLaMA) never share scratch.  Whether to split at all is host policy: K >= streamk_min_k (default 2048: below that the
+# slab round trip costs more than the partial round it replaces); `streamk_policy(None)` turns the split off, which the model
+# does while a second stream is filling the idle CUs of a partial round anyway.
+_SK_WS = {}
+_SK_MIN_K = [2048]
+
+
+def _streamk_ws(device: torch.device, stream_id: int):
+    key = (device.index, stream_id)
+    ws = _SK_WS.get(key)
+    if ws is None:
+        with torch.cuda.device(device):
+            ws = _SK_WS[key] = torch.empty(_lib.query("ull_gemm_streamk_ws_bytes"), device=device, dtype=torch.uint8)
+    return ws
+
+
+class streamk_policy:
+    """with streamk_policy(min_k): ... -- K threshold of the stream-K tail inside the block (None = never split)."""
+
+    def __init__(self, min_k: Optional[int]):
+        self.min_k = min_k
+
+    def __enter__(self):
+        self.prev = _SK_MIN_K[0]
+        _SK_MIN_K[0] = self.min_k
+        return self
+
+    def __exit__(self, *exc):
+        _SK_MIN_K[0] = self.prev
+        return False
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
            residual: Optional[torch.Tensor] = None, swiglu: bool = False, out: Optional[torch.Tensor] = None,
-           out_f32: bool = False, rms_w: Optional[torch.Tensor] = None, rms_eps: float = 0.0) -> torch.Tensor:
+           out_f32: bool = False, rms_w: Optional[torch.Tensor] = None, rms_eps: float = 0.0, tune: int = 0) -> torch.Tensor:
     """y = epilogue(x @ w.T).  x [..., K]; w [N, K] (nn.Linear layout).  swiglu: w is the 16-row interleaved gate/up pack.
-    rms_w/rms_eps: apply LlamaRMSNorm to x first (fused into the GEMV prologue at decode shapes, a separate kernel otherwise)."""
+    rms_w/rms_eps: apply LlamaRMSNorm to x first (fused into the GEMV prologue at decode shapes, a separate kernel otherwise).
+    tune: ULL_GEMM_TUNE_* bits (tools/ only)."""
     _chk(x, "x"); _chk(w, "w")
     M, ldx = _rows(x)
     N, K = w.shape
@@ -146,17 +179,21 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         _chk(residual, "residual")
         _, ldr = _rows(residual)
     _, ldc = _rows(out)
-    wt = _tiled_of(w) if (M >= 1024 and N >= 512 and K >= 128) else None
+    big = M >= 1024 and N >= 512 and K >= 128
+    wt = _tiled_of(w) if big else None
+    st = _stream()
+    ws_ptr, ws_bytes = None, 0
+    min_k = _SK_MIN_K[0]
+    if big and min_k is not None and K >= min_k:
+        ws = _streamk_ws(x.device, st)
+        ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
     if wt is not None:
-        _lib.call("ull_gemm_bf16", _p(x), ldx, _p(wt), K, _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags | EPI_W_TILED, _stream())
+        _lib.call("ull_gemm_bf16", _p(x), ldx, _p(wt), K, _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags | EPI_W_TILED | tune,
+                  ws_ptr, ws_bytes, st)
     else:
-        _lib.call("ull_gemm_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags, _stream())
+        _lib.call("ull_gemm_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags | tune,
+                  ws_ptr, ws_bytes, st)
     return out
-
-
-def set_gemm_streamk_min_k(min_k: int) -> None:
-    """see ull_gemm_set_streamk_min_k: 2048 by default; raised while two streams share the GPU."""
-    _lib.call("ull_gemm_set_streamk_min_k", int(min_k))
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -274,11 +311,12 @@ def patchify(img: torch.Tensor, wp: torch.Tensor, ps: int, bias: Optional[torch.
     return out
 
 
-def mm_spans(ids: torch.Tensor, img_start: int, img_end: int, vid_start: int, vid_end: int) -> torch.Tensor:
+def mm_spans(ids: torch.Tensor, img_start: int, img_end: int, vid_start: int, vid_end: int, vocab: int = 0) -> torch.Tensor:
+    """int32 [B, 4] = {kind, first start pos, feature index, error bits (1: start/end counts differ, 2: id outside [0, vocab))}."""
     _chk(ids, "input_ids", torch.int64)
     B, S = ids.shape
     spans = torch.empty(B, 4, device=ids.device, dtype=torch.int32)
-    _lib.call("ull_mm_spans", _p(ids), B, S, img_start, img_end, vid_start, vid_end, _p(spans), _stream())
+    _lib.call("ull_mm_spans", _p(ids), B, S, img_start, img_end, vid_start, vid_end, vocab, _p(spans), _stream())
     return spans
 
 
@@ -298,7 +336,7 @@ def embed_splice(ids: torch.Tensor, table: torch.Tensor, img_feat: Optional[torc
         _chk(vid_feat, "vid_feat")
         n_vid = vid_feat.shape[-2]
     _lib.call("ull_embed_splice_bf16", _p(ids), _p(table), _p(img_feat), img_tokens, img_pitch, img_off, _p(vid_feat), n_vid, _p(spans),
-              _p(out), B, S, D, _stream())
+              _p(out), B, S, D, table.shape[0], _stream())
     return out
 
 

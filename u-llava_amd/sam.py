@@ -109,9 +109,6 @@ def build_sam_holder(cfg: SamConfig, device=None, dtype=BF16) -> nn.Module:
     return sam
 
 
-_GLOBAL_TABLES = bool(__import__("os").environ.get("ULL_SAM_GLOBAL_TABLES"))     # A/B switch: rel-pos tables from relpos_kernel
-
-
 class SamEngine:
     """Runs the SAM sub-models of a `build_sam_holder` tree on the HIP path (weights re-laid out once)."""
 
@@ -181,7 +178,7 @@ class SamEngine:
             strides = (S * 3 * C, hd, 3 * C)
             vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
             att = torch.empty(NB * S, C, device=x.device, dtype=BF16)
-            if glob and (side != 64 or _GLOBAL_TABLES):
+            if glob and side != 64:
                 # other grid sizes: per-query bias tables from their own kernel, looked up by the attention kernel
                 rel_h, rel_w = ops.sam_relpos(qkv, strides, blk.attn.rel_pos_h, blk.attn.rel_pos_w, NB, nH, side, side, hd)
                 ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
