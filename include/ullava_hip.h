@@ -1,5 +1,9 @@
 /* ullava_hip.h -- C ABI of libullava_hip.so, the MI355X (gfx950) kernels of the u-LLaVA forward path.
  *
+ * Element types: the functions named *_bf16 below take bfloat16 tensors (the reference's configured dtype, configs/train/ullava.yaml
+ * bf16: true); each has a twin *_f16 for IEEE binary16 (declared at the end of this file).  Byte / fp32 work with mixed dtypes takes
+ * a dtype code: ULL_DT_F32 / ULL_DT_BF16 / ULL_DT_F16.
+ *
  * The reference (OPPOMKLab/u-LLaVA) has no FFI: its hot path is PyTorch nn.Modules calling ATen.  Each entry
  * point below replaces the ATen calls of the reference lines it cites (paths relative to the reference repo;
  * "hf:" = transformers, the reference's pinned third-party dependency, cited from v5.15.0).
@@ -15,6 +19,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define ULL_DT_F32 0
+#define ULL_DT_BF16 1
+#define ULL_DT_F16 2
 
 #define ULL_OK 0
 #define ULL_ERR_ARG (-1)    /* null pointer / non-positive size */
@@ -162,8 +170,9 @@ int ull_im2col3x3_bf16(const void* x, void* out, int64_t B, int64_t H, int64_t W
  * ConvTranspose2d(k=2,s=2) GEMMs: [n][G*G cells][d1][d2][C].  masks bf16 [n,T,4G,4G]. */
 int ull_mask_matmul_bf16(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
 
-/* sam.py:137-172 postprocess_masks: F.interpolate(bilinear, align_corners=False) in fp32 of n images (bf16 or fp32, strided crop). */
-int ull_bilinear_f32(const void* in, int in_is_bf16, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w, void* out,
+/* sam.py:137-172 postprocess_masks: F.interpolate(bilinear, align_corners=False) in fp32 of n images of dtype in_dtype (ULL_DT_*;
+ * strided crop). */
+int ull_bilinear_f32(const void* in, int in_dtype, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w, void* out,
                      int64_t n, int64_t out_h, int64_t out_w, void* stream);
 
 /* Fused ViT patch embedding: Conv2d(C, N, kernel = stride = ps) as one GEMM whose A tiles are LDS-DMA'd straight from the pixels
@@ -184,11 +193,11 @@ int ull_patchify_bf16(const void* img, int64_t n_img, int64_t C, int64_t H, int6
 int ull_resample_u8(const void* src, int64_t H, int64_t W, int64_t C, int axis, int64_t out_size, const void* bounds, const void* coeffs,
                     int64_t ksize, void* dst, void* stream);
 
-/* uint8 [H, W, 3] -> fp32 / bf16 [3, OH, OW]: dst[c][y][x] = lut[c][src[top+y][left+x][c]] for y < copy_h, x < copy_w, else 0.
+/* uint8 [H, W, 3] -> [3, OH, OW] of dtype out_dtype (ULL_DT_*): dst[c][y][x] = lut[c][src[top+y][left+x][c]] for y < copy_h, x < copy_w, else 0.
  * lut fp32 [3, 256] holds the reference's normalisation of every byte value.  CLIP: center crop + /255 + (x-mean)/std
  * (transformers rescale + normalize); SAM: (x-mean)/std + zero pad to 1024 (dataset/tools/mask_toolbox.py:15-25). */
 int ull_u8_lut_chw(const void* src, int64_t H, int64_t W, int64_t C, int64_t top, int64_t left, const void* lut, void* dst, int64_t OH,
-                   int64_t OW, int64_t copy_h, int64_t copy_w, int out_bf16, void* stream);
+                   int64_t OW, int64_t copy_h, int64_t copy_w, int out_dtype, void* stream);
 
 /* evaluation/tools.py:29-41 intersectionAndUnionGPU(K = 2) on (logits > 0) (trainers/ullava_trainer.py:44): logits fp32
  * [n, hw], target uint8 [n, hw]; counts int32 [n, 6] += {inter0, inter1, out0, out1, tgt0, tgt1}, ignore_index pixels dropped. */
@@ -201,8 +210,37 @@ int ull_mask_iou_counts(const void* logits, const void* target, int64_t n_masks,
 int ull_mask_loss_sums_f32(const void* logits, const void* target, int64_t n_masks, int64_t hw, float scale, void* part, void* stream);
 
 /* bbox_l1_loss / bbox_giou_loss numerators (loss.py:92-110): out float[2] = {sum |pred - gt|, sum (1 - GIoU(pred_i, gt_i)) over
- * predictions with x1 >= x0 and y1 >= y0}.  pred [n,4] bf16 or fp32, gt [n,4] fp32, xyxy. */
-int ull_box_losses_f32(const void* pred, int pred_is_bf16, const void* gt, int64_t n, void* out, void* stream);
+ * predictions with x1 >= x0 and y1 >= y0}.  pred [n,4] of dtype pred_dtype (ULL_DT_*), gt [n,4] fp32, xyxy. */
+int ull_box_losses_f32(const void* pred, int pred_dtype, const void* gt, int64_t n, void* out, void* stream);
+
+/* ==== BEGIN fp16 twins (generated by tools/gen_header_f16.py) ==== */
+/* IEEE binary16 build of every dtype-dependent entry point: same arguments, layouts, flags and rounding points as the *_bf16
+ * function of the same name; every 16-bit element is an fp16 instead of a bf16 (the reference's `--dtype fp16`,
+ * inference_ullava.py:26,164-168).  Both builds live in the same library; the host picks by tensor dtype. */
+int ull_gemm_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream);
+int ull_gemv_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+int ull_gemv_rmsnorm_f16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+int ull_rmsnorm_f16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+int ull_shifted_cross_entropy_f16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, void* out, void* stream);
+int ull_layernorm_f16(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+int ull_clip_embed_ln_f16(const void* patch, int64_t ldp, const void* cls, const void* pos, const void* w, const void* b, void* y, int64_t ldy, int64_t n_img, int64_t tokens, int64_t D, float eps, void* stream);
+int ull_attention_f16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs, int64_t k_ss, const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O, int64_t o_bs, int64_t o_hs, int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, float q_scale, const void* rel_h, const void* rel_w, int64_t rel_kh, int64_t rel_kw, int rel_mode, const void* zeros, void* stream);
+int ull_rope_inplace_f16(void* x, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads, int64_t hd, void* stream);
+int ull_rope_append_f16(void* qkv, int64_t row_stride, const void* positions, const void* inv_freq, int64_t B, int64_t S, int64_t H, int64_t hd, void* k_cache, void* vt_cache, int64_t smax, int64_t past, void* stream);
+int ull_transpose_v_f16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch, void* stream);
+int ull_im2col_f16(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp, void* stream);
+int ull_embed_splice_f16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
+int ull_video_pool_f16(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch, int64_t tok_off, void* stream);
+int ull_gather_rows_f16(const void* src, int64_t lds, const void* idx, void* dst, int64_t ldd, int64_t n, int64_t D, void* stream);
+int ull_add_rows_f16(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream);
+int ull_window_partition_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
+int ull_window_unpartition_add_f16(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
+int ull_sam_relpos_f16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w, void* out_h, void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
+int ull_layernorm2d_cl_f16(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu, void* stream);
+int ull_im2col3x3_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+int ull_mask_matmul_f16(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
+int ull_patchify_f16(const void* img, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, const void* Wp, int64_t Kp, const void* bias, void* out, int64_t ldc, int64_t N, const void* zeros, void* stream);
+/* ==== END fp16 twins ==== */
 
 #ifdef __cplusplus
 }

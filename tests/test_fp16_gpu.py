@@ -1,0 +1,222 @@
+"""GPU parity of the IEEE-binary16 build (ull_*_f16): the reference's `--dtype fp16` (inference_ullava.py:26,164-168).
+
+north_star's stated floating-point bar is "mask logits within 1e-3 fp16": the SAM prompt-encoder -> MaskDecoder -> postprocess
+chain is run in fp16 against the committed REFERENCE fp16 fixtures (G7 at full decoder dims, n = 1 / 3 / 10 prompts; G8 the full
+UllavaForCausalLM.forward with a shrunk SAM encoder) and the assert is |d mask logit| <= 1e-3 * max|logit|, directly HIP vs
+reference.  The kernel-level tests use the same oracle ops as the bf16 tests with fp16 tensors; one fp16 ulp is 2^-11..2^-10
+relative."""
+import math
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import pkg, load_fixture, fixture_sd, rel_err
+from oracle import ullava_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H = torch.float16
+RESULTS = []
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_results():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_fp16.json"), "w") as f:
+        json.dump(RESULTS, f, indent=1)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(H)
+
+
+def assert_close_f16(a, b, ulps=2.0, floor=None, what=""):
+    """|a-b| <= ulps * 2^-10 * max(|b|, floor); floor defaults to 2 % of max|b|."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    fl = float(b.abs().max()) * 0.02 if floor is None else floor
+    tol = ulps * 2.0 ** -10 * torch.maximum(b.abs(), torch.full_like(b, fl))
+    bad = (a - b).abs() > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} off; max|d|={float((a - b).abs().max()):.4g} max|ref|={float(b.abs().max()):.4g}"
+
+
+def _mm_ref(x, w):
+    return (x.float() @ w.float().t()).to(H)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (77, 100, 192), (515, 1280, 1024), (1029, 4096, 2048), (256 * 9, 256 * 32, 2048), (3, 520, 1088)])
+def test_gemm_fp16(M, N, K):
+    """128x128 kernel, 256x256 kernel (incl. the stream-K tail) and the decode GEMV in the fp16 build."""
+    ops = pkg("ops")
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    y = ops.linear(x.to(DEV), w.to(DEV))
+    assert y.dtype == H
+    assert_close_f16(y, _mm_ref(x, w), what=f"fp16 gemm {M}x{N}x{K}")
+
+
+def test_gemm_fp16_epilogues_and_swiglu():
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    M, N, K = 300, 384, 256
+    x, w, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5), _rand(N, seed=5), _rand(M, N, seed=6)
+    t = F.linear(x.float(), w.float(), b.float()).to(H)
+    for act, fn in (("gelu", F.gelu), ("relu", F.relu), ("quick_gelu", lambda v: v * torch.sigmoid(1.702 * v))):
+        assert_close_f16(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=act), fn(t), what=act)
+    assert_close_f16(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=r.to(DEV)), r + t, what="bias+residual")
+    wg, wu = _rand(N // 2, K, seed=7, scale=K ** -0.5), _rand(N // 2, K, seed=8, scale=K ** -0.5)
+    y = ops.linear(x.to(DEV), M_.interleave_gate_up(wg, wu).to(DEV), swiglu=True)
+    assert_close_f16(y, F.silu(_mm_ref(x, wg)) * _mm_ref(x, wu), what="swiglu")
+    with pytest.raises(RuntimeError, match="must be torch.float16"):
+        ops.linear(x.to(DEV), w.to(DEV).to(torch.bfloat16))           # no mixed-dtype kernels
+
+
+def test_norms_rope_fp16():
+    ops = pkg("ops")
+    x, w, b = _rand(37, 4096, seed=9, scale=2.0), _rand(4096, seed=10) * 0.1 + 1.0, _rand(4096, seed=11) * 0.1
+    assert_close_f16(ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6), O.rms_norm(x, w, 1e-6), what="rmsnorm")
+    assert_close_f16(ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5), F.layer_norm(x, (4096,), w, b, 1e-5), what="layernorm")
+    Hn, hd, T = 4, 128, 50
+    qk = _rand(T, 2 * Hn * hd, seed=12)
+    pos = torch.arange(T).unsqueeze(0)
+    cos, sin = O.rope_tables(pos, hd, 10000.0, H)
+    q = qk[:, :Hn * hd].view(1, T, Hn, hd).transpose(1, 2)
+    k = qk[:, Hn * hd:].view(1, T, Hn, hd).transpose(1, 2)
+    rq, rk = O.apply_rope(q, k, cos, sin)
+    buf = qk.clone().to(DEV)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(DEV)
+    ops.rope_inplace(buf, 2 * Hn * hd, pos[0].to(DEV), inv, T, 2 * Hn, hd)
+    got = buf.cpu()
+    assert_close_f16(got[:, :Hn * hd].view(T, Hn, hd), rq[0].transpose(0, 1), ulps=1.0, what="rope q")
+    assert_close_f16(got[:, Hn * hd:].view(T, Hn, hd), rk[0].transpose(0, 1), ulps=1.0, what="rope k")
+
+
+@pytest.mark.parametrize("Sq,Sk,hd,causal", [(6, 4096, 16, False), (4096, 6, 16, False), (200, 200, 64, False), (300, 300, 128, True)])
+def test_attention_fp16(Sq, Sk, hd, causal):
+    """few-query, register and causal attention kernels in fp16 vs the eager recipe (scores fp16, softmax fp32 -> fp16, P*V)."""
+    ops = pkg("ops")
+    n, Hn = 2, 8 if hd <= 32 else 2
+    Di = Hn * hd
+    q, k, v = _rand(n * Sq, Di, seed=11), _rand(n * Sk, Di, seed=12), _rand(n * Sk, Di, seed=13)
+    qh, kh, vh = (t.view(n, -1, Hn, hd).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2)
+    if hd <= 32:
+        s = s / math.sqrt(hd)
+        mode, scale = 2, math.sqrt(hd)
+    else:
+        s = s * hd ** -0.5
+        mode, scale = 1, hd ** -0.5
+    if causal:
+        s = s + torch.full((Sq, Sk), torch.finfo(H).min, dtype=H).triu(1)
+    a = torch.softmax(s, dim=-1, dtype=torch.float32).to(H)
+    ref = (a @ vh).transpose(1, 2).reshape(n * Sq, Di)
+    vt = ops.transpose_v(v.to(DEV), Sk * Di, Di, n, Sk, Hn, hd)
+    out = torch.empty(n * Sq, Di, device=DEV, dtype=H)
+    ops.attention(q.to(DEV), k.to(DEV), vt, out, n, Hn, Sq, Sk, hd, (Sq * Di, hd, Di), (Sk * Di, hd, Di), (Sq * Di, hd, Di), None,
+                  causal=causal, scale_mode=mode, scale=scale)
+    # P is rounded to fp16 in both; a flipped rounding of a dominant probability moves the output by 2^-11 * max|v|
+    vmax = float(v.float().abs().max())
+    assert_close_f16(out, ref, ulps=2.0, floor=vmax * 0.5, what=f"fp16 attention {Sq}x{Sk}")
+
+
+def _decoder_engine(fx):
+    C, S = pkg("configuration"), pkg("sam")
+    cfg = C.SamConfig(depth=0)
+    holder = S.build_sam_holder(cfg, device=DEV, dtype=H)
+    sd = {k[len("visual_model."):]: v for k, v in fixture_sd(fx, H).items()}
+    missing = holder.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    return S.SamEngine(holder, cfg), fixture_sd(fx, H)
+
+
+def test_mask_decoder_fp16_fixture_g7_within_1e3():
+    """north_star: mask logits within 1e-3 (fp16) -- HIP fp16 vs the REFERENCE's fp16 run, full decoder dims, n = 1, 3, 10."""
+    fx = load_fixture("g7_sam_decoder_fp16.pt")
+    assert fx["dtype"] == "torch.float16"
+    eng, sd = _decoder_engine(fx)
+    pe = eng.dense_pe().cpu()
+    ref_pe = O.dense_pe(sd, (64, 64))[0].permute(1, 2, 0).reshape(4096, 256)
+    assert pe.dtype == H and torch.equal(pe, ref_pe), "dense PE must be bit-exact (constant folded with the reference's fp16 recipe)"
+    g = torch.Generator().manual_seed(fx["image_embedding_seed"])
+    emb = torch.randn(1, 256, 64, 64, generator=g).to(H)
+    emb_tm = emb[0].permute(1, 2, 0).reshape(4096, 256).contiguous().to(DEV)
+    for case in fx["cases"]:
+        masks, iou = eng.decode(emb_tm, case["text_embeds"][:, 0].to(DEV))
+        assert masks.dtype == H
+        st = case["low_res_stride"]
+        low = masks[:, 0:1, ::st, ::st].float().cpu()
+        ref_low = case["low_res_masks"].float()
+        d = (low - ref_low).abs()
+        e = float(d.max()) / case["low_res_max"]
+        e_iou = rel_err(iou[:, 0:1], case["iou"])
+        print(f"fp16 n={case['n']}: max|dlogit| / max|logit| = {e:.2e} (mean {float(d.mean()) / case['low_res_max']:.2e}); iou err {e_iou:.2e}")
+        RESULTS.append(dict(test="g7_fp16", n=case["n"], max_dlogit_over_max_logit=e, mean=float(d.mean()) / case["low_res_max"], iou=e_iou))
+        assert e <= 1e-3, f"mask logits differ from the reference fp16 run by {e:.2e} of max|logit| (bar: 1e-3)"
+        assert e_iou <= 2e-3
+        post = eng.postprocess(masks[:, 0].contiguous(), (768, 1024), (480, 640)).cpu()
+        assert post.dtype == torch.float32
+        ep = float((post[:, ::8, ::8] - case["post_sample"][:, 0]).abs().max()) / case["low_res_max"]
+        assert ep <= 1e-3, ep
+
+
+def test_full_forward_fp16_fixture_g8():
+    """UllavaForCausalLM.forward(inference=True) in fp16 (tiny LLM + shrunk SAM encoder) vs the reference's fp16 run."""
+    fx = load_fixture("g8_full_tiny_fp16.pt")
+    C, M = pkg("configuration"), pkg("modeling_ullava")
+    cfg, cd = fx["cfg"], fx["cfg"]["llm"]
+    ucfg = C.UllavaConfig(llm_config=dict(vision_config=cd["vision_config"], vision_hidden_layer=cd["vision_hidden_layer"],
+                                          projector_type="mlp", mm_token_ids=cd["mm_token_ids"], vocab_size=cd["vocab_size"],
+                                          hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
+                                          num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"]),
+                            seg_token_idx=cfg["seg_token_idx"], loc_token_idx=cfg["loc_token_idx"], sam_config=dict(cfg["sam"]))
+    model = M.UllavaForCausalLM(ucfg, device=DEV, dtype=H)
+    model.load_state_dict(fixture_sd(fx, H), strict=True)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(H)
+    out = model(images_sam=images_sam.to(DEV), images=fx["images"].to(DEV), input_ids=fx["input_ids"].to(DEV), labels=None,
+                attention_mask=fx["attention_mask"].to(DEV), mask_list=[None, None], size_list=fx["size_list"],
+                resize_list=fx["resize_list"], bbox_list=[None, None], inference=True)
+    assert out["logits"].dtype == H
+    valid = fx["attention_mask"].bool()
+    el = rel_err(out["logits"].cpu()[valid], fx["logits"][valid])
+    print("fp16 logits err vs reference", el)
+    assert el < 4e-3
+    assert [m.shape[0] for m in out["pred_masks"]] == [2, 1] and [b.shape[0] for b in out["pred_boxes"]] == [1, 2]
+    for i in range(2):
+        ref = fx["pred_mask_samples"][i]
+        em = float((out["pred_masks"][i].cpu()[:, ::8, ::8] - ref).abs().max()) / float(fx["low_res_masks"][i].float().abs().max())
+        eb = rel_err(out["pred_boxes"][i], fx["pred_boxes"][i])
+        print(f"fp16 sample {i}: mask err {em:.2e} box err {eb:.2e}")
+        RESULTS.append(dict(test="g8_fp16", sample=i, mask_vs_reference=em, box_vs_reference=eb, logits=el))
+        assert em <= 4e-3 and eb <= 2e-3
+
+
+def test_core_forward_fp16_vs_oracle_and_greedy_ids():
+    """tiny UllavaCoreForCausalLM in fp16 vs the (dtype-generic, reference-pinned) oracle on the same fp16 weights: logits and
+    greedy ids, no-cache and KV-cache."""
+    fx = load_fixture("g1_core_tiny_fp32.pt")
+    M, C = pkg("modeling_core"), pkg("configuration")
+    cd = fx["cfg"]
+    cfg = C.UllavaCoreConfig(vision_config=cd["vision_config"], vision_hidden_layer=cd["vision_hidden_layer"], projector_type=cd["projector_type"],
+                             projector_from_scratch=False, mm_token_ids=cd["mm_token_ids"], vocab_size=cd["vocab_size"],
+                             hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"], num_hidden_layers=cd["num_hidden_layers"],
+                             num_attention_heads=cd["num_attention_heads"], rms_norm_eps=cd["rms_norm_eps"], rope_theta=cd["rope_theta"])
+    model = M.UllavaCoreForCausalLM(cfg, device=DEV, dtype=H)
+    sd = fixture_sd(fx, H)
+    model.load_state_dict(sd, strict=True)
+    ids, mask, images = fx["input_ids"], fx["attention_mask"], fx["images"].to(H)
+    o = O.core_forward(sd, cd, ids, mask, images)
+    out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), images=images.to(DEV), output_hidden_states=True)
+    valid = mask.bool()
+    e = rel_err(out.logits.cpu()[valid], o["logits"][valid])
+    print("fp16 core logits err vs oracle fp16", e)
+    assert e < 3e-3
+    seq_ref, _ = O.greedy_generate(sd, cd, fx["greedy_prompt"], images[:1], None, 8)
+    for use_cache in (False, True):
+        seq = model.generate(input_ids=fx["greedy_prompt"].to(DEV), images=images[:1].to(DEV), max_new_tokens=8, do_sample=False,
+                             use_cache=use_cache, eos_token_id=-1)
+        assert torch.equal(seq.cpu(), seq_ref), (use_cache, seq.tolist(), seq_ref.tolist())

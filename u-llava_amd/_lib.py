@@ -48,6 +48,9 @@ SIGNATURES = {
     "ull_box_losses_f32": [_ptr, _i32, _ptr, _i64, _ptr, _ptr],
 }
 
+# every dtype-dependent entry point exists twice: ull_*_bf16 (bfloat16 build) and ull_*_f16 (IEEE binary16 build), same signature
+SIGNATURES.update({name[:-4] + "f16": args for name, args in list(SIGNATURES.items()) if name.endswith("_bf16")})
+
 VALUE_RETURNING = {"ull_gemm_streamk_ws_bytes": _i64}      # plain queries: the return value is the answer, not a status
 
 ERRORS = {-1: "ULL_ERR_ARG (null pointer / bad size)", -2: "ULL_ERR_SHAPE (alignment or shape constraint)",

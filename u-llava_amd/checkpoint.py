@@ -102,7 +102,7 @@ def save_pretrained(model: torch.nn.Module, path: str, max_shard_bytes: int = 5 
     os.makedirs(path, exist_ok=True)
     cfg = model.config.to_dict()
     cfg["architectures"] = [type(model).__name__]
-    cfg["torch_dtype"] = "bfloat16"
+    cfg["torch_dtype"] = str(next(model.parameters()).dtype).replace("torch.", "")
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(cfg, f, indent=2, sort_keys=True)
     sd = {_reference_key(k): v.detach().to("cpu").contiguous() for k, v in model.state_dict().items()}
@@ -139,9 +139,14 @@ def save_pretrained(model: torch.nn.Module, path: str, max_shard_bytes: int = 5 
 
 
 def _dtype_arg(torch_dtype):
-    if torch_dtype not in (None, torch.bfloat16, "bfloat16", "bf16"):
-        raise NotImplementedError("the MI355X path computes in bf16 (reference configs: bf16: true); pass torch_dtype=torch.bfloat16")
-    return torch.bfloat16
+    """reference: inference_ullava.py:26,164-168 `--dtype {fp32,bf16,fp16}` -> torch_dtype.  The MI355X path has bf16 (default, the
+    reference's training dtype) and fp16 kernel builds."""
+    if torch_dtype in (None, torch.bfloat16, "bfloat16", "bf16"):
+        return torch.bfloat16
+    if torch_dtype in (torch.float16, "float16", "fp16", "half"):
+        return torch.float16
+    raise NotImplementedError("the MI355X path has bf16 and fp16 kernel builds; pass torch_dtype=torch.bfloat16 or torch.float16 "
+                              "(fp32 models are not supported)")
 
 
 def core_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict: bool = True, **config_overrides):

@@ -22,19 +22,17 @@
 namespace {
 
 constexpr int KT = 64;                 // keys per tile
-constexpr uint16_t BF16_NEG_INF = 0xFF80;
-constexpr uint16_t BF16_MIN = 0xFF7F;  // torch.finfo(torch.bfloat16).min: the eager additive mask value
 
 struct AttnArgs {
-    const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
+    const elem_t* Q; const elem_t* K; const elem_t* Vt; elem_t* O;
     const int32_t* key_mask;            // [B, Sk] nonzero = may be attended, or null
     long q_bs, q_hs, q_ss, k_bs, k_hs, k_ss, vt_bs, vt_hs, vt_ds, o_bs, o_hs, o_ss;
     int B, H, Sq, Sk, hd, vt_len;
     int causal, scale_mode;
     float scale;
-    const bf16_t* zeros;                // >= 16 readable zero bytes (source of the head-dim padding chunks)
+    const elem_t* zeros;                // >= 16 readable zero bytes (source of the head-dim padding chunks)
     // SAM decomposed relative-position bias (image_encoder.py:354-392): S += rel_h[q, key / KW]; S += rel_w[q, key % KW]
-    const bf16_t* rel_h; const bf16_t* rel_w;   // [B*H, Sq, KH] / [B*H, Sq, KW] or null
+    const elem_t* rel_h; const elem_t* rel_w;   // [B*H, Sq, KH] / [B*H, Sq, KW] or null
     int KH, KW;
     int rel_mode;                       // 1: rel_h/rel_w are per-query tables [B*H,Sq,KH|KW]; 2: they are the raw rel_pos_h/w parameters
                                         //    [2KH-1,hd] / [2KW-1,hd] and the tables are built in the kernel prologue on the MFMA
@@ -55,7 +53,7 @@ constexpr int FL_SAM_DEC = 3;    // S / sqrt(hd)                                
 //   acc[r] = raw fp32 dot product for key j0 + r;  mk = 4 mask bytes (1 attend, 0 masked, 2 out of range)
 //   brow   = this query's bias row in LDS, rel_h(kh) = brow[bh_off - kh], rel_w(kw) = brow[bw_off - kw]; or null
 template <int FL>
-ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t mk, int qi, int koff, const bf16_t* brow, int bh_off,
+ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t mk, int qi, int koff, const elem_t* brow, int bh_off,
                         int bw_off, uint32_t& lo, uint32_t& hi) {
     const bool do_mul = FL == FL_RUNTIME ? p.scale_mode == 1 : (FL == FL_LLAMA || FL == FL_CLIP);
     const bool do_div = FL == FL_RUNTIME ? p.scale_mode == 2 : (FL == FL_SAM_DEC);
@@ -65,20 +63,20 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int j = j0 + r;
-        float sv = rbf(acc[r]);
-        if (do_mul) sv = rbf(sv * p.scale);
-        if (do_div) sv = rbf(sv / p.scale);
+        float sv = rnd(acc[r]);
+        if (do_mul) sv = rnd(sv * p.scale);
+        if (do_div) sv = rnd(sv / p.scale);
         if (do_bias) {
             // j / KW without the integer-division sequence: exact for j < 2^16, KW <= 256 (|err| << 0.5 / KW)
             const int kh = min((int)(((float)j + 0.5f) * p.inv_kw), p.KH - 1), kw = j - kh * p.KW;
-            sv = rbf(rbf(sv + bf2f(brow[bh_off - kh])) + bf2f(brow[bw_off - kw]));
+            sv = rnd(rnd(sv + e2f(brow[bh_off - kh])) + e2f(brow[bw_off - kw]));
         }
         const uint32_t mb = (mk >> (8 * r)) & 0xff;
         const bool allowed = (mb == 1) && (!do_causal || j <= qi + koff);
-        o[r] = (mb == 2) ? -INFINITY : (allowed ? sv : -3.3895313892515355e38f);   // -inf / finfo(bf16).min, exact in bf16
+        o[r] = (mb == 2) ? -INFINITY : (allowed ? sv : ELEM_MIN_F);   // -inf / finfo(bf16).min, exact in bf16
     }
-    lo = pack2bf(o[0], o[1]);
-    hi = pack2bf(o[2], o[3]);
+    lo = pack2e(o[0], o[1]);
+    hi = pack2e(o[2], o[3]);
 }
 
 // The same for a quad whose four keys are all attendable for every lane of the wave (no padding, below the causal diagonal, no
@@ -90,13 +88,13 @@ ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& l
     float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float sv = rbf(acc[r]);
-        if (do_mul) sv = rbf(sv * p.scale);
-        if (do_div) sv = rbf(sv / p.scale);
+        float sv = rnd(acc[r]);
+        if (do_mul) sv = rnd(sv * p.scale);
+        if (do_div) sv = rnd(sv / p.scale);
         o[r] = sv;
     }
-    lo = pack2bf(o[0], o[1]);
-    hi = pack2bf(o[2], o[3]);
+    lo = pack2e(o[0], o[1]);
+    hi = pack2e(o[2], o[3]);
 }
 
 
@@ -106,7 +104,7 @@ ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& l
 //               einsum("bhwc,hkc->bhwk") is a Toeplitz slice of exactly this product: rel_h[q][kh] = Gh[q][qy - kh + KH - 1]).
 // qf0 = the wave's UNSCALED query fragments.  Returns the two lookup offsets of this lane's query.
 template <int NKS>
-ULL_DEV void stage_rel_bias(const AttnArgs& p, bf16_t* dst, int bp, const uint4 (&qf0)[NKS], int q_first, long head, int lane,
+ULL_DEV void stage_rel_bias(const AttnArgs& p, elem_t* dst, int bp, const uint4 (&qf0)[NKS], int q_first, long head, int lane,
                             int& bh_off, int& bw_off, int hd) {
     const int fr = lane & 15, fg = lane >> 4;
     const int qi = min(q_first + fr, p.Sq - 1);
@@ -130,7 +128,7 @@ ULL_DEV void stage_rel_bias(const AttnArgs& p, bf16_t* dst, int bp, const uint4 
             for (int which = 0; which < 2; ++which)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
-                    const bf16_t* tab = which ? p.rel_w : p.rel_h;
+                    const elem_t* tab = which ? p.rel_w : p.rel_h;
                     const int nt = which ? ntw : nth;
                     const int t = min(st * 16 + fr, nt - 1);
 #pragma unroll
@@ -151,13 +149,13 @@ ULL_DEV void stage_rel_bias(const AttnArgs& p, bf16_t* dst, int bp, const uint4 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int tt = st * 16 + fg * 4 + r;
-                        if (tt < nt) dst[fr * bp + base + tt] = f2bf(acc[r]);
+                        if (tt < nt) dst[fr * bp + base + tt] = f2e(acc[r]);
                     }
                 }
         } else
 #pragma unroll 1
         for (int which = 0; which < 2; ++which) {
-            const bf16_t* tab = which ? p.rel_w : p.rel_h;
+            const elem_t* tab = which ? p.rel_w : p.rel_h;
             const int nt = which ? ntw : nth, base = which ? nth : 0;
             for (int st = 0; st * 16 < nt; ++st) {
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -174,7 +172,7 @@ ULL_DEV void stage_rel_bias(const AttnArgs& p, bf16_t* dst, int bp, const uint4 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int tt = st * 16 + fg * 4 + r;
-                    if (tt < nt) dst[fr * bp + base + tt] = f2bf(acc[r]);
+                    if (tt < nt) dst[fr * bp + base + tt] = f2e(acc[r]);
                 }
             }
         }
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     constexpr int NBUF = EXACT ? 2 * NT : 2;                     // EXACT: [K tiles 0..NT) [V^T tiles 0..NT)
     char* maskb = smem + NBUF * TILE;     // one byte per key: 1 attend, 0 masked (finfo.min), 2 out of range (-inf)
-    bf16_t* biasb = (bf16_t*)(smem + NBUF * TILE + NT * KT);
+    elem_t* biasb = (elem_t*)(smem + NBUF * TILE + NT * KT);
 
     int kend = p.Sk;
     if (p.causal) kend = min(p.Sk, q0 + BQ + koff);
@@ -263,8 +261,8 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     if (p.causal) kend_w = min(p.Sk, q0 + wave * 16 + 16 + koff);
     const int nkt_w = EXACT ? NT : (q0 + wave * 16 < p.Sq) ? max(1, (kend_w + KT - 1) / KT) : 0;   // tiles this wave computes on
 
-    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
-    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
     // stream step s: s < nkt -> K tile s ; else V^T tile s - nkt.   Buffer = s & 1.
     auto issue = [&](int s) {
         const uint32_t dst = lds_base + (EXACT ? s : (s & 1)) * TILE;
@@ -277,7 +275,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                     const int row = i * (64 / CPR) + lane / CPR;
                     const int c = (lane % CPR) ^ swz<CPR>(row);
                     const int key = min(kt * KT + row, p.Sk - 1);
-                    const bf16_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                    const elem_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
                     glds16(src, dst + i * 1024);
                 }
             }
@@ -305,7 +303,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     uint4 qf[NKS];
     const int qi = q0 + wave * 16 + fr;
     {
-        const bf16_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
+        const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             maskb[j] = m;
         }
     }
-    const bf16_t* brow = nullptr;
+    const elem_t* brow = nullptr;
     int bh_off = 0, bw_off = 0;
     if (p.rel_h != nullptr) {
         const int bp = bias_pitch(p);
@@ -384,8 +382,8 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             if (kt < nkt_w) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    m = fmaxf(m, __uint_as_float(sp[kt][i] << 16));
-                    m = fmaxf(m, __uint_as_float(sp[kt][i] & 0xffff0000u));
+                    m = fmaxf(m, pk_lo(sp[kt][i]));
+                    m = fmaxf(m, pk_hi(sp[kt][i]));
                 }
             }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -396,8 +394,8 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             if (kt < nkt_w) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    sum += __expf(__uint_as_float(sp[kt][i] << 16) - m);
-                    sum += __expf(__uint_as_float(sp[kt][i] & 0xffff0000u) - m);
+                    sum += __expf(pk_lo(sp[kt][i]) - m);
+                    sum += __expf(pk_hi(sp[kt][i]) - m);
                 }
                 if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
@@ -409,9 +407,9 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             if (kt < nkt_w) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float lo = __expf(__uint_as_float(sp[kt][i] << 16) - m) * inv;
-                    const float hi = __expf(__uint_as_float(sp[kt][i] & 0xffff0000u) - m) * inv;
-                    sp[kt][i] = pack2bf(lo, hi);
+                    const float lo = __expf(pk_lo(sp[kt][i]) - m) * inv;
+                    const float hi = __expf(pk_hi(sp[kt][i]) - m) * inv;
+                    sp[kt][i] = pack2e(lo, hi);
                 }
                 if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
@@ -454,13 +452,13 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
         }
     }
     if (qi < p.Sq) {
-        bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
+        elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
             if (ds * 16 < hd) {
                 uint2 pk;
-                pk.x = pack2bf(oacc[ds][0], oacc[ds][1]);
-                pk.y = pack2bf(oacc[ds][2], oacc[ds][3]);
+                pk.x = pack2e(oacc[ds][0], oacc[ds][1]);
+                pk.y = pack2e(oacc[ds][2], oacc[ds][3]);
                 *(uint2*)(op + ds * 16 + fg * 4) = pk;
             }
         }
@@ -499,12 +497,12 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
     if (kend < 1) kend = 1;
     const int nkt = (kend + KT - 1) / KT;
     char* maskb = smem + 4 * TILE;
-    bf16_t* biasb = (bf16_t*)(smem + 4 * TILE + ((nkt * KT + 15) & ~15));
+    elem_t* biasb = (elem_t*)(smem + 4 * TILE + ((nkt * KT + 15) & ~15));
 
     uint4 qf[NKS];
     const int qi = q0 + wave * 16 + fr;
     {
-        const bf16_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
+        const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
@@ -516,7 +514,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
             maskb[j] = m;
         }
     }
-    const bf16_t* brow = nullptr;
+    const elem_t* brow = nullptr;
     int bh_off = 0, bw_off = 0;
     if (p.rel_h != nullptr) {
         const int bp = bias_pitch(p);
@@ -529,8 +527,8 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
-    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
     // stream step s: s < nkt -> K tile s (pass 1); else K tile + V^T tile s - nkt (pass 2).  Slot = s & 1, [K | V^T].
     auto issue = [&](int s) {
         if (s >= 2 * nkt) return;
@@ -543,7 +541,7 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
                 const int row = i * (64 / CPR) + lane / CPR;
                 const int c = (lane % CPR) ^ swz<CPR>(row);
                 const int key = min(kt * KT + row, p.Sk - 1);
-                const bf16_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                const elem_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
                 glds16(src, dst + i * 1024);
             }
         }
@@ -589,15 +587,15 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
         float tm = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            tm = fmaxf(tm, __uint_as_float(sq[i] << 16));
-            tm = fmaxf(tm, __uint_as_float(sq[i] & 0xffff0000u));
+            tm = fmaxf(tm, pk_lo(sq[i]));
+            tm = fmaxf(tm, pk_hi(sq[i]));
         }
         if (tm > m) { l *= __expf(m - tm); m = tm; }
         if (m > -INFINITY) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                l += __expf(__uint_as_float(sq[i] << 16) - m);
-                l += __expf(__uint_as_float(sq[i] & 0xffff0000u) - m);
+                l += __expf(pk_lo(sq[i]) - m);
+                l += __expf(pk_hi(sq[i]) - m);
             }
         }
     }
@@ -625,9 +623,9 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
         scores(tb, kt, sq);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float lo = __expf(__uint_as_float(sq[i] << 16) - m) * inv;
-            const float hi = __expf(__uint_as_float(sq[i] & 0xffff0000u) - m) * inv;
-            sq[i] = pack2bf(lo, hi);
+            const float lo = __expf(pk_lo(sq[i]) - m) * inv;
+            const float hi = __expf(pk_hi(sq[i]) - m) * inv;
+            sq[i] = pack2e(lo, hi);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -643,13 +641,13 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
         }
     }
     if (qi < p.Sq) {
-        bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
+        elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
             if (ds * 16 < hd) {
                 uint2 pk;
-                pk.x = pack2bf(oacc[ds][0], oacc[ds][1]);
-                pk.y = pack2bf(oacc[ds][2], oacc[ds][3]);
+                pk.x = pack2e(oacc[ds][0], oacc[ds][1]);
+                pk.y = pack2e(oacc[ds][2], oacc[ds][3]);
                 *(uint2*)(op + ds * 16 + fg * 4) = pk;
             }
         }
@@ -693,13 +691,13 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     if (kend < 1) kend = 1;
     const int nkt = (kend + KT - 1) / KT;
     char* maskb = smem + 4 * TILE;
-    bf16_t* biasb = (bf16_t*)(smem + 4 * TILE + ((nkt * KT + 15) & ~15));
+    elem_t* biasb = (elem_t*)(smem + 4 * TILE + ((nkt * KT + 15) & ~15));
 
     uint4 qf[NKS];
     const int qi = q0 + wave * 16 + fr;
     const int qic = min(qi, p.Sq - 1);
     {
-        const bf16_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
+        const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
@@ -713,30 +711,30 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             }
         }
     }
-    const bf16_t* brow = nullptr;
+    const elem_t* brow = nullptr;
     int bh_off = 0, bw_off = 0;
     float rw[16];                                              // HOIST: rel_w of this lane's 16 key columns
-    const bf16_t* rh_row = nullptr;                            // HOIST: rel_h row of this lane's query
+    const elem_t* rh_row = nullptr;                            // HOIST: rel_h row of this lane's query
     float gh[4][4];                                            // HOIST 2: rel_h of this wave's 16 queries, see below
     if constexpr (HOIST == 1) {
         const long row = (long)head * p.Sq + qic;
-        const bf16_t* wrow = p.rel_w + row * p.KW;
+        const elem_t* wrow = p.rel_w + row * p.KW;
 #pragma unroll
         for (int ns = 0; ns < 4; ++ns) {
             const uint2 v = *(const uint2*)(wrow + ns * 16 + fg * 4);
-            rw[ns * 4 + 0] = bf2f((bf16_t)(v.x & 0xffff)); rw[ns * 4 + 1] = bf2f((bf16_t)(v.x >> 16));
-            rw[ns * 4 + 2] = bf2f((bf16_t)(v.y & 0xffff)); rw[ns * 4 + 3] = bf2f((bf16_t)(v.y >> 16));
+            rw[ns * 4 + 0] = pk_lo(v.x); rw[ns * 4 + 1] = pk_hi(v.x);
+            rw[ns * 4 + 2] = pk_lo(v.y); rw[ns * 4 + 3] = pk_hi(v.y);
         }
         rh_row = p.rel_h + row * p.KH;
     } else if constexpr (HOIST == 2) {
         // raw rel_pos_h / rel_pos_w [127, hd] (64 x 64 grid): G[q][t] = bf16(q . rel_pos[t]) on the MFMA (A = table rows, B = the
         // UNSCALED query fragments), rel_w[q][kw] = Gw[q][qx - kw + 63], rel_h[q][kh] = Gh[q][qy - kh + 63] (image_encoder.py:354-392).
         // Gw: all 127 rows -> this wave's 4-KiB LDS pad (aliases the tile buffers, which are not in use yet) -> 16 registers.
-        bf16_t* gw = (bf16_t*)(smem + wave * 4096);            // [16 queries][128]
+        elem_t* gw = (elem_t*)(smem + wave * 4096);            // [16 queries][128]
 #pragma unroll 2
         for (int st = 0; st < 8; ++st) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            const bf16_t* tr = p.rel_w + (long)min(st * 16 + fr, 126) * hd + fg * 8;
+            const elem_t* tr = p.rel_w + (long)min(st * 16 + fr, 126) * hd + fg * 8;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 if (ks * 32 < hd) {
@@ -745,7 +743,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gw[fr * 128 + st * 16 + fg * 4 + r] = f2bf(acc[r]);      // G[t = st*16 + 4*fg + r][query fr]
+            for (int r = 0; r < 4; ++r) gw[fr * 128 + st * 16 + fg * 4 + r] = f2e(acc[r]);      // G[t = st*16 + 4*fg + r][query fr]
         }
         // Gh: the 16 queries of a wave share qy, so the 64 table rows they need are qy - kh + 63; group g (kh = 16g .. 16g+15) is
         // rows base_g .. base_g + 15 with base_g = qy - 16g + 48, one MFMA chain per group, kept in registers: lane (fr, fg')
@@ -754,7 +752,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            const bf16_t* tr = p.rel_h + (long)min(max(qy - 16 * g + 48 + fr, 0), 126) * hd + fg * 8;
+            const elem_t* tr = p.rel_h + (long)min(max(qy - 16 * g + 48 + fr, 0), 126) * hd + fg * 8;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 if (ks * 32 < hd) {
@@ -763,12 +761,12 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gh[g][r] = rbf(acc[r]);
+            for (int r = 0; r < 4; ++r) gh[g][r] = rnd(acc[r]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own pad only
         const int qx = qic & 63;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rw[i] = bf2f(gw[fr * 128 + qx - ((i >> 2) * 16 + fg * 4 + (i & 3)) + 63]);
+        for (int i = 0; i < 16; ++i) rw[i] = e2f(gw[fr * 128 + qx - ((i >> 2) * 16 + fg * 4 + (i & 3)) + 63]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // every wave is done with its pad before tile 0 is DMA'd over it
     } else if (p.rel_h != nullptr) {
@@ -782,8 +780,8 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
-    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
     auto issue = [&](int kt) {                                // K tile kt and V^T tile kt -> slot kt & 1 = [K | V^T]
         if (kt >= nkt) return;
         const uint32_t dst = lds_base + (kt & 1) * (2 * TILE);
@@ -794,7 +792,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                 const int row = i * (64 / CPR) + lane / CPR;
                 const int c = (lane % CPR) ^ swz<CPR>(row);
                 const int key = min(kt * KT + row, p.Sk - 1);
-                const bf16_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                const elem_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
                 glds16(src, dst + i * 1024);
             }
         }
@@ -834,13 +832,13 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             }
             if constexpr (HOIST != 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sv[ns * 4 + r] = rbf(rbf(rbf(acc[r]) + rh) + rw[ns * 4 + r]);
+                for (int r = 0; r < 4; ++r) sv[ns * 4 + r] = rnd(rnd(rnd(acc[r]) + rh) + rw[ns * 4 + r]);
             } else {
                 const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
                 uint32_t lo, hi;
                 score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, lo, hi);
-                sv[ns * 4 + 0] = __uint_as_float(lo << 16); sv[ns * 4 + 1] = __uint_as_float(lo & 0xffff0000u);
-                sv[ns * 4 + 2] = __uint_as_float(hi << 16); sv[ns * 4 + 3] = __uint_as_float(hi & 0xffff0000u);
+                sv[ns * 4 + 0] = pk_lo(lo); sv[ns * 4 + 1] = pk_hi(lo);
+                sv[ns * 4 + 2] = pk_lo(hi); sv[ns * 4 + 3] = pk_hi(hi);
             }
         }
         float tm = sv[0];
@@ -862,9 +860,9 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float e0 = __expf(sv[2 * i] - m), e1 = __expf(sv[2 * i + 1] - m);
-            pk[i] = pack2bf(e0, e1);
+            pk[i] = pack2e(e0, e1);
             // the sum runs over the ROUNDED probabilities, so that O / l is a true weighted mean of V rows
-            l += __uint_as_float(pk[i] << 16) + __uint_as_float(pk[i] & 0xffff0000u);
+            l += pk_lo(pk[i]) + pk_hi(pk[i]);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -894,9 +892,9 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             }
         }
     } else if constexpr (HOIST == 1) {
-        float rh = bf2f(rh_row[0]);
+        float rh = e2f(rh_row[0]);
         for (int kt = 0; kt < nkt; ++kt) {
-            const float rh_next = bf2f(rh_row[min(kt + 1, p.KH - 1)]);
+            const float rh_next = e2f(rh_row[min(kt + 1, p.KH - 1)]);
             tile(kt, rh);
             rh = rh_next;
         }
@@ -907,13 +905,13 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     if (qi < p.Sq) {
-        bf16_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
+        elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
             if (ds * 16 < hd) {
                 uint2 o;
-                o.x = pack2bf(oacc[ds][0] * inv, oacc[ds][1] * inv);
-                o.y = pack2bf(oacc[ds][2] * inv, oacc[ds][3] * inv);
+                o.x = pack2e(oacc[ds][0] * inv, oacc[ds][1] * inv);
+                o.y = pack2e(oacc[ds][2] * inv, oacc[ds][3] * inv);
                 *(uint2*)(op + ds * 16 + fg * 4) = o;
             }
         }
@@ -950,7 +948,7 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
     uint4 qf[NKS];
     const int qi = fr;
     {
-        const bf16_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
+        const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
@@ -961,8 +959,8 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
             for (int ks = 0; ks < NKS; ++ks) qf[ks] = scale_q8(qf[ks], p.q_scale);
         }
     }
-    const bf16_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
-    const bf16_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
 
     // ---- scores of this wave's tiles -> registers (packed bf16), running max -------------------------------
     uint32_t sp[TPW][8];
@@ -974,7 +972,7 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
 #pragma unroll
             for (int ns = 0; ns < 4; ++ns) {
                 const int key = min(kt * KT + ns * 16 + fr, p.Sk - 1);
-                const bf16_t* kp = kbase + (long)key * p.k_ss + fg * 8;
+                const elem_t* kp = kbase + (long)key * p.k_ss + fg * 8;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
@@ -996,8 +994,8 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                m = fmaxf(m, __uint_as_float(sp[t][i] << 16));
-                m = fmaxf(m, __uint_as_float(sp[t][i] & 0xffff0000u));
+                m = fmaxf(m, pk_lo(sp[t][i]));
+                m = fmaxf(m, pk_hi(sp[t][i]));
             }
         }
     }
@@ -1024,8 +1022,8 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
         if (wave + t * nwv < nkt) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                sum += __expf(__uint_as_float(sp[t][i] << 16) - m);
-                sum += __expf(__uint_as_float(sp[t][i] & 0xffff0000u) - m);
+                sum += __expf(pk_lo(sp[t][i]) - m);
+                sum += __expf(pk_hi(sp[t][i]) - m);
             }
         }
     sum += __shfl_xor(sum, 16, 64);
@@ -1046,9 +1044,9 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
         if (kt < nkt) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float lo = __expf(__uint_as_float(sp[t][i] << 16) - m) * inv;
-                const float hi = __expf(__uint_as_float(sp[t][i] & 0xffff0000u) - m) * inv;
-                sp[t][i] = pack2bf(lo, hi);
+                const float lo = __expf(pk_lo(sp[t][i]) - m) * inv;
+                const float hi = __expf(pk_hi(sp[t][i]) - m) * inv;
+                sp[t][i] = pack2e(lo, hi);
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -1076,7 +1074,7 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
         for (int w = 0; w < nwv; ++w) acc += obuf[w * NDS * 4 * 64 + e];
         const int reg = e >> 6, ln = e & 63;
         const int q = ln & 15, d = (reg >> 2) * 16 + (ln >> 4) * 4 + (reg & 3);
-        if (q < p.Sq && d < hd) p.O[(long)b * p.o_bs + (long)h * p.o_hs + (long)q * p.o_ss + d] = f2bf(acc);
+        if (q < p.Sq && d < hd) p.O[(long)b * p.o_bs + (long)h * p.o_hs + (long)q * p.o_ss + d] = f2e(acc);
     }
 }
 
@@ -1084,7 +1082,7 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
 // RoPE in place on the q|k part of a fused QKV buffer (transformers apply_rotary_pos_emb on bf16
 // tensors: q*cos -> bf16, rotate_half(q)*sin -> bf16, sum -> bf16; cos/sin are fp32 values cast to bf16).
 // One block per token; thread t owns the 8-wide dim chunk (t % (hd/16)) of head-instances t / (hd/16), ...
-__global__ __launch_bounds__(256) void rope_inplace_kernel(bf16_t* __restrict__ x, long row_stride, const int64_t* __restrict__ pos,
+__global__ __launch_bounds__(256) void rope_inplace_kernel(elem_t* __restrict__ x, long row_stride, const int64_t* __restrict__ pos,
                                                            const float* __restrict__ inv_freq, int n_heads, int hd) {
     const long tok = blockIdx.x;
     const int half = hd >> 1;
@@ -1095,20 +1093,20 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(bf16_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float a = pf * inv_freq[c * 8 + j];
-        cs[j] = rbf(cosf(a));
-        sn[j] = rbf(sinf(a));
+        cs[j] = rnd(cosf(a));
+        sn[j] = rnd(sinf(a));
     }
-    bf16_t* xr = x + tok * row_stride;
+    elem_t* xr = x + tok * row_stride;
     for (int hh = threadIdx.x / cpr; hh < n_heads; hh += blockDim.x / cpr) {
-        bf16_t* p1 = xr + hh * hd + c * 8;
-        bf16_t* p2 = p1 + half;
+        elem_t* p1 = xr + hh * hd + c * 8;
+        elem_t* p2 = p1 + half;
         float a[8], bb[8], o1[8], o2[8];
         unpack8(*(const uint4*)p1, a);
         unpack8(*(const uint4*)p2, bb);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            o1[j] = rbf(a[j] * cs[j]) + rbf(-bb[j] * sn[j]);
-            o2[j] = rbf(bb[j] * cs[j]) + rbf(a[j] * sn[j]);
+            o1[j] = rnd(a[j] * cs[j]) + rnd(-bb[j] * sn[j]);
+            o2[j] = rnd(bb[j] * cs[j]) + rnd(a[j] * sn[j]);
         }
         *(uint4*)p1 = pack8(o1);
         *(uint4*)p2 = pack8(o2);
@@ -1119,9 +1117,9 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(bf16_t* __restrict__ 
 // (was rope + two strided copies per layer).  qkv rows = tokens (b, s) of a step, [q | k | v] heads contiguous; the token at
 // step position s goes to cache slot past + s: K cache [B, H, smax, hd] row past + s, V^T cache [B, H, hd, smax] column
 // vt_slot(past + s) (the key-permuted layout of transpose_v_kernel).  One block per token.
-__global__ __launch_bounds__(256) void rope_append_kernel(bf16_t* __restrict__ qkv, long row_stride, const int64_t* __restrict__ pos,
-                                                          const float* __restrict__ inv_freq, int S, int H, int hd, bf16_t* __restrict__ kc,
-                                                          bf16_t* __restrict__ vtc, int smax, int past) {
+__global__ __launch_bounds__(256) void rope_append_kernel(elem_t* __restrict__ qkv, long row_stride, const int64_t* __restrict__ pos,
+                                                          const float* __restrict__ inv_freq, int S, int H, int hd, elem_t* __restrict__ kc,
+                                                          elem_t* __restrict__ vtc, int smax, int past) {
     const long tok = blockIdx.x;
     const int b = (int)(tok / S), s = (int)(tok % S);
     const int half = hd >> 1;
@@ -1132,35 +1130,35 @@ __global__ __launch_bounds__(256) void rope_append_kernel(bf16_t* __restrict__ q
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float a = pf * inv_freq[c * 8 + j];
-        cs[j] = rbf(cosf(a));
-        sn[j] = rbf(sinf(a));
+        cs[j] = rnd(cosf(a));
+        sn[j] = rnd(sinf(a));
     }
-    bf16_t* xr = qkv + tok * row_stride;
+    elem_t* xr = qkv + tok * row_stride;
     const int slot_k = past + s;
     for (int hh = threadIdx.x / cpr; hh < 2 * H; hh += blockDim.x / cpr) {
-        bf16_t* p1 = xr + hh * hd + c * 8;
-        bf16_t* p2 = p1 + half;
+        elem_t* p1 = xr + hh * hd + c * 8;
+        elem_t* p2 = p1 + half;
         float a[8], bb[8], o1[8], o2[8];
         unpack8(*(const uint4*)p1, a);
         unpack8(*(const uint4*)p2, bb);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            o1[j] = rbf(a[j] * cs[j]) + rbf(-bb[j] * sn[j]);
-            o2[j] = rbf(bb[j] * cs[j]) + rbf(a[j] * sn[j]);
+            o1[j] = rnd(a[j] * cs[j]) + rnd(-bb[j] * sn[j]);
+            o2[j] = rnd(bb[j] * cs[j]) + rnd(a[j] * sn[j]);
         }
         const uint4 r1 = pack8(o1), r2 = pack8(o2);
         if (hh < H) {
             *(uint4*)p1 = r1;
             *(uint4*)p2 = r2;
         } else {
-            bf16_t* kp = kc + (((long)b * H + (hh - H)) * smax + slot_k) * hd + c * 8;
+            elem_t* kp = kc + (((long)b * H + (hh - H)) * smax + slot_k) * hd + c * 8;
             *(uint4*)kp = r1;
             *(uint4*)(kp + half) = r2;
         }
     }
     const int w = slot_k & 31;
     const int slot_v = (slot_k & ~31) + 8 * ((w >> 2) & 3) + 4 * (w >> 4) + (w & 3);
-    const bf16_t* vr = xr + 2 * H * hd;
+    const elem_t* vr = xr + 2 * H * hd;
     for (int i = threadIdx.x; i < H * hd; i += blockDim.x) vtc[((long)b * H * hd + i) * smax + slot_v] = vr[i];
 }
 
@@ -1168,12 +1166,12 @@ __global__ __launch_bounds__(256) void rope_append_kernel(bf16_t* __restrict__ q
 // Inside every 32-key block the keys are stored permuted: slot 8g + 4a + r holds key 16a + 4g + r (a<2, g<4, r<4),
 // which is the (lane group g, element j = 4a + r) <-> key map that the attention kernel's probability registers
 // have after the swapped QK^T MFMA -- so P*V needs no cross-lane movement.  64(s) x 64(d) tiles through LDS.
-__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, long v_bs, long v_ss, bf16_t* __restrict__ vt, int S,
+__global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restrict__ v, long v_bs, long v_ss, elem_t* __restrict__ vt, int S,
                                                           int H, int hd, int pitch) {
-    __shared__ __attribute__((aligned(16))) bf16_t t[64][68];            // [d][key]; 136-byte rows keep the 8-byte reads aligned
+    __shared__ __attribute__((aligned(16))) elem_t t[64][68];            // [d][key]; 136-byte rows keep the 8-byte reads aligned
     const int b = blockIdx.z / H, h = blockIdx.z % H;
     const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
-    const bf16_t* vp = v + (long)b * v_bs + (long)h * hd;
+    const elem_t* vp = v + (long)b * v_bs + (long)h * hd;
     // 16-byte loads along d (coalesced: 8 lanes cover one token's 64 dims), scattered 2-byte LDS writes
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -1184,12 +1182,12 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
         const uint32_t w[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t[dc + 2 * j][sl] = (bf16_t)(w[j] & 0xffff);
-            t[dc + 2 * j + 1][sl] = (bf16_t)(w[j] >> 16);
+            t[dc + 2 * j][sl] = (elem_t)(w[j] & 0xffff);
+            t[dc + 2 * j + 1][sl] = (elem_t)(w[j] >> 16);
         }
     }
     __syncthreads();
-    bf16_t* op = vt + ((long)b * H + h) * hd * pitch;
+    elem_t* op = vt + ((long)b * H + h) * hd * pitch;
     // output chunk oc = 8 consecutive slots 8g .. 8g+7 of a 32-key block = keys {4g..4g+3} and {16+4g..16+4g+3}: two 8-byte LDS reads
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -1321,7 +1319,7 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
 // Strides are in elements.  Q/K rows are head_dim-contiguous; Vt rows (one per head dim) are key-contiguous with
 // `vt_len` readable, finite columns (multiple of 8; keys >= Sk must be zero).  key_mask: int32 [B, Sk] or null.
 // scale_mode 0: S = bf16(QK^T); 1: bf16(bf16(QK^T) * scale); 2: bf16(bf16(QK^T) / scale).
-extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs,
+extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs,
                                   int64_t k_ss, const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O,
                                   int64_t o_bs, int64_t o_hs, int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq,
                                   int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, float q_scale, const void* rel_h,
@@ -1332,14 +1330,14 @@ extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int
         (o_ss & 3) || (o_hs & 3) || (o_bs & 3))
         return ULL_ERR_SHAPE;
     AttnArgs a;
-    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.Vt = (const bf16_t*)Vt; a.O = (bf16_t*)O;
+    a.Q = (const elem_t*)Q; a.K = (const elem_t*)K; a.Vt = (const elem_t*)Vt; a.O = (elem_t*)O;
     a.key_mask = (const int32_t*)key_mask;
     a.q_bs = q_bs; a.q_hs = q_hs; a.q_ss = q_ss; a.k_bs = k_bs; a.k_hs = k_hs; a.k_ss = k_ss;
     a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_hs = o_hs; a.o_ss = o_ss;
     a.B = (int)B; a.H = (int)H; a.Sq = (int)Sq; a.Sk = (int)Sk; a.hd = (int)hd; a.vt_len = (int)vt_len;
     a.causal = causal; a.scale_mode = scale_mode; a.scale = scale;
-    a.zeros = (const bf16_t*)zeros;
-    a.rel_h = (const bf16_t*)rel_h; a.rel_w = (const bf16_t*)rel_w; a.KH = (int)rel_kh; a.KW = (int)rel_kw; a.q_scale = q_scale;
+    a.zeros = (const elem_t*)zeros;
+    a.rel_h = (const elem_t*)rel_h; a.rel_w = (const elem_t*)rel_w; a.KH = (int)rel_kh; a.KW = (int)rel_kw; a.q_scale = q_scale;
     a.inv_kw = rel_kw > 0 ? 1.0f / (float)rel_kw : 0.f;
     a.rel_mode = rel_h ? rel_mode : 0;
     if (rel_h && rel_mode != 1 && rel_mode != 2) return ULL_ERR_ARG;
@@ -1353,34 +1351,34 @@ extern "C" int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int
 
 // x: first of `n_heads` consecutive heads (q heads then k heads of a fused QKV row); positions int64 [tokens];
 // inv_freq fp32 [hd/2] (host-computed exactly like LlamaRotaryEmbedding).
-extern "C" int ull_rope_inplace_bf16(void* x, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens,
+extern "C" int ULL_FN(ull_rope_inplace_)(void* x, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens,
                                      int64_t n_heads, int64_t hd, void* stream) {
     if (!x || !positions || !inv_freq || tokens <= 0) return ULL_ERR_ARG;
     const int64_t cpr = hd >> 4;
     if ((hd & 15) || hd > 256 || (cpr & (cpr - 1)) || (row_stride & 7)) return ULL_ERR_SHAPE;   // 256 % (hd/16) == 0
-    hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, row_stride,
+    hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (elem_t*)x, row_stride,
                        (const int64_t*)positions, (const float*)inv_freq, (int)n_heads, (int)hd);
     return ull_check_launch();
 }
 
 // Decode step: RoPE on the q and k heads of the fused QKV rows + append of k (roped) and v to the KV cache (see the kernel).
-extern "C" int ull_rope_append_bf16(void* qkv, int64_t row_stride, const void* positions, const void* inv_freq, int64_t B, int64_t S,
+extern "C" int ULL_FN(ull_rope_append_)(void* qkv, int64_t row_stride, const void* positions, const void* inv_freq, int64_t B, int64_t S,
                                     int64_t H, int64_t hd, void* k_cache, void* vt_cache, int64_t smax, int64_t past, void* stream) {
     if (!qkv || !positions || !inv_freq || !k_cache || !vt_cache || B <= 0 || S <= 0) return ULL_ERR_ARG;
     const int64_t cpr = hd >> 4;
     if ((hd & 15) || hd > 256 || (cpr & (cpr - 1)) || (row_stride & 7) || past + S > smax) return ULL_ERR_SHAPE;
-    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, row_stride,
-                       (const int64_t*)positions, (const float*)inv_freq, (int)S, (int)H, (int)hd, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, (elem_t*)qkv, row_stride,
+                       (const int64_t*)positions, (const float*)inv_freq, (int)S, (int)H, (int)hd, (elem_t*)k_cache, (elem_t*)vt_cache,
                        (int)smax, (int)past);
     return ull_check_launch();
 }
 
-extern "C" int ull_transpose_v_bf16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd,
+extern "C" int ULL_FN(ull_transpose_v_)(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd,
                                     int64_t pitch, void* stream) {
     if (!v || !vt || B <= 0 || S <= 0) return ULL_ERR_ARG;
     if (pitch < S || (pitch & 63)) return ULL_ERR_SHAPE;
     const dim3 grid((unsigned)((pitch + 63) / 64), (unsigned)((hd + 63) / 64), (unsigned)(B * H));
-    hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v, v_bs, v_ss, (bf16_t*)vt, (int)S, (int)H,
+    hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const elem_t*)v, v_bs, v_ss, (elem_t*)vt, (int)S, (int)H,
                        (int)hd, (int)pitch);
     return ull_check_launch();
 }

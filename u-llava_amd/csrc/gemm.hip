@@ -17,7 +17,7 @@
 //     ds_read_b128 address (same involution both sides).
 //   * MFMA operands are swapped (A-operand = W rows, B-operand = X rows) so each lane ends up with 4
 //     consecutive output features of one token -> 8-byte bf16 stores into row-major C.
-//   * Fused epilogues reproduce the rounding points of the reference's bf16 graph (rbf()).
+//   * Fused epilogues reproduce the rounding points of the reference's bf16 graph (rnd()).
 //   * 1-D grid with XCD-aware remap (block b runs on XCD b%8; each XCD gets a contiguous chunk of the
 //     tile space, walked in GROUP_M-row groups so co-resident blocks share X / W panels in that L2).
 #include "ull_common.h"
@@ -38,8 +38,8 @@ constexpr int EPI_RESID = 8, EPI_SWIGLU = 16, EPI_OUT_F32 = 32;
 constexpr int EPI_W_TILED = 64, EPI_X_TILED = 128;
 
 struct GemmArgs {
-    const bf16_t* X; const bf16_t* W; void* C;
-    const bf16_t* bias; const bf16_t* R;
+    const elem_t* X; const elem_t* W; void* C;
+    const elem_t* bias; const elem_t* R;
     long ldx, ldw, ldc, ldr;
     int M, N, K, flags;
     int nbm, nbn;
@@ -88,26 +88,26 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
     auto finish8 = [&](float (&a)[8], int m, int n) {
         if (act == 1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_bf16(a[e]);
+            for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_e(a[e]);
         } else if (act == 2) {
 #pragma unroll 1
-            for (int e = 0; e < 8; ++e) a[e] = rbf(act_gelu_erf(a[e]));
+            for (int e = 0; e < 8; ++e) a[e] = rnd(act_gelu_erf(a[e]));
         } else if (act == 3) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.f);
         }
         const bool full = n + 8 <= n_out;
         if (has_res) {
-            const bf16_t* rp = p.R + (long)m * p.ldr + n;
+            const elem_t* rp = p.R + (long)m * p.ldr + n;
             if (full && r_al) {
                 float b[8];
                 unpack8(*(const uint4*)rp, b);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = rbf(b[e] + a[e]);
+                for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
             } else {
 #pragma unroll 1
                 for (int e = 0; e < 8; ++e)
-                    if (n + e < n_out) a[e] = rbf(bf2f(rp[e]) + a[e]);
+                    if (n + e < n_out) a[e] = rnd(e2f(rp[e]) + a[e]);
             }
         }
         if (out_f32) {
@@ -121,13 +121,13 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                     if (n + e < n_out) cp[e] = a[e];
             }
         } else {
-            bf16_t* cp = (bf16_t*)p.C + (long)m * p.ldc + n;
+            elem_t* cp = (elem_t*)p.C + (long)m * p.ldc + n;
             if (full && c_al) {
                 *(uint4*)cp = pack8(a);
             } else {
 #pragma unroll 1
                 for (int e = 0; e < 8; ++e)
-                    if (n + e < n_out) cp[e] = f2bf(a[e]);
+                    if (n + e < n_out) cp[e] = f2e(a[e]);
             }
         }
     };
@@ -138,7 +138,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = nw0 + i * 16 + fg * 4 + r;
-            bias_v[i][r] = (!SWIGLU && (flags & EPI_BIAS) && n < p.N) ? bf2f(p.bias[n]) : -0.0f;
+            bias_v[i][r] = (!SWIGLU && (flags & EPI_BIAS) && n < p.N) ? e2f(p.bias[n]) : -0.0f;
         }
 
     if (!raw_f32) {
@@ -153,21 +153,21 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float g = rbf(acc[2 * ip][j][r]);          // gate_proj output (bf16 tensor)
-                        const float u = rbf(acc[2 * ip + 1][j][r]);      // up_proj output (bf16 tensor)
-                        v[r] = rbf(act_silu(g)) * u;                     // silu -> bf16, product -> bf16 (by the pack)
+                        const float g = rnd(acc[2 * ip][j][r]);          // gate_proj output (bf16 tensor)
+                        const float u = rnd(acc[2 * ip + 1][j][r]);      // up_proj output (bf16 tensor)
+                        v[r] = rnd(act_silu(g)) * u;                     // silu -> bf16, product -> bf16 (by the pack)
                     }
                     uint2 o;
-                    o.x = pack2bf(v[0], v[1]);
-                    o.y = pack2bf(v[2], v[3]);
+                    o.x = pack2e(v[0], v[1]);
+                    o.y = pack2e(v[2], v[3]);
                     *(uint2*)(reg + (j * 16 + fr) * PITCH + (ip * 16 + fg * 4) * 2) = o;
                 }
             } else {
 #pragma clang loop unroll(full)
                 for (int i = 0; i < 4; ++i) {
                     uint2 o;                                             // the Linear's bf16 output
-                    o.x = pack2bf(acc[i][j][0] + bias_v[i][0], acc[i][j][1] + bias_v[i][1]);
-                    o.y = pack2bf(acc[i][j][2] + bias_v[i][2], acc[i][j][3] + bias_v[i][3]);
+                    o.x = pack2e(acc[i][j][0] + bias_v[i][0], acc[i][j][1] + bias_v[i][1]);
+                    o.y = pack2e(acc[i][j][2] + bias_v[i][2], acc[i][j][3] + bias_v[i][3]);
                     *(uint2*)(reg + (j * 16 + fr) * PITCH + (i * 16 + fg * 4) * 2) = o;
                 }
             }
@@ -217,7 +217,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
 }
 
 template <bool SWIGLU>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
     // which must fetch LOGICAL chunk (l&7) ^ (row&7) so that reads can undo the swizzle.
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
-    const bf16_t* xsrc[4];
-    const bf16_t* wsrc[4];
+    const elem_t* xsrc[4];
+    const elem_t* wsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + srow;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
 // The one chunk that would read past the end of the buffer (last image, last channel, last pixel row, last patch: 12 real bytes +
 // 4 beyond) goes through registers instead of the DMA.
 struct PatchArgs {
-    const bf16_t* img; const bf16_t* zeros; const bf16_t* img_end;
+    const elem_t* img; const elem_t* zeros; const elem_t* img_end;
     int C, H, W, ps, gw, gh;          // image geometry; gw x gh patches per image
     int nseg;                         // C * ps real (c, ky) segments; segments >= nseg read zeros
 };
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void patchify_gemm_kernel(GemmArgs p, Patch
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;                 // logical 16-byte chunk of the 128-byte K-tile row this lane fetches
     const int seg = schunk >> 1, half = schunk & 1;       // (c, ky) segment within the K-tile, first / second 8 kx
-    const bf16_t* xbase[4];                               // pixel (b, c = 0, y = py*ps, x = px*ps) of the patch this lane stages
-    const bf16_t* wsrc[4];
+    const elem_t* xbase[4];                               // pixel (b, c = 0, y = py*ps, x = px*ps) of the patch this lane stages
+    const elem_t* wsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + srow;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void patchify_gemm_kernel(GemmArgs p, Patch
         const long ko = (long)kt * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bf16_t* sp = real ? xbase[i] + xoff : q.zeros;
+            const elem_t* sp = real ? xbase[i] + xoff : q.zeros;
             if (real && sp + 8 > q.img_end) {
                 // the one chunk that would read past the buffer (last image / channel / pixel row / patch, second half): its 6 real
                 // pixels come through registers, the 2 pad slots are zero (W' is zero there anyway, but garbage could be NaN bits)
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // DMA: a 1-KiB piece = 8 rows x 128 B; wave w stages pieces 4w..4w+3 of X and of W.
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
-    const bf16_t* xsrc[4];
-    const bf16_t* wsrc[4];
+    const elem_t* xsrc[4];
+    const elem_t* wsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + srow;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
             }
             n = n0 / 2 + grp * 16 + off;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = rbf(rbf(act_silu(rbf(g[r]))) * rbf(u[r]));
+            for (int r = 0; r < 4; ++r) v[r] = rnd(rnd(act_silu(rnd(g[r]))) * rnd(u[r]));
         } else {
             float a4[4] = {0.f, 0.f, 0.f, 0.f};
             for (int s = 0; s < p.sk; ++s) {
@@ -647,10 +647,10 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = a4[r];
-                if ((flags & EPI_BIAS) && n + r < p.N) t += bf2f(p.bias[n + r]);
-                if (!out_f32 || act || (flags & EPI_RESID)) t = rbf(t);
-                if (act == 1) t = act_quick_gelu_bf16(t);
-                else if (act == 2) t = rbf(act_gelu_erf(t));
+                if ((flags & EPI_BIAS) && n + r < p.N) t += e2f(p.bias[n + r]);
+                if (!out_f32 || act || (flags & EPI_RESID)) t = rnd(t);
+                if (act == 1) t = act_quick_gelu_e(t);
+                else if (act == 2) t = rnd(act_gelu_erf(t));
                 else if (act == 3) t = fmaxf(t, 0.f);
                 v[r] = t;
             }
@@ -659,9 +659,9 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
         for (int r = 0; r < 4; ++r) {
             if (n + r >= n_out_total) continue;
             float t = v[r];
-            if (flags & EPI_RESID) t = rbf(bf2f(p.R[(long)m * p.ldr + n + r]) + t);
+            if (flags & EPI_RESID) t = rnd(e2f(p.R[(long)m * p.ldr + n + r]) + t);
             if (out_f32) ((float*)p.C)[(long)m * p.ldc + n + r] = t;
-            else ((bf16_t*)p.C)[(long)m * p.ldc + n + r] = f2bf(t);
+            else ((elem_t*)p.C)[(long)m * p.ldc + n + r] = f2e(t);
         }
     }
 }
@@ -683,8 +683,8 @@ static int gemm_device_state(int* n_cu_out) {
         const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)patchify_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         n_cu[dev] = n;                   // last: a racing first call on another thread repeats the (idempotent) attribute calls
     }
@@ -692,9 +692,11 @@ static int gemm_device_state(int* n_cu_out) {
     return ULL_OK;
 }
 
+#ifndef ULL_ELEM_F16
 extern "C" int64_t ull_gemm_streamk_ws_bytes(void) { return (int64_t)256 * big::BM * big::BN * sizeof(float); }
+#endif
 
-extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
+extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
                              const void* bias, const void* R, int64_t ldr,
                              int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream) {
     if (!X || !W || !C || M <= 0 || N <= 0 || K <= 0 || ws_bytes < 0) return ULL_ERR_ARG;
@@ -710,8 +712,8 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
     const bool force_small = flags & (1 << 20);
     flags &= 0xffff;
     GemmArgs a;
-    a.X = (const bf16_t*)X; a.W = (const bf16_t*)W; a.C = C;
-    a.bias = (const bf16_t*)bias; a.R = (const bf16_t*)R;
+    a.X = (const elem_t*)X; a.W = (const elem_t*)W; a.C = C;
+    a.bias = (const elem_t*)bias; a.R = (const elem_t*)R;
     a.ldx = ldx; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags;
     // short K and fewer than two rounds of 256x256 tiles (ViT patchify: K = 640, 128 / 288 tiles): the 128x128 kernel's 4x finer
@@ -751,9 +753,9 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
     if (flags & EPI_SWIGLU)
-        hipLaunchKernelGGL(gemm_bf16_nt_kernel<true>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gemm128_kernel<true>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(gemm_bf16_nt_kernel<false>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gemm128_kernel<false>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
     return ull_check_launch();
 }
 
@@ -761,18 +763,18 @@ extern "C" int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t 
 // Wp: packed weight [N, Kp], Kp = ceil(C*ps*16 / 64) * 64, Wp[n][(c*ps+ky)*16 + kx] = w[n][c][ky][kx] for kx < ps, zero elsewhere.
 // img: contiguous [n_img, C, H, W] bf16 (nothing behind it is read); zeros: >= 16 zero bytes.  ps even, <= 16, H % ps == W % ps == 0,
 // W >= 16.
-extern "C" int ull_patchify_bf16(const void* img, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, const void* Wp, int64_t Kp,
+extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, const void* Wp, int64_t Kp,
                                  const void* bias, void* out, int64_t ldc, int64_t N, const void* zeros, void* stream) {
     if (!img || !Wp || !out || !zeros || n_img <= 0 || C <= 0 || H <= 0 || W < 16 || N <= 0) return ULL_ERR_ARG;
     if (ps <= 0 || ps > 16 || (ps & 1) || H % ps || W % ps || Kp % BK || Kp < C * ps * 16 || (ldc & 7)) return ULL_ERR_SHAPE;
     GemmArgs a;
     PatchArgs q;
-    q.img = (const bf16_t*)img; q.zeros = (const bf16_t*)zeros;
-    q.img_end = (const bf16_t*)img + n_img * C * H * W;
+    q.img = (const elem_t*)img; q.zeros = (const elem_t*)zeros;
+    q.img_end = (const elem_t*)img + n_img * C * H * W;
     q.C = (int)C; q.H = (int)H; q.W = (int)W; q.ps = (int)ps; q.gw = (int)(W / ps); q.gh = (int)(H / ps); q.nseg = (int)(C * ps);
     const int64_t M = n_img * q.gw * q.gh;
     if (M > (1 << 30)) return ULL_ERR_SHAPE;
-    a.X = nullptr; a.W = (const bf16_t*)Wp; a.C = out; a.bias = (const bf16_t*)bias; a.R = nullptr;
+    a.X = nullptr; a.W = (const elem_t*)Wp; a.C = out; a.bias = (const elem_t*)bias; a.R = nullptr;
     a.ldx = 0; a.ldw = Kp; a.ldc = ldc; a.ldr = 0;
     a.M = (int)M; a.N = (int)N; a.K = (int)Kp; a.flags = bias ? EPI_BIAS : 0;
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);

@@ -20,11 +20,11 @@ constexpr int XS_MAX_BYTES = 32 * 1024;     // X (optionally RMS-normalised) is 
 // which removes one tiny latency-bound kernel per projection from the decode step.  The weight stream keeps U 16-byte loads
 // per lane in flight (U KiB per wave).
 template <int M, int U>
-__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ W, long ldw, void* C,
-                                                   long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, long ldr, int N, int K,
-                                                   int flags, int n_out, const bf16_t* __restrict__ norm_w, float eps, int staged) {
+__global__ __launch_bounds__(256) void gemv_kernel(const elem_t* __restrict__ X, long ldx, const elem_t* __restrict__ W, long ldw, void* C,
+                                                   long ldc, const elem_t* __restrict__ bias, const elem_t* __restrict__ R, long ldr, int N, int K,
+                                                   int flags, int n_out, const elem_t* __restrict__ norm_w, float eps, int staged) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* xs = (bf16_t*)smem;                                   // [M][K] when staged
+    elem_t* xs = (elem_t*)smem;                                   // [M][K] when staged
     __shared__ float red[4][MAXM];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     const int gw = blockIdx.x * 4 + wv_id;                        // global wave id
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ X,
                     float xv[8];
                     unpack8(raw, xv);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xv[j] = wn[j] * rbf(xv[j] * rstd[m]);
+                    for (int j = 0; j < 8; ++j) xv[j] = wn[j] * rnd(xv[j] * rstd[m]);
                     raw = pack8(xv);
                 }
                 *(uint4*)(xs + (long)m * K + c * 8) = raw;
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ X,
     for (int o = gw; o < n_out; o += nwaves) {
         // SwiGLU pack: output o <- gate row (o/16)*32 + o%16 and up row 16 below it
         const int row0 = swiglu ? (o >> 4) * 32 + (o & 15) : o;
-        const bf16_t* w0 = W + (long)row0 * ldw;
-        const bf16_t* w1 = w0 + 16 * ldw;
+        const elem_t* w0 = W + (long)row0 * ldw;
+        const elem_t* w1 = w0 + 16 * ldw;
         float a0[M], a1[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) a0[m] = a1[m] = 0.f;
@@ -123,18 +123,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ X,
             for (int m = 0; m < M; ++m) {
                 float t;
                 if (swiglu) {
-                    t = rbf(rbf(act_silu(rbf(a0[m]))) * rbf(a1[m]));
+                    t = rnd(rnd(act_silu(rnd(a0[m]))) * rnd(a1[m]));
                 } else {
                     t = a0[m];
-                    if (flags & EPI_BIAS) t += bf2f(bias[o]);
-                    if (!(flags & EPI_OUT_F32) || act || (flags & EPI_RESID)) t = rbf(t);
-                    if (act == 1) t = act_quick_gelu_bf16(t);
-                    else if (act == 2) t = rbf(act_gelu_erf(t));
+                    if (flags & EPI_BIAS) t += e2f(bias[o]);
+                    if (!(flags & EPI_OUT_F32) || act || (flags & EPI_RESID)) t = rnd(t);
+                    if (act == 1) t = act_quick_gelu_e(t);
+                    else if (act == 2) t = rnd(act_gelu_erf(t));
                     else if (act == 3) t = fmaxf(t, 0.f);
                 }
-                if (flags & EPI_RESID) t = rbf(bf2f(R[(long)m * ldr + o]) + t);
+                if (flags & EPI_RESID) t = rnd(e2f(R[(long)m * ldr + o]) + t);
                 if (flags & EPI_OUT_F32) ((float*)C)[(long)m * ldc + o] = t;
-                else ((bf16_t*)C)[(long)m * ldc + o] = f2bf(t);
+                else ((elem_t*)C)[(long)m * ldc + o] = f2e(t);
             }
         }
     }
@@ -157,8 +157,8 @@ int launch_gemv(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C,
     if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;
 #define ULL_GV(MM, UU)                                                                                                                    \
-    hipLaunchKernelGGL((gemv_kernel<MM, UU>), dim3(blocks), dim3(256), lds, st, (const bf16_t*)X, ldx, (const bf16_t*)W, ldw, C, ldc,     \
-                       (const bf16_t*)bias, (const bf16_t*)R, ldr, (int)N, (int)K, flags, n_out, (const bf16_t*)norm_w, eps, staged)
+    hipLaunchKernelGGL((gemv_kernel<MM, UU>), dim3(blocks), dim3(256), lds, st, (const elem_t*)X, ldx, (const elem_t*)W, ldw, C, ldc,     \
+                       (const elem_t*)bias, (const elem_t*)R, ldr, (int)N, (int)K, flags, n_out, (const elem_t*)norm_w, eps, staged)
     switch ((int)M) {
         case 1: ULL_GV(1, 8); break;
         case 2: ULL_GV(2, 4); break;
@@ -172,13 +172,13 @@ int launch_gemv(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C,
 }  // namespace
 
 // Same contract as ull_gemm_bf16 (flags, layouts) for M <= 4; K % 8 == 0.
-extern "C" int ull_gemv_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
+extern "C" int ULL_FN(ull_gemv_)(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                              int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream) {
     return launch_gemv(X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, nullptr, 0.f, stream);
 }
 
 // The same with the preceding LlamaRMSNorm fused in: C = epilogue(rmsnorm(X; norm_w, eps) * W^T).  M * K <= 16384.
-extern "C" int ull_gemv_rmsnorm_bf16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C,
+extern "C" int ULL_FN(ull_gemv_rmsnorm_)(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C,
                                      int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags,
                                      void* stream) {
     if (!norm_w) return ULL_ERR_ARG;

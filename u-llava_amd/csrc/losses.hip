@@ -36,15 +36,14 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const float* __restrict_
 }
 
 // out[0] = sum_i sum_c |p_ic - g_ic|;  out[1] = sum over boxes with x1 >= x0 and y1 >= y0 of (1 - GIoU(p_i, g_i))
-template <typename T>
-__global__ void box_loss_kernel(const T* __restrict__ pred, const float* __restrict__ gt, int n, float* __restrict__ out) {
+template <int DT>
+__global__ void box_loss_kernel(const void* __restrict__ pred, const float* __restrict__ gt, int n, float* __restrict__ out) {
     float l1 = 0.f, gl = 0.f;
     for (int i = threadIdx.x; i < n; i += 64) {
         float p[4], g[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if constexpr (sizeof(T) == 2) p[c] = bf2f(pred[i * 4 + c]);
-            else p[c] = pred[i * 4 + c];
+            p[c] = load_dt<DT>(pred, i * 4 + c);
             g[c] = gt[i * 4 + c];
             l1 += fabsf(p[c] - g[c]);
         }
@@ -72,12 +71,12 @@ extern "C" int ull_mask_loss_sums_f32(const void* logits, const void* target, in
     return ull_check_launch();
 }
 
-// pred [n, 4] bf16 (pred_is_bf16) or fp32, gt [n, 4] fp32, xyxy; out float[2] = {L1 sum, sum of (1 - GIoU) over well-formed predictions}.
-extern "C" int ull_box_losses_f32(const void* pred, int pred_is_bf16, const void* gt, int64_t n, void* out, void* stream) {
-    if (!pred || !gt || !out || n <= 0) return ULL_ERR_ARG;
-    if (pred_is_bf16)
-        hipLaunchKernelGGL(box_loss_kernel<bf16_t>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)pred, (const float*)gt, (int)n, (float*)out);
-    else
-        hipLaunchKernelGGL(box_loss_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)pred, (const float*)gt, (int)n, (float*)out);
+// pred [n, 4] of dtype pred_dtype (ULL_DT_*), gt [n, 4] fp32, xyxy; out float[2] = {L1 sum, sum of (1 - GIoU) over well-formed predictions}.
+extern "C" int ull_box_losses_f32(const void* pred, int pred_dtype, const void* gt, int64_t n, void* out, void* stream) {
+    if (!pred || !gt || !out || n <= 0 || pred_dtype < 0 || pred_dtype > 2) return ULL_ERR_ARG;
+    const hipStream_t st = (hipStream_t)stream;
+    if (pred_dtype == ULL_DT_BF16) hipLaunchKernelGGL(box_loss_kernel<ULL_DT_BF16>, dim3(1), dim3(64), 0, st, pred, (const float*)gt, (int)n, (float*)out);
+    else if (pred_dtype == ULL_DT_F16) hipLaunchKernelGGL(box_loss_kernel<ULL_DT_F16>, dim3(1), dim3(64), 0, st, pred, (const float*)gt, (int)n, (float*)out);
+    else hipLaunchKernelGGL(box_loss_kernel<ULL_DT_F32>, dim3(1), dim3(64), 0, st, pred, (const float*)gt, (int)n, (float*)out);
     return ull_check_launch();
 }

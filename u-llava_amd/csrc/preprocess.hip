@@ -46,9 +46,9 @@ __global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restr
 }
 
 // dst[c][y][x] = lut[c][src[top + y][left + x][c]] inside the copy_h x copy_w window, 0 outside (SAM's zero padding).
-template <typename T>
+template <int DT>
 __global__ __launch_bounds__(256) void u8_lut_chw_kernel(const uint8_t* __restrict__ src, int W, int C, int top, int left,
-                                                         const float* __restrict__ lut, T* __restrict__ dst, int OH, int OW, int copy_h,
+                                                         const float* __restrict__ lut, void* __restrict__ dst, int OH, int OW, int copy_h,
                                                          int copy_w) {
     __shared__ float tab[3 * 256];
     for (int i = threadIdx.x; i < C * 256; i += blockDim.x) tab[i] = lut[i];
@@ -59,8 +59,7 @@ __global__ __launch_bounds__(256) void u8_lut_chw_kernel(const uint8_t* __restri
     const int x = (int)(i % OW), y = (int)((i / OW) % OH), c = (int)(i / ((long)OW * OH));
     float v = 0.f;
     if (y < copy_h && x < copy_w) v = tab[c * 256 + src[((long)(top + y) * W + left + x) * C + c]];
-    if constexpr (sizeof(T) == 2) dst[i] = f2bf(v);
-    else dst[i] = v;
+    store_dt<DT>(dst, i, v);
 }
 
 // counts[m][0..5] += {inter0, inter1, out0, out1, tgt0, tgt1} of mask m, with out = logits > 0 and pixels whose target is
@@ -101,17 +100,18 @@ extern "C" int ull_resample_u8(const void* src, int64_t H, int64_t W, int64_t C,
 }
 
 extern "C" int ull_u8_lut_chw(const void* src, int64_t H, int64_t W, int64_t C, int64_t top, int64_t left, const void* lut, void* dst,
-                              int64_t OH, int64_t OW, int64_t copy_h, int64_t copy_w, int out_bf16, void* stream) {
-    if (!src || !lut || !dst || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return ULL_ERR_ARG;
+                              int64_t OH, int64_t OW, int64_t copy_h, int64_t copy_w, int out_dtype, void* stream) {
+    if (!src || !lut || !dst || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || out_dtype < 0 || out_dtype > 2) return ULL_ERR_ARG;
     if (C != 3 || top < 0 || left < 0 || copy_h > OH || copy_w > OW || top + copy_h > H || left + copy_w > W) return ULL_ERR_SHAPE;
     const long total = C * OH * OW;
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (out_bf16)
-        hipLaunchKernelGGL(u8_lut_chw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (int)W, (int)C, (int)top,
-                           (int)left, (const float*)lut, (bf16_t*)dst, (int)OH, (int)OW, (int)copy_h, (int)copy_w);
-    else
-        hipLaunchKernelGGL(u8_lut_chw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (int)W, (int)C, (int)top,
-                           (int)left, (const float*)lut, (float*)dst, (int)OH, (int)OW, (int)copy_h, (int)copy_w);
+#define ULL_LAUNCH_LUT(DT)                                                                                                              \
+    hipLaunchKernelGGL(u8_lut_chw_kernel<DT>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (int)W, (int)C, (int)top, \
+                       (int)left, (const float*)lut, dst, (int)OH, (int)OW, (int)copy_h, (int)copy_w)
+    if (out_dtype == ULL_DT_BF16) ULL_LAUNCH_LUT(ULL_DT_BF16);
+    else if (out_dtype == ULL_DT_F16) ULL_LAUNCH_LUT(ULL_DT_F16);
+    else ULL_LAUNCH_LUT(ULL_DT_F32);
+#undef ULL_LAUNCH_LUT
     return ull_check_launch();
 }
 

@@ -11,7 +11,7 @@
 namespace {
 
 // x [B, H, W, C] -> windows [B * nWh * nWw, ws * ws, C]; tokens beyond H/W are zero rows (F.pad in the reference)
-__global__ __launch_bounds__(256) void window_partition_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int H, int W, int C,
+__global__ __launch_bounds__(256) void window_partition_kernel(const elem_t* __restrict__ x, elem_t* __restrict__ out, int H, int W, int C,
                                                                int ws, int nWh, int nWw, long total_chunks) {
     const int cpr = C >> 3;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (long)gridDim.x * 256) {
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(256) void window_partition_kernel(const bf16_t* __r
 }
 
 // out[b, y, x, :] = bf16(shortcut[b, y, x, :] + win[window(b, y, x), :])
-__global__ __launch_bounds__(256) void window_unpartition_add_kernel(const bf16_t* __restrict__ win, const bf16_t* __restrict__ shortcut,
-                                                                     bf16_t* __restrict__ out, int H, int W, int C, int ws, int nWh, int nWw,
+__global__ __launch_bounds__(256) void window_unpartition_add_kernel(const elem_t* __restrict__ win, const elem_t* __restrict__ shortcut,
+                                                                     elem_t* __restrict__ out, int H, int W, int C, int ws, int nWh, int nWw,
                                                                      long total_chunks) {
     const int cpr = C >> 3;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (long)gridDim.x * 256) {
@@ -50,9 +50,9 @@ __global__ __launch_bounds__(256) void window_unpartition_add_kernel(const bf16_
 
 // One block per (head-instance bh, query s = (qy, qx)): rel_h[bh, s, kh] = bf16(sum_c q[c] * Rh[qy - kh + KH - 1][c]),
 // rel_w[bh, s, kw] = bf16(sum_c q[c] * Rw[qx - kw + KW - 1][c])   (q and k grids have the same size: no interpolation)
-__global__ __launch_bounds__(128) void relpos_kernel(const bf16_t* __restrict__ q, long q_bs, long q_hs, long q_ss,
-                                                     const bf16_t* __restrict__ rph, const bf16_t* __restrict__ rpw,
-                                                     bf16_t* __restrict__ out_h, bf16_t* __restrict__ out_w, int nH, int KH, int KW, int hd) {
+__global__ __launch_bounds__(128) void relpos_kernel(const elem_t* __restrict__ q, long q_bs, long q_hs, long q_ss,
+                                                     const elem_t* __restrict__ rph, const elem_t* __restrict__ rpw,
+                                                     elem_t* __restrict__ out_h, elem_t* __restrict__ out_w, int nH, int KH, int KW, int hd) {
     __shared__ float qs[256];
     const int S = KH * KW;
     const long blk = blockIdx.x;
@@ -60,16 +60,16 @@ __global__ __launch_bounds__(128) void relpos_kernel(const bf16_t* __restrict__ 
     const long bh = blk / S;
     const long b = bh / nH;
     const int h = (int)(bh % nH);
-    const bf16_t* qp = q + b * q_bs + (long)h * q_hs + (long)s * q_ss;
-    for (int c = threadIdx.x; c < hd; c += 128) qs[c] = bf2f(qp[c]);
+    const elem_t* qp = q + b * q_bs + (long)h * q_hs + (long)s * q_ss;
+    for (int c = threadIdx.x; c < hd; c += 128) qs[c] = e2f(qp[c]);
     __syncthreads();
     const int qy = s / KW, qx = s % KW;
     for (int t = threadIdx.x; t < KH + KW; t += 128) {
-        const bf16_t* r = (t < KH) ? rph + (long)(qy - t + KH - 1) * hd : rpw + (long)(qx - (t - KH) + KW - 1) * hd;
+        const elem_t* r = (t < KH) ? rph + (long)(qy - t + KH - 1) * hd : rpw + (long)(qx - (t - KH) + KW - 1) * hd;
         float acc = 0.f;
-        for (int c = 0; c < hd; ++c) acc += qs[c] * bf2f(r[c]);
-        if (t < KH) out_h[(bh * S + s) * KH + t] = f2bf(acc);
-        else out_w[(bh * S + s) * KW + (t - KH)] = f2bf(acc);
+        for (int c = 0; c < hd; ++c) acc += qs[c] * e2f(r[c]);
+        if (t < KH) out_h[(bh * S + s) * KH + t] = f2e(acc);
+        else out_w[(bh * S + s) * KW + (t - KH)] = f2e(acc);
     }
 }
 
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(128) void relpos_kernel(const bf16_t* __restrict__ 
 //   u = bf16(mean(x)); d = bf16(x - u); s = bf16(mean(bf16(d*d))); y = bf16(d / bf16(sqrt(bf16(s + eps))));
 //   out = bf16(bf16(w * y) + b)  [; out = bf16(gelu(out))]
 // One row per `lpr` lanes (C/8 chunks, C <= 512).
-__global__ __launch_bounds__(256) void layernorm2d_cl_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                             const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long rows, int C,
+__global__ __launch_bounds__(256) void layernorm2d_cl_kernel(const elem_t* __restrict__ x, const elem_t* __restrict__ w,
+                                                             const elem_t* __restrict__ b, elem_t* __restrict__ y, long rows, int C,
                                                              float eps, int lpr, int gelu) {
     const int lane = threadIdx.x & 63;
     const int sub = lane & (lpr - 1);
@@ -92,22 +92,22 @@ __global__ __launch_bounds__(256) void layernorm2d_cl_kernel(const bf16_t* __res
     float s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1 += v[j];
-    const float u = rbf(group_sum(s1, lpr) / (float)C);
+    const float u = rnd(group_sum(s1, lpr) / (float)C);
     float d[8], s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        d[j] = ok ? rbf(v[j] - u) : 0.f;
-        s2 += rbf(d[j] * d[j]);
+        d[j] = ok ? rnd(v[j] - u) : 0.f;
+        s2 += rnd(d[j] * d[j]);
     }
-    const float var = rbf(group_sum(s2, lpr) / (float)C);
-    const float den = rbf(sqrtf(rbf(var + eps)));
+    const float var = rnd(group_sum(s2, lpr) / (float)C);
+    const float den = rnd(sqrtf(rnd(var + eps)));
     if (!ok) return;
     float wv[8], bv[8], o[8];
     unpack8(*(const uint4*)(w + sub * 8), wv);
     unpack8(*(const uint4*)(b + sub * 8), bv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        float t = rbf(rbf(wv[j] * rbf(d[j] / den)) + bv[j]);
+        float t = rnd(rnd(wv[j] * rnd(d[j] / den)) + bv[j]);
         if (gelu) t = act_gelu_erf(t);
         o[j] = t;
     }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void layernorm2d_cl_kernel(const bf16_t* __res
 
 // x [B, H, W, C] channels-last -> cols [B*H*W, 9*C], column block (ky*3+kx) holds the C channels of the neighbour
 // (y+ky-1, x+kx-1), zeros outside the image (conv padding=1).  Weight is packed host-side in the same (ky,kx,ci) order.
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int H, int W, int C,
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const elem_t* __restrict__ x, elem_t* __restrict__ out, int H, int W, int C,
                                                         long total_chunks) {
     const int cpr = C >> 3;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (long)gridDim.x * 256) {
@@ -134,32 +134,34 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const bf16_t* __restrict
 
 // masks[n, t, Y, X] = bf16( sum_c hyper[n, t, c] * up[n, pixel(Y, X), c] ), up given in the blocked layout produced by
 // the two transposed convolutions run as GEMMs:  up[n][y][x][d1 = dy*2+dx][d2 = dy2*2+dx2][c], Y = 4y + 2dy + dy2, X = 4x + 2dx + dx2.
-__global__ __launch_bounds__(256) void mask_matmul_kernel(const bf16_t* __restrict__ hyper, const bf16_t* __restrict__ up,
-                                                          bf16_t* __restrict__ masks, int T, int Cc, int G, long total) {
+__global__ __launch_bounds__(256) void mask_matmul_kernel(const elem_t* __restrict__ hyper, const elem_t* __restrict__ up,
+                                                          elem_t* __restrict__ masks, int T, int Cc, int G, long total) {
     // total = n * G*G*16 output pixels; one thread per output pixel, all T masks
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int d2 = (int)(i & 3), d1 = (int)((i >> 2) & 3);
         const long cell = i >> 4;                        // n*G*G + y*G + x
         const int xx = (int)(cell % G), y = (int)((cell / G) % G);
         const long n = cell / ((long)G * G);
-        const bf16_t* u = up + i * Cc;
+        const elem_t* u = up + i * Cc;
         float uv[32];
         for (int c0 = 0; c0 < Cc; c0 += 8) unpack8(*(const uint4*)(u + c0), uv + c0);
         const int Y = 4 * y + 2 * (d1 >> 1) + (d2 >> 1), X = 4 * xx + 2 * (d1 & 1) + (d2 & 1);
         const int HW = 4 * G;
         for (int t = 0; t < T; ++t) {
-            const bf16_t* hp = hyper + (n * T + t) * Cc;
+            const elem_t* hp = hyper + (n * T + t) * Cc;
             float acc = 0.f;
-            for (int c = 0; c < Cc; ++c) acc += bf2f(hp[c]) * uv[c];
-            masks[((n * T + t) * HW + Y) * (long)HW + X] = f2bf(acc);
+            for (int c = 0; c < Cc; ++c) acc += e2f(hp[c]) * uv[c];
+            masks[((n * T + t) * HW + Y) * (long)HW + X] = f2e(acc);
         }
     }
 }
 
 // F.interpolate(mode="bilinear", align_corners=False) in fp32: src = max((dst + 0.5) * (in / out) - 0.5, 0).
-// Input image i: bf16 or fp32 at `in + i * in_img_stride`, rows `in_row_stride` apart, logical size in_h x in_w (a crop).
-template <typename TIN>
-__global__ __launch_bounds__(256) void bilinear_kernel(const TIN* __restrict__ in, long in_img_stride, long in_row_stride, int in_h, int in_w,
+// Input image i: elements of dtype DT (ULL_DT_*) at `in + i * in_img_stride`, rows `in_row_stride` apart, logical size in_h x in_w (a crop).
+// (dtype-coded, so it exists once: only the bf16 build of this file defines it)
+#ifndef ULL_ELEM_F16
+template <int DT>
+__global__ __launch_bounds__(256) void bilinear_kernel(const void* __restrict__ in, long in_img_stride, long in_row_stride, int in_h, int in_w,
                                                        float* __restrict__ out, int out_h, int out_w, long total) {
     const float sh = (float)in_h / (float)out_h, sw = (float)in_w / (float)out_w;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -172,16 +174,14 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const TIN* __restrict__ i
         const int y1 = y0 + (y0 < in_h - 1 ? 1 : 0), x1 = x0 + (x0 < in_w - 1 ? 1 : 0);
         const float ly = fy - (float)y0, lx = fx - (float)x0;
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const TIN* p = in + n * in_img_stride;
-        auto ld = [&](int yy, int xx) -> float {
-            if constexpr (sizeof(TIN) == 2) return bf2f(p[(long)yy * in_row_stride + xx]);
-            else return p[(long)yy * in_row_stride + xx];
-        };
+        const long base = n * in_img_stride;
+        auto ld = [&](int yy, int xx) -> float { return load_dt<DT>(in, base + (long)yy * in_row_stride + xx); };
         const float t0 = __fadd_rn(__fmul_rn(hx, ld(y0, x0)), __fmul_rn(lx, ld(y0, x1)));
         const float t1 = __fadd_rn(__fmul_rn(hx, ld(y1, x0)), __fmul_rn(lx, ld(y1, x1)));
         out[i] = __fadd_rn(__fmul_rn(hy, t0), __fmul_rn(ly, t1));
     }
 }
+#endif
 
 inline unsigned nblocks(long total, long cap = 16384) {
     long b = (total + 255) / 256;
@@ -190,37 +190,37 @@ inline unsigned nblocks(long total, long cap = 16384) {
 
 }  // namespace
 
-extern "C" int ull_window_partition_bf16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream) {
+extern "C" int ULL_FN(ull_window_partition_)(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream) {
     if (!x || !out || B <= 0 || ws <= 0) return ULL_ERR_ARG;
     if (C & 7) return ULL_ERR_SHAPE;
     const int nWh = (int)((H + ws - 1) / ws), nWw = (int)((W + ws - 1) / ws);
     const long total = B * nWh * nWw * ws * ws * (C >> 3);
-    hipLaunchKernelGGL(window_partition_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, (int)H,
+    hipLaunchKernelGGL(window_partition_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (elem_t*)out, (int)H,
                        (int)W, (int)C, (int)ws, nWh, nWw, total);
     return ull_check_launch();
 }
 
-extern "C" int ull_window_unpartition_add_bf16(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C,
+extern "C" int ULL_FN(ull_window_unpartition_add_)(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C,
                                                int64_t ws, void* stream) {
     if (!win || !shortcut || !out || B <= 0 || ws <= 0) return ULL_ERR_ARG;
     if (C & 7) return ULL_ERR_SHAPE;
     const int nWh = (int)((H + ws - 1) / ws), nWw = (int)((W + ws - 1) / ws);
     const long total = B * H * W * (C >> 3);
-    hipLaunchKernelGGL(window_unpartition_add_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)win,
-                       (const bf16_t*)shortcut, (bf16_t*)out, (int)H, (int)W, (int)C, (int)ws, nWh, nWw, total);
+    hipLaunchKernelGGL(window_unpartition_add_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)win,
+                       (const elem_t*)shortcut, (elem_t*)out, (int)H, (int)W, (int)C, (int)ws, nWh, nWw, total);
     return ull_check_launch();
 }
 
-extern "C" int ull_sam_relpos_bf16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w,
+extern "C" int ULL_FN(ull_sam_relpos_)(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w,
                                    void* out_h, void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream) {
     if (!q || !rel_pos_h || !rel_pos_w || !out_h || !out_w || NB <= 0) return ULL_ERR_ARG;
     if (hd > 256 || KH + KW > 4096) return ULL_ERR_SHAPE;
-    hipLaunchKernelGGL(relpos_kernel, dim3((unsigned)(NB * nH * KH * KW)), dim3(128), 0, (hipStream_t)stream, (const bf16_t*)q, q_bs, q_hs, q_ss,
-                       (const bf16_t*)rel_pos_h, (const bf16_t*)rel_pos_w, (bf16_t*)out_h, (bf16_t*)out_w, (int)nH, (int)KH, (int)KW, (int)hd);
+    hipLaunchKernelGGL(relpos_kernel, dim3((unsigned)(NB * nH * KH * KW)), dim3(128), 0, (hipStream_t)stream, (const elem_t*)q, q_bs, q_hs, q_ss,
+                       (const elem_t*)rel_pos_h, (const elem_t*)rel_pos_w, (elem_t*)out_h, (elem_t*)out_w, (int)nH, (int)KH, (int)KW, (int)hd);
     return ull_check_launch();
 }
 
-extern "C" int ull_layernorm2d_cl_bf16(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu,
+extern "C" int ULL_FN(ull_layernorm2d_cl_)(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu,
                                        void* stream) {
     if (!x || !w || !b || !y || rows <= 0) return ULL_ERR_ARG;
     if ((C & 7) || C > 512) return ULL_ERR_SHAPE;
@@ -228,37 +228,40 @@ extern "C" int ull_layernorm2d_cl_bf16(const void* x, const void* w, const void*
     while (lpr < (C >> 3)) lpr <<= 1;
     const long rows_per_block = 4 * (64 / lpr);
     hipLaunchKernelGGL(layernorm2d_cl_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, (int)C, eps, lpr, gelu);
+                       (const elem_t*)x, (const elem_t*)w, (const elem_t*)b, (elem_t*)y, rows, (int)C, eps, lpr, gelu);
     return ull_check_launch();
 }
 
-extern "C" int ull_im2col3x3_bf16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+extern "C" int ULL_FN(ull_im2col3x3_)(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
     if (!x || !out || B <= 0) return ULL_ERR_ARG;
     if (C & 7) return ULL_ERR_SHAPE;
     const long total = B * H * W * 9 * (C >> 3);
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, (int)H, (int)W,
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (elem_t*)out, (int)H, (int)W,
                        (int)C, total);
     return ull_check_launch();
 }
 
-extern "C" int ull_mask_matmul_bf16(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream) {
+extern "C" int ULL_FN(ull_mask_matmul_)(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream) {
     if (!hyper || !up || !masks || n <= 0) return ULL_ERR_ARG;
     if (C != 32 && C != 16 && C != 8) return ULL_ERR_SHAPE;
     const long total = n * G * G * 16;
-    hipLaunchKernelGGL(mask_matmul_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hyper, (const bf16_t*)up,
-                       (bf16_t*)masks, (int)T, (int)C, (int)G, total);
+    hipLaunchKernelGGL(mask_matmul_kernel, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)hyper, (const elem_t*)up,
+                       (elem_t*)masks, (int)T, (int)C, (int)G, total);
     return ull_check_launch();
 }
 
-extern "C" int ull_bilinear_f32(const void* in, int in_is_bf16, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w,
+#ifndef ULL_ELEM_F16
+extern "C" int ull_bilinear_f32(const void* in, int in_dtype, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w,
                                 void* out, int64_t n, int64_t out_h, int64_t out_w, void* stream) {
-    if (!in || !out || n <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return ULL_ERR_ARG;
+    if (!in || !out || n <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || in_dtype < 0 || in_dtype > 2) return ULL_ERR_ARG;
     const long total = n * out_h * out_w;
-    if (in_is_bf16)
-        hipLaunchKernelGGL(bilinear_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, in_img_stride,
-                           in_row_stride, (int)in_h, (int)in_w, (float*)out, (int)out_h, (int)out_w, total);
-    else
-        hipLaunchKernelGGL(bilinear_kernel<float>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)in, in_img_stride,
-                           in_row_stride, (int)in_h, (int)in_w, (float*)out, (int)out_h, (int)out_w, total);
+#define ULL_LAUNCH_BIL(DT)                                                                                                             \
+    hipLaunchKernelGGL(bilinear_kernel<DT>, dim3(nblocks(total)), dim3(256), 0, (hipStream_t)stream, in, in_img_stride, in_row_stride, \
+                       (int)in_h, (int)in_w, (float*)out, (int)out_h, (int)out_w, total)
+    if (in_dtype == ULL_DT_BF16) ULL_LAUNCH_BIL(ULL_DT_BF16);
+    else if (in_dtype == ULL_DT_F16) ULL_LAUNCH_BIL(ULL_DT_F16);
+    else ULL_LAUNCH_BIL(ULL_DT_F32);
+#undef ULL_LAUNCH_BIL
     return ull_check_launch();
 }
+#endif

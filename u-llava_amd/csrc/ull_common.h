@@ -4,38 +4,92 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits; all HBM activations / weights are bf16
+// ---- element type of the 16-bit tensors: a BUILD-TIME parameter of the translation unit --------------------------------------
+// Every dtype-dependent .hip file is compiled twice (Makefile): as-is for bfloat16 (entry points ull_*_bf16) and with
+// -DULL_ELEM_F16 for IEEE binary16 (entry points ull_*_f16; the reference's `--dtype fp16`, inference_ullava.py:26,164-168).
+// The kernels are written against elem_t / e2f / f2e / rnd / pack2e / pk_lo / pk_hi / mfma16 only, so both builds keep the same
+// rounding points (every torch op boundary of the reference's 16-bit graph) -- only the 16-bit format differs.
+typedef uint16_t elem_t;   // raw bits of one 16-bit element (bfloat16 or binary16); all HBM activations / weights
 
-using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;  // one MFMA A/B operand (4 VGPRs)
 using f32x4_t = __attribute__((ext_vector_type(4))) float;    // 16x16 MFMA accumulator
 using f32x16_t = __attribute__((ext_vector_type(16))) float;  // 32x32 MFMA accumulator
 
 #define ULL_DEV __device__ __forceinline__
+#define ULL_CAT_(a, b) a##b
+#define ULL_CAT(a, b) ULL_CAT_(a, b)
 
-// ---- bf16 <-> f32 (round-to-nearest-even, identical to torch's c10::BFloat16) -------------
-ULL_DEV float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// f32 -> bf16 goes through the native __bf16 type so hipcc emits gfx950's v_cvt_pk_bf16_f32 (IEEE round-to-nearest-even,
-// two values per instruction) instead of a ~8-instruction integer sequence; bf16 -> f32 is a 16-bit shift.
-typedef __bf16 bf16x2_native_t __attribute__((ext_vector_type(2)));
-ULL_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
-// Round an fp32 value through bf16: this is how the kernels reproduce the rounding points of the
-// reference's bf16 PyTorch graph (every torch op boundary stores bf16) inside fused epilogues.
-ULL_DEV float rbf(float f) { return (float)(__bf16)f; }
+// both formats are always available by name (the byte-level pre/post-processing and loss kernels take a dtype code)
+#define ULL_DT_F32 0
+#define ULL_DT_BF16 1
+#define ULL_DT_F16 2
+ULL_DEV float bf16_bits_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+ULL_DEV float f16_bits_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// f32 -> 16 bit goes through the native types so hipcc emits gfx950's v_cvt_pk_bf16_f32 / v_cvt_f16_f32 (IEEE round-to-nearest-even,
+// identical to torch's c10::BFloat16 / c10::Half conversions)
+ULL_DEV uint16_t f32_to_bf16_bits(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+ULL_DEV uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 
-ULL_DEV uint32_t pack2bf(float lo, float hi) {
-    const bf16x2_native_t v = {(__bf16)lo, (__bf16)hi};
+// dtype-coded access for the kernels that are compiled once and take ULL_DT_* at run time (bilinear, box losses, u8 -> CHW)
+template <int DT> ULL_DEV float load_dt(const void* p, long i) {
+    if constexpr (DT == ULL_DT_F32) return ((const float*)p)[i];
+    else if constexpr (DT == ULL_DT_BF16) return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+    else return f16_bits_to_f32(((const uint16_t*)p)[i]);
+}
+template <int DT> ULL_DEV void store_dt(void* p, long i, float v) {
+    if constexpr (DT == ULL_DT_F32) ((float*)p)[i] = v;
+    else if constexpr (DT == ULL_DT_BF16) ((uint16_t*)p)[i] = f32_to_bf16_bits(v);
+    else ((uint16_t*)p)[i] = f32_to_f16_bits(v);
+}
+
+#ifdef ULL_ELEM_F16
+// ------------------------------------------------------------------ IEEE binary16 build
+#define ULL_FN(base) ULL_CAT(base, f16)                        // ULL_FN(ull_gemm_) -> ull_gemm_f16
+using mfma_ab_t = __attribute__((ext_vector_type(8))) _Float16;   // one MFMA A/B operand (4 VGPRs)
+typedef _Float16 elem2_native_t __attribute__((ext_vector_type(2)));
+constexpr uint16_t ELEM_NEG_INF = 0xFC00;
+constexpr uint16_t ELEM_MIN = 0xFBFF;                          // torch.finfo(torch.float16).min = -65504
+#define ELEM_MIN_F (-65504.0f)
+ULL_DEV float e2f(elem_t v) { return f16_bits_to_f32(v); }
+ULL_DEV elem_t f2e(float f) { return f32_to_f16_bits(f); }
+ULL_DEV float rnd(float f) { return (float)(_Float16)f; }
+ULL_DEV uint32_t pack2e(float lo, float hi) {
+    const elem2_native_t v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
+// low / high element of a packed pair as fp32
+ULL_DEV float pk_lo(uint32_t v) { return (float)__builtin_bit_cast(elem2_native_t, v)[0]; }
+ULL_DEV float pk_hi(uint32_t v) { return (float)__builtin_bit_cast(elem2_native_t, v)[1]; }
+#else
+// ------------------------------------------------------------------ bfloat16 build
+#define ULL_FN(base) ULL_CAT(base, bf16)                       // ULL_FN(ull_gemm_) -> ull_gemm_bf16
+using mfma_ab_t = __attribute__((ext_vector_type(8))) __bf16;  // one MFMA A/B operand (4 VGPRs)
+typedef __bf16 elem2_native_t __attribute__((ext_vector_type(2)));
+constexpr uint16_t ELEM_NEG_INF = 0xFF80;
+constexpr uint16_t ELEM_MIN = 0xFF7F;                          // torch.finfo(torch.bfloat16).min: the eager additive mask value
+#define ELEM_MIN_F (-3.3895313892515355e38f)
+ULL_DEV float e2f(elem_t v) { return bf16_bits_to_f32(v); }
+ULL_DEV elem_t f2e(float f) { return f32_to_bf16_bits(f); }
+// Round an fp32 value through the element type: this is how the kernels reproduce the rounding points of the reference's 16-bit
+// PyTorch graph (every torch op boundary stores a 16-bit tensor) inside fused epilogues.
+ULL_DEV float rnd(float f) { return (float)(__bf16)f; }
+ULL_DEV uint32_t pack2e(float lo, float hi) {
+    const elem2_native_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+ULL_DEV float pk_lo(uint32_t v) { return __uint_as_float(v << 16); }           // bf16 -> fp32 is a 16-bit shift
+ULL_DEV float pk_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+#endif
+
 ULL_DEV void unpack8(const uint4& v, float* f) {
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    f[0] = pk_lo(v.x); f[1] = pk_hi(v.x);
+    f[2] = pk_lo(v.y); f[3] = pk_hi(v.y);
+    f[4] = pk_lo(v.z); f[5] = pk_hi(v.z);
+    f[6] = pk_lo(v.w); f[7] = pk_hi(v.w);
 }
 ULL_DEV uint4 pack8(const float* f) {
     uint4 v;
-    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
-    v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    v.x = pack2e(f[0], f[1]); v.y = pack2e(f[2], f[3]);
+    v.z = pack2e(f[4], f[5]); v.w = pack2e(f[6], f[7]);
     return v;
 }
 
@@ -61,33 +115,41 @@ ULL_DEV float group_max(float v, int w) {
 }
 
 // ---- MFMA wrappers ------------------------------------------------------------------------
-// v_mfma_f32_16x16x32_bf16: D[16x16] += A[16x32] * B[32x16].
+// v_mfma_f32_16x16x32_{bf16,f16}: D[16x16] += A[16x32] * B[32x16].
 //   operand A: lane l holds A[row = l&15][k = 8*(l>>4) + j], j = 0..7
 //   operand B: lane l holds B[k = 8*(l>>4) + j][col = l&15]
 //   C/D      : lane l, reg r holds D[row = 4*(l>>4) + r][col = l&15]
 // (the k <-> (lane group, j) map is the same for A and B, so any K-contiguous 16-byte load that is
 //  identical for both operands is correct by construction.)
 ULL_DEV f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#ifdef ULL_ELEM_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_ab_t, a), __builtin_bit_cast(mfma_ab_t, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_ab_t, a), __builtin_bit_cast(mfma_ab_t, b), c, 0, 0, 0);
+#endif
 }
 
-// v_mfma_f32_32x32x16_bf16: D[32x32] += A[32x16] * B[16x32].
+// v_mfma_f32_32x32x16_{bf16,f16}: D[32x32] += A[32x16] * B[16x32].
 //   operand A: lane l holds A[row = l&31][k = 8*(l>>5) + j];  operand B: lane l holds B[k = 8*(l>>5) + j][col = l&31]
 //   C/D      : lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
 ULL_DEV f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#ifdef ULL_ELEM_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mfma_ab_t, a), __builtin_bit_cast(mfma_ab_t, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_ab_t, a), __builtin_bit_cast(mfma_ab_t, b), c, 0, 0, 0);
+#endif
 }
 
-// ---- activations (computed in fp32 on a bf16-rounded input, like torch's bf16 CPU/GPU kernels)
+// ---- activations (computed in fp32 on a 16-bit-rounded input, like torch's bf16 / fp16 CPU and GPU kernels)
 ULL_DEV float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 ULL_DEV float act_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 ULL_DEV float act_silu(float x) { return x / (1.0f + __expf(-x)); }
-// transformers QuickGELUActivation on a bf16 tensor: input * sigmoid(1.702 * input) has THREE bf16
-// roundings (the scaled input, the sigmoid, the product).
-ULL_DEV float act_quick_gelu_bf16(float t) {
-    float u = rbf(1.702f * t);
-    float s = rbf(act_sigmoid(u));
-    return rbf(t * s);
+// transformers QuickGELUActivation on a 16-bit tensor: input * sigmoid(1.702 * input) has THREE roundings
+// (the scaled input, the sigmoid, the product).
+ULL_DEV float act_quick_gelu_e(float t) {
+    float u = rnd(1.702f * t);
+    float s = rnd(act_sigmoid(u));
+    return rnd(t * s);
 }
 
 // C-ABI status codes (mirrored in include/ullava_hip.h)

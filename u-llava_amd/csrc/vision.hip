@@ -13,7 +13,7 @@ namespace {
 // [C*ps*ps, Kp) are zero so the GEMM can use K = Kp (multiple of 64).
 // Fast path (even patch size, W % 8 == 0): one thread per 8-pixel chunk of an image row -> one coalesced 16-byte load and four
 // 4-byte stores (a dword never straddles a patch because ps and the chunk start are even).
-__global__ __launch_bounds__(256) void im2col_vec_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int C, int Hh, int Ww, int ps,
+__global__ __launch_bounds__(256) void im2col_vec_kernel(const elem_t* __restrict__ img, elem_t* __restrict__ out, int C, int Hh, int Ww, int ps,
                                                          int gw, int Kp, long total_chunks, int K, long pad_dwords) {
     const int cpr = Ww >> 3;
     const int padw = (Kp - K) >> 1;
@@ -43,13 +43,13 @@ __global__ __launch_bounds__(256) void im2col_vec_kernel(const bf16_t* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int C, int Hh, int Ww, int ps,
+__global__ __launch_bounds__(256) void im2col_kernel(const elem_t* __restrict__ img, elem_t* __restrict__ out, int C, int Hh, int Ww, int ps,
                                                      int gh, int gw, int Kp, long total) {
     const int K = C * ps * ps;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int k = (int)(i % Kp);
         const long row = i / Kp;
-        bf16_t v = 0;
+        elem_t v = 0;
         if (k < K) {
             const int kx = k % ps, ky = (k / ps) % ps, c = k / (ps * ps);
             const int px = (int)(row % gw), py = (int)((row / gw) % gh);
@@ -95,10 +95,10 @@ __global__ void mm_spans_kernel(const int64_t* __restrict__ ids, int B, int S, i
 }
 
 // out[b, s, :] = image/video feature row if s lies in the placeholder span of sample b, else table[ids[b, s]]
-__global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table,
-                                                           const bf16_t* __restrict__ img_feat, int n_img_tok, int img_pitch, int img_off,
-                                                           const bf16_t* __restrict__ vid_feat, int n_vid_tok,
-                                                           const int32_t* __restrict__ spans, bf16_t* __restrict__ out, int S, int D,
+__global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __restrict__ ids, const elem_t* __restrict__ table,
+                                                           const elem_t* __restrict__ img_feat, int n_img_tok, int img_pitch, int img_off,
+                                                           const elem_t* __restrict__ vid_feat, int n_vid_tok,
+                                                           const int32_t* __restrict__ spans, elem_t* __restrict__ out, int S, int D,
                                                            long rows, long vocab) {
     const int cpr = D >> 3;                      // 16-byte chunks per row
     const int rows_per_block = 256 / min(cpr, 256);
@@ -108,47 +108,47 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const int64_t* __rest
     const int b = (int)(row / S), s = (int)(row % S);
     long id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);     // never read outside the table (ull_mm_spans reports such ids)
-    const bf16_t* src = table + id * D;
+    const elem_t* src = table + id * D;
     if (spans != nullptr) {
         const int kind = spans[b * 4], pos = spans[b * 4 + 1], idx = spans[b * 4 + 2];
         if (kind == 1 && img_feat != nullptr && s > pos && s <= pos + n_img_tok) src = img_feat + ((long)idx * img_pitch + img_off + (s - pos - 1)) * D;
         if (kind == 2 && vid_feat != nullptr && s > pos && s <= pos + n_vid_tok) src = vid_feat + ((long)idx * n_vid_tok + (s - pos - 1)) * D;
     }
-    bf16_t* dst = out + row * D;
+    elem_t* dst = out + row * D;
     for (int c = threadIdx.x % lanes_per_row; c < cpr; c += lanes_per_row) *(uint4*)(dst + c * 8) = *(const uint4*)(src + c * 8);
 }
 
 // f [b, t, pitch, d] (tokens off..off+n of every frame are the patches) -> out [b, t + n, d]: rows [0, t) = mean over patches (temporal), rows [t, t+n) = mean over
 // frames (spatial); fp32 accumulate, one bf16 rounding (torch.mean on a bf16 tensor).
-__global__ __launch_bounds__(256) void video_pool_kernel(const bf16_t* __restrict__ f, bf16_t* __restrict__ out, int T, int N, int D,
+__global__ __launch_bounds__(256) void video_pool_kernel(const elem_t* __restrict__ f, elem_t* __restrict__ out, int T, int N, int D,
                                                          int pitch, int off) {
     const int b = blockIdx.y;
     const int r = blockIdx.x;                    // output row in [0, T + N)
-    const bf16_t* fb = f + ((long)b * T * pitch + off) * D;
-    bf16_t* o = out + ((long)b * (T + N) + r) * D;
+    const elem_t* fb = f + ((long)b * T * pitch + off) * D;
+    elem_t* o = out + ((long)b * (T + N) + r) * D;
     for (int d = threadIdx.x; d < D; d += 256) {
         float acc = 0.f;
         if (r < T) {
-            for (int n = 0; n < N; ++n) acc += bf2f(fb[((long)r * pitch + n) * D + d]);
-            o[d] = f2bf(acc / (float)N);
+            for (int n = 0; n < N; ++n) acc += e2f(fb[((long)r * pitch + n) * D + d]);
+            o[d] = f2e(acc / (float)N);
         } else {
             const int n = r - T;
-            for (int t = 0; t < T; ++t) acc += bf2f(fb[((long)t * pitch + n) * D + d]);
-            o[d] = f2bf(acc / (float)T);
+            for (int t = 0; t < T; ++t) acc += e2f(fb[((long)t * pitch + n) * D + d]);
+            o[d] = f2e(acc / (float)T);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, long lds_, const int64_t* __restrict__ idx,
-                                                          bf16_t* __restrict__ dst, long ldd, int D) {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const elem_t* __restrict__ src, long lds_, const int64_t* __restrict__ idx,
+                                                          elem_t* __restrict__ dst, long ldd, int D) {
     const long r = blockIdx.x;
-    const bf16_t* s = src + idx[r] * lds_;
-    bf16_t* d = dst + r * ldd;
+    const elem_t* s = src + idx[r] * lds_;
+    elem_t* d = dst + r * ldd;
     for (int c = threadIdx.x; c < (D >> 3); c += 256) *(uint4*)(d + c * 8) = *(const uint4*)(s + c * 8);
 }
 
 // out = bf16(a + b[row % b_rows])   (row-broadcast add: residual adds, + positional tables)
-__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void add_rows_kernel(const elem_t* __restrict__ a, const elem_t* __restrict__ b, elem_t* __restrict__ out,
                                                        long rows, int D, long b_rows) {
     const int cpr = D >> 3;
     const long total = rows * cpr;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict_
 
 }  // namespace
 
-extern "C" int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp,
+extern "C" int ULL_FN(ull_im2col_)(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp,
                                void* stream) {
     if (!img || !out || n_img <= 0 || ps <= 0) return ULL_ERR_ARG;
     if (H % ps || W % ps || Kp < C * ps * ps) return ULL_ERR_SHAPE;
@@ -180,15 +180,16 @@ extern "C" int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_
         const long pad_dwords = rows * ((Kp - K) >> 1);                      // K and Kp are even: the zero tail is whole dwords
         const long work = chunks + pad_dwords;
         hipLaunchKernelGGL(im2col_vec_kernel, dim3((unsigned)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384)), dim3(256), 0,
-                           (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, (int)C, (int)H, (int)W, (int)ps, gw, (int)Kp, chunks, K,
+                           (hipStream_t)stream, (const elem_t*)img, (elem_t*)out, (int)C, (int)H, (int)W, (int)ps, gw, (int)Kp, chunks, K,
                            pad_dwords);
         return ull_check_launch();
     }
-    hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, (int)C, (int)H, (int)W,
+    hipLaunchKernelGGL(im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)img, (elem_t*)out, (int)C, (int)H, (int)W,
                        (int)ps, gh, gw, (int)Kp, total);
     return ull_check_launch();
 }
 
+#ifndef ULL_ELEM_F16      // integer work: exists once (bf16 build of this file)
 extern "C" int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_start, int64_t img_end, int64_t vid_start, int64_t vid_end,
                             int64_t vocab, void* spans, void* stream) {
     if (!ids || !spans || B <= 0 || S <= 0) return ULL_ERR_ARG;
@@ -198,8 +199,9 @@ extern "C" int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_s
                        (int)img_end, (int)vid_start, (int)vid_end, (long)vocab, (int32_t*)spans);
     return ull_check_launch();
 }
+#endif
 
-extern "C" int ull_embed_splice_bf16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch,
+extern "C" int ULL_FN(ull_embed_splice_)(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch,
                                      int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B,
                                      int64_t S, int64_t D, int64_t vocab, void* stream) {
     if (!ids || !table || !out || B <= 0 || S <= 0 || vocab <= 0) return ULL_ERR_ARG;
@@ -208,36 +210,36 @@ extern "C" int ull_embed_splice_bf16(const void* ids, const void* table, const v
     const int cpr = (int)(D >> 3);
     const int rows_per_block = 256 / (cpr < 256 ? cpr : 256);
     const unsigned blocks = (unsigned)((rows + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(embed_splice_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, (const bf16_t*)table,
-                       (const bf16_t*)img_feat, (int)n_img_tok, (int)img_pitch, (int)img_off, (const bf16_t*)vid_feat, (int)n_vid_tok, (const int32_t*)spans,
-                       (bf16_t*)out, (int)S, (int)D, rows, (long)vocab);
+    hipLaunchKernelGGL(embed_splice_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, (const elem_t*)table,
+                       (const elem_t*)img_feat, (int)n_img_tok, (int)img_pitch, (int)img_off, (const elem_t*)vid_feat, (int)n_vid_tok, (const int32_t*)spans,
+                       (elem_t*)out, (int)S, (int)D, rows, (long)vocab);
     return ull_check_launch();
 }
 
-extern "C" int ull_video_pool_bf16(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch,
+extern "C" int ULL_FN(ull_video_pool_)(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch,
                                    int64_t tok_off, void* stream) {
     if (!f || !out || B <= 0 || T <= 0 || N <= 0 || D <= 0) return ULL_ERR_ARG;
-    hipLaunchKernelGGL(video_pool_kernel, dim3((unsigned)(T + N), (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)f,
-                       (bf16_t*)out, (int)T, (int)N, (int)D, (int)tok_pitch, (int)tok_off);
+    hipLaunchKernelGGL(video_pool_kernel, dim3((unsigned)(T + N), (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const elem_t*)f,
+                       (elem_t*)out, (int)T, (int)N, (int)D, (int)tok_pitch, (int)tok_off);
     return ull_check_launch();
 }
 
-extern "C" int ull_gather_rows_bf16(const void* src, int64_t lds_, const void* idx, void* dst, int64_t ldd, int64_t n, int64_t D,
+extern "C" int ULL_FN(ull_gather_rows_)(const void* src, int64_t lds_, const void* idx, void* dst, int64_t ldd, int64_t n, int64_t D,
                                     void* stream) {
     if (!src || !idx || !dst) return ULL_ERR_ARG;
     if (n == 0) return ULL_OK;
     if ((D & 7) || (lds_ & 7) || (ldd & 7)) return ULL_ERR_SHAPE;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, lds_, (const int64_t*)idx,
-                       (bf16_t*)dst, ldd, (int)D);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const elem_t*)src, lds_, (const int64_t*)idx,
+                       (elem_t*)dst, ldd, (int)D);
     return ull_check_launch();
 }
 
-extern "C" int ull_add_rows_bf16(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream) {
+extern "C" int ULL_FN(ull_add_rows_)(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream) {
     if (!a || !b || !out || rows <= 0 || b_rows <= 0) return ULL_ERR_ARG;
     if (D & 7) return ULL_ERR_SHAPE;
     const long total = rows * (D >> 3);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, rows,
+    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)a, (const elem_t*)b, (elem_t*)out, rows,
                        (int)D, b_rows);
     return ull_check_launch();
 }

@@ -130,10 +130,10 @@ class KVCache:
     last-layer hidden states of every position seen so far (what `evaluate()` reads for [SEG]/[LOC] rows).  Truthy once a
     prefill has been stored, like a non-empty HF past_key_values tuple."""
 
-    def __init__(self, n_layers, B, H, hd, smax, device):
+    def __init__(self, n_layers, B, H, hd, smax, device, dtype=BF16):
         self.smax = ((smax + 63) // 64) * 64
-        self.k = [torch.empty(B, H, self.smax, hd, device=device, dtype=BF16) for _ in range(n_layers)]
-        self.vt = [torch.zeros(B, H, hd, self.smax, device=device, dtype=BF16) for _ in range(n_layers)]
+        self.k = [torch.empty(B, H, self.smax, hd, device=device, dtype=dtype) for _ in range(n_layers)]
+        self.vt = [torch.zeros(B, H, hd, self.smax, device=device, dtype=dtype) for _ in range(n_layers)]
         self.length = 0
         self.last_hidden = []
 
@@ -163,9 +163,11 @@ class UllavaCoreForCausalLM(nn.Module):
 
     def __init__(self, config: UllavaCoreConfig, device=None, dtype=BF16):
         super().__init__()
-        if dtype != BF16:
-            raise NotImplementedError("the MI355X path computes in bf16 (reference configs: bf16: true)")
+        if dtype not in (BF16, torch.float16):
+            raise NotImplementedError("the MI355X path has bf16 (reference configs: bf16: true) and fp16 (inference_ullava.py --dtype fp16) "
+                                      "kernel builds; fp32 is not supported")
         self.config = config
+        self.dtype = dtype
         D = config.hidden_size
         self.model = _Holder()
         self.model.embed_tokens = Embedding(config.vocab_size, D, device=device, dtype=dtype)
@@ -285,7 +287,7 @@ class UllavaCoreForCausalLM(nn.Module):
         if pixel_values.shape[-1] != vc.image_size or pixel_values.shape[-2] != vc.image_size:
             raise ValueError(f"Input image size ({pixel_values.shape[-2]}*{pixel_values.shape[-1]}) doesn't match model "
                              f"({vc.image_size}*{vc.image_size}).")
-        x = pixel_values.to(BF16).contiguous()
+        x = pixel_values.to(self.dtype).contiguous()
         P = (vc.image_size // vc.patch_size) ** 2
         Dv, H = vc.hidden_size, vc.num_attention_heads
         hd = Dv // H
@@ -301,7 +303,7 @@ class UllavaCoreForCausalLM(nn.Module):
             y = ops.layernorm(h, w["ln1"].weight, w["ln1"].bias, vc.layer_norm_eps)
             qkv = ops.linear(y, w["w_qkv"], w["b_qkv"])
             vt = ops.transpose_v(qkv[:, 2 * Dv:], S * 3 * Dv, 3 * Dv, n, S, H, hd)
-            att = torch.empty(n * S, Dv, device=h.device, dtype=BF16)
+            att = torch.empty(n * S, Dv, device=h.device, dtype=h.dtype)
             ops.attention(qkv, qkv[:, Dv:], vt, att, n, H, S, S, hd, (S * 3 * Dv, hd, 3 * Dv), (S * 3 * Dv, hd, 3 * Dv),
                           (S * Dv, hd, Dv), None, causal=False, scale_mode=1, scale=hd ** -0.5)
             h = ops.linear(att, w["w_out"], w["b_out"], residual=h)
@@ -394,7 +396,7 @@ class UllavaCoreForCausalLM(nn.Module):
                 all_h.append(x.view(B, S, D))
             decode = cache is not None and past > 0
             qkv = ops.linear(x, w["w_qkv"], rms_w=w["ln1"], rms_eps=cfg.rms_norm_eps)      # input_layernorm -> q|k|v
-            att = torch.empty(T, D, device=dev, dtype=BF16)
+            att = torch.empty(T, D, device=dev, dtype=x.dtype)
             if decode:
                 # generation step: RoPE + cache append in one launch, then the split-key attention over the cache
                 kc, vtc = cache.k[li], cache.vt[li]
@@ -447,7 +449,7 @@ class UllavaCoreForCausalLM(nn.Module):
             B_, S_ = inputs_embeds.shape[:2]
             cache = KVCache(self.config.num_hidden_layers, B_, self.config.num_attention_heads,
                             self.config.hidden_size // self.config.num_attention_heads,
-                            max(S_ + getattr(self, "_cache_headroom", 512), 64), inputs_embeds.device)
+                            max(S_ + getattr(self, "_cache_headroom", 512), 64), inputs_embeds.device, inputs_embeds.dtype)
         last, all_h = self._llama(inputs_embeds, attention_mask, position_ids, output_hidden_states, cache)
         logits = ops.linear(last, self.lm_head.weight)
         loss = None

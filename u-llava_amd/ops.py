@@ -1,7 +1,8 @@
 """Thin torch-tensor wrappers over the C-ABI (device pointers + sizes + current HIP stream).
 
 torch is used for device memory and streams only; every arithmetic op on the path is a HIP kernel from
-libullava_hip.so.  All activations are bf16, row-major, last dim contiguous.
+libullava_hip.so.  Activations are 16-bit (bf16 or fp16: every kernel exists in both builds, picked by the dtype of the op's first
+operand; the other operands must match), row-major, last dim contiguous.
 """
 from typing import Optional
 
@@ -10,6 +11,9 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+_SFX = {BF16: "bf16", F16: "f16"}                           # entry-point suffix of the two builds of every dtype-dependent kernel
+DT_CODE = {torch.float32: 0, BF16: 1, F16: 2}               # ULL_DT_* of the dtype-coded entry points
 EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_RELU, EPI_RESID, EPI_SWIGLU, EPI_F32 = 1, 1 << 1, 2 << 1, 3 << 1, 8, 16, 32
 ACTS = {None: 0, "quick_gelu": EPI_QGELU, "gelu": EPI_GELU, "relu": EPI_RELU}
 
@@ -40,10 +44,16 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
-def _chk(t: torch.Tensor, name: str, dtype=BF16):
+def _chk(t: torch.Tensor, name: str, dtype=None):
+    """dtype None: any 16-bit element type with a kernel build (bf16 / fp16); otherwise exactly `dtype` (the op's other operands
+    must match its first one -- there are no mixed-dtype kernels)."""
     if not t.is_cuda:
         raise RuntimeError(f"u-llava_amd: `{name}` must live on the GPU (no CPU path exists)")
-    if t.dtype != dtype:
+    if dtype is None:
+        if t.dtype not in _SFX:
+            raise RuntimeError(f"u-llava_amd: `{name}` must be torch.bfloat16 or torch.float16, got {t.dtype} "
+                               "(the MI355X path has bf16 and fp16 kernel builds; fp32 models are not supported)")
+    elif t.dtype != dtype:
         raise RuntimeError(f"u-llava_amd: `{name}` must be {dtype}, got {t.dtype}")
     if t.dim() and t.stride(-1) != 1:
         raise RuntimeError(f"u-llava_amd: `{name}` must be contiguous in its last dim")
@@ -133,7 +143,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     """y = epilogue(x @ w.T).  x [..., K]; w [N, K] (nn.Linear layout).  swiglu: w is the 16-row interleaved gate/up pack.
     rms_w/rms_eps: apply LlamaRMSNorm to x first (fused into the GEMV prologue at decode shapes, a separate kernel otherwise).
     tune: ULL_GEMM_TUNE_* bits (tools/ only)."""
-    _chk(x, "x"); _chk(w, "w")
+    _chk(x, "x"); _chk(w, "w", x.dtype)
     M, ldx = _rows(x)
     N, K = w.shape
     lead = tuple(x.shape[:-1])
@@ -147,16 +157,16 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         # decode shape: weight-streaming GEMV (no padding, no MFMA)
         n_out = N // 2 if swiglu else N
         if out is None:
-            out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else BF16)
+            out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
         flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | \
             (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0)
         ldr = _rows(residual)[1] if residual is not None else 0
         if rms_w is not None:
-            _chk(rms_w, "rms_w")
-            _lib.call("ull_gemv_rmsnorm_bf16", _p(x), ldx, _p(rms_w), float(rms_eps), _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias),
+            _chk(rms_w, "rms_w", x.dtype)
+            _lib.call("ull_gemv_rmsnorm_" + _SFX[x.dtype], _p(x), ldx, _p(rms_w), float(rms_eps), _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias),
                       _p(residual), ldr, M, N, K, flags, _stream())
         else:
-            _lib.call("ull_gemv_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias), _p(residual), ldr, M, N, K, flags,
+            _lib.call("ull_gemv_" + _SFX[x.dtype], _p(x), ldx, _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias), _p(residual), ldr, M, N, K, flags,
                       _stream())
         return out
     if K % 64:
@@ -169,14 +179,14 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         K, ldx = Kp, Kp
     n_out = N // 2 if swiglu else N
     if out is None:
-        out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else BF16)
+        out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | \
         (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0)
     if bias is not None:
-        _chk(bias, "bias")
+        _chk(bias, "bias", x.dtype)
     ldr = 0
     if residual is not None:
-        _chk(residual, "residual")
+        _chk(residual, "residual", x.dtype)
         _, ldr = _rows(residual)
     _, ldc = _rows(out)
     big = M >= 1024 and N >= 512 and K >= 128
@@ -188,42 +198,43 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         ws = _streamk_ws(x.device, st)
         ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
     if wt is not None:
-        _lib.call("ull_gemm_bf16", _p(x), ldx, _p(wt), K, _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags | EPI_W_TILED | tune,
+        _lib.call("ull_gemm_" + _SFX[x.dtype], _p(x), ldx, _p(wt), K, _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags | EPI_W_TILED | tune,
                   ws_ptr, ws_bytes, st)
     else:
-        _lib.call("ull_gemm_bf16", _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags | tune,
+        _lib.call("ull_gemm_" + _SFX[x.dtype], _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, _p(bias), _p(residual), ldr, M, N, K, flags | tune,
                   ws_ptr, ws_bytes, st)
     return out
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk(x, "x"); _chk(w, "w")
+    _chk(x, "x"); _chk(w, "w", x.dtype)
     rows, ldx = _rows(x)
     if out is None:
-        out = torch.empty(x.shape, device=x.device, dtype=BF16)
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
     _, ldy = _rows(out)
-    _lib.call("ull_rmsnorm_bf16", _p(x), ldx, _p(w), _p(out), ldy, rows, x.shape[-1], float(eps), _stream())
+    _lib.call("ull_rmsnorm_" + _SFX[x.dtype], _p(x), ldx, _p(w), _p(out), ldy, rows, x.shape[-1], float(eps), _stream())
     return out
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk(x, "x"); _chk(w, "w"); _chk(b, "b")
+    _chk(x, "x"); _chk(w, "w", x.dtype); _chk(b, "b", x.dtype)
     rows, ldx = _rows(x)
     if out is None:
-        out = torch.empty(x.shape, device=x.device, dtype=BF16)
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
     _, ldy = _rows(out)
-    _lib.call("ull_layernorm_bf16", _p(x), ldx, _p(w), _p(b), _p(out), ldy, rows, x.shape[-1], float(eps), _stream())
+    _lib.call("ull_layernorm_" + _SFX[x.dtype], _p(x), ldx, _p(w), _p(b), _p(out), ldy, rows, x.shape[-1], float(eps), _stream())
     return out
 
 
 def clip_embed_ln(patch: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, w: torch.Tensor, b: torch.Tensor, n_img: int, tokens: int,
                   eps: float) -> torch.Tensor:
     """patch [n_img*(tokens-1), D] -> pre-LN hidden states [n_img, tokens, D]."""
-    for t, n in ((patch, "patch"), (cls, "cls"), (pos, "pos"), (w, "w"), (b, "b")):
-        _chk(t, n)
+    _chk(patch, "patch")
+    for t, n in ((cls, "cls"), (pos, "pos"), (w, "w"), (b, "b")):
+        _chk(t, n, patch.dtype)
     D = patch.shape[-1]
-    out = torch.empty(n_img, tokens, D, device=patch.device, dtype=BF16)
-    _lib.call("ull_clip_embed_ln_bf16", _p(patch), patch.stride(0), _p(cls), _p(pos), _p(w), _p(b), _p(out), D, n_img, tokens, D,
+    out = torch.empty(n_img, tokens, D, device=patch.device, dtype=patch.dtype)
+    _lib.call("ull_clip_embed_ln_" + _SFX[patch.dtype], _p(patch), patch.stride(0), _p(cls), _p(pos), _p(w), _p(b), _p(out), D, n_img, tokens, D,
               float(eps), _stream())
     return out
 
@@ -234,10 +245,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
               rel_pos_hw: Optional[tuple] = None):
     """rel_h/rel_w: either per-query bias tables [B*H, Sq, KH|KW] (from sam_relpos), or -- with rel_pos_hw=(KH, KW) -- the raw
     rel_pos_h / rel_pos_w parameters [2KH-1, hd] / [2KW-1, hd], in which case the kernel builds the tables itself."""
-    _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt"); _chk(out, "out")
+    _chk(q, "q"); _chk(k, "k", q.dtype); _chk(vt, "vt", q.dtype); _chk(out, "out", q.dtype)
     rel_mode, kh, kw = 0, 0, 0
     if rel_h is not None:
-        _chk(rel_h, "rel_h"); _chk(rel_w, "rel_w")
+        _chk(rel_h, "rel_h", q.dtype); _chk(rel_w, "rel_w", q.dtype)
         if rel_pos_hw is not None:
             rel_mode, (kh, kw) = 2, rel_pos_hw
             if rel_h.shape[0] != 2 * kh - 1 or rel_w.shape[0] != 2 * kw - 1 or rel_h.shape[1] != hd:
@@ -247,7 +258,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     if key_mask is not None:
         _chk(key_mask, "key_mask", torch.int32)
     pitch = vt.shape[-1]
-    _lib.call("ull_attention_bf16", _p(q), *q_strides, _p(k), *k_strides, _p(vt), H * hd * pitch, hd * pitch, pitch, pitch, _p(out),
+    _lib.call("ull_attention_" + _SFX[q.dtype], _p(q), *q_strides, _p(k), *k_strides, _p(vt), H * hd * pitch, hd * pitch, pitch, pitch, _p(out),
               *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), float(q_scale), _p(rel_h), _p(rel_w),
               kh, kw, rel_mode, _zeros(q.device).data_ptr(), _stream())
     return out
@@ -255,15 +266,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
 
 def rope_inplace(x: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_freq: torch.Tensor, tokens: int, n_heads: int, hd: int):
     _chk(x, "x"); _chk(positions, "positions", torch.int64); _chk(inv_freq, "inv_freq", torch.float32)
-    _lib.call("ull_rope_inplace_bf16", _p(x), row_stride, _p(positions), _p(inv_freq), tokens, n_heads, hd, _stream())
+    _lib.call("ull_rope_inplace_" + _SFX[x.dtype], _p(x), row_stride, _p(positions), _p(inv_freq), tokens, n_heads, hd, _stream())
 
 
 def rope_append(qkv: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_freq: torch.Tensor, B: int, S: int, H: int, hd: int,
                 k_cache: torch.Tensor, vt_cache: torch.Tensor, smax: int, past: int):
     """decode step: RoPE on q (in place) and k + append of k / v to the KV cache (K [B,H,smax,hd], V^T [B,H,hd,smax] permuted)."""
     _chk(qkv, "qkv"); _chk(positions, "positions", torch.int64); _chk(inv_freq, "inv_freq", torch.float32)
-    _chk(k_cache, "k_cache"); _chk(vt_cache, "vt_cache")
-    _lib.call("ull_rope_append_bf16", _p(qkv), row_stride, _p(positions), _p(inv_freq), B, S, H, hd, _p(k_cache), _p(vt_cache), smax, past,
+    _chk(k_cache, "k_cache", qkv.dtype); _chk(vt_cache, "vt_cache", qkv.dtype)
+    _lib.call("ull_rope_append_" + _SFX[qkv.dtype], _p(qkv), row_stride, _p(positions), _p(inv_freq), B, S, H, hd, _p(k_cache), _p(vt_cache), smax, past,
               _stream())
 
 
@@ -271,8 +282,8 @@ def transpose_v(v: torch.Tensor, v_bs: int, v_ss: int, B: int, S: int, H: int, h
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(v, "v")
     pitch = pitch or ((S + 63) // 64) * 64
-    vt = out if out is not None else torch.empty(B, H, hd, pitch, device=v.device, dtype=BF16)
-    _lib.call("ull_transpose_v_bf16", _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, _stream())
+    vt = out if out is not None else torch.empty(B, H, hd, pitch, device=v.device, dtype=v.dtype)
+    _lib.call("ull_transpose_v_" + _SFX[v.dtype], _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, _stream())
     return vt
 
 
@@ -281,8 +292,8 @@ def im2col(img: torch.Tensor, ps: int, Kp: int) -> torch.Tensor:
     if not img.is_contiguous():
         raise RuntimeError("u-llava_amd.im2col: image batch must be contiguous NCHW")
     n, C, H, W = img.shape
-    out = torch.empty(n * (H // ps) * (W // ps), Kp, device=img.device, dtype=BF16)
-    _lib.call("ull_im2col_bf16", _p(img), _p(out), n, C, H, W, ps, Kp, _stream())
+    out = torch.empty(n * (H // ps) * (W // ps), Kp, device=img.device, dtype=img.dtype)
+    _lib.call("ull_im2col_" + _SFX[img.dtype], _p(img), _p(out), n, C, H, W, ps, Kp, _stream())
     return out
 
 
@@ -301,13 +312,13 @@ def pack_patch_weight(w: torch.Tensor) -> torch.Tensor:
 
 def patchify(img: torch.Tensor, wp: torch.Tensor, ps: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Conv2d(kernel = stride = ps) patch embedding straight from the pixels: img [n, C, H, W] bf16 -> [n*(H/ps)*(W/ps), N]."""
-    _chk(img, "img"); _chk(wp, "packed patch weight")
+    _chk(img, "img"); _chk(wp, "packed patch weight", img.dtype)
     if not img.is_contiguous():
         raise RuntimeError("u-llava_amd.patchify: image batch must be contiguous NCHW")
     n, C, H, W = img.shape
     N, Kp = wp.shape
-    out = torch.empty(n * (H // ps) * (W // ps), N, device=img.device, dtype=BF16)
-    _lib.call("ull_patchify_bf16", _p(img), n, C, H, W, ps, _p(wp), Kp, _p(bias), _p(out), N, N, _zeros(img.device).data_ptr(), _stream())
+    out = torch.empty(n * (H // ps) * (W // ps), N, device=img.device, dtype=img.dtype)
+    _lib.call("ull_patchify_" + _SFX[img.dtype], _p(img), n, C, H, W, ps, _p(wp), Kp, _p(bias), _p(out), N, N, _zeros(img.device).data_ptr(), _stream())
     return out
 
 
@@ -326,16 +337,16 @@ def embed_splice(ids: torch.Tensor, table: torch.Tensor, img_feat: Optional[torc
     _chk(ids, "input_ids", torch.int64); _chk(table, "embed_tokens")
     B, S = ids.shape
     D = table.shape[1]
-    out = torch.empty(B, S, D, device=ids.device, dtype=BF16)
+    out = torch.empty(B, S, D, device=ids.device, dtype=table.dtype)
     if img_feat is not None:
-        _chk(img_feat, "img_feat")
+        _chk(img_feat, "img_feat", table.dtype)
         img_pitch = img_pitch or img_feat.shape[-2]
         img_tokens = img_tokens or img_pitch - img_off
     n_vid = 0
     if vid_feat is not None:
-        _chk(vid_feat, "vid_feat")
+        _chk(vid_feat, "vid_feat", table.dtype)
         n_vid = vid_feat.shape[-2]
-    _lib.call("ull_embed_splice_bf16", _p(ids), _p(table), _p(img_feat), img_tokens, img_pitch, img_off, _p(vid_feat), n_vid, _p(spans),
+    _lib.call("ull_embed_splice_" + _SFX[table.dtype], _p(ids), _p(table), _p(img_feat), img_tokens, img_pitch, img_off, _p(vid_feat), n_vid, _p(spans),
               _p(out), B, S, D, table.shape[0], _stream())
     return out
 
@@ -344,27 +355,27 @@ def video_pool(f: torch.Tensor, B: int, T: int, N: int, tok_pitch: Optional[int]
     """f [B*T, tok_pitch, D]; patches are tokens tok_off..tok_off+N of every frame."""
     _chk(f, "f")
     D = f.shape[-1]
-    out = torch.empty(B, T + N, D, device=f.device, dtype=BF16)
-    _lib.call("ull_video_pool_bf16", _p(f), _p(out), B, T, N, D, tok_pitch or N, tok_off, _stream())
+    out = torch.empty(B, T + N, D, device=f.device, dtype=f.dtype)
+    _lib.call("ull_video_pool_" + _SFX[f.dtype], _p(f), _p(out), B, T, N, D, tok_pitch or N, tok_off, _stream())
     return out
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _chk(src, "src"); _chk(idx, "idx", torch.int64)
     n, D = idx.numel(), src.shape[-1]
-    out = torch.empty(n, D, device=src.device, dtype=BF16)
+    out = torch.empty(n, D, device=src.device, dtype=src.dtype)
     if n:
-        _lib.call("ull_gather_rows_bf16", _p(src), src.stride(-2), _p(idx), _p(out), D, n, D, _stream())
+        _lib.call("ull_gather_rows_" + _SFX[src.dtype], _p(src), src.stride(-2), _p(idx), _p(out), D, n, D, _stream())
     return out
 
 
 def add_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """bf16(a + b) with b broadcast over leading rows (b has b_rows rows, a has k*b_rows)."""
-    _chk(a, "a"); _chk(b, "b")
+    _chk(a, "a"); _chk(b, "b", a.dtype)
     D = a.shape[-1]
     rows, b_rows = a.numel() // D, b.numel() // D
     out = torch.empty_like(a)
-    _lib.call("ull_add_rows_bf16", _p(a), _p(b), _p(out), rows, D, b_rows, _stream())
+    _lib.call("ull_add_rows_" + _SFX[a.dtype], _p(a), _p(b), _p(out), rows, D, b_rows, _stream())
     return out
 
 
@@ -374,70 +385,70 @@ def window_partition(x: torch.Tensor, B: int, H: int, W: int, ws: int) -> torch.
     _chk(x, "x")
     C = x.shape[-1]
     nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
-    out = torch.empty(B * nW * ws * ws, C, device=x.device, dtype=BF16)
-    _lib.call("ull_window_partition_bf16", _p(x), _p(out), B, H, W, C, ws, _stream())
+    out = torch.empty(B * nW * ws * ws, C, device=x.device, dtype=x.dtype)
+    _lib.call("ull_window_partition_" + _SFX[x.dtype], _p(x), _p(out), B, H, W, C, ws, _stream())
     return out
 
 
 def window_unpartition_add(win: torch.Tensor, shortcut: torch.Tensor, B: int, H: int, W: int, ws: int) -> torch.Tensor:
-    _chk(win, "win"); _chk(shortcut, "shortcut")
+    _chk(win, "win"); _chk(shortcut, "shortcut", win.dtype)
     out = torch.empty_like(shortcut)
-    _lib.call("ull_window_unpartition_add_bf16", _p(win), _p(shortcut), _p(out), B, H, W, shortcut.shape[-1], ws, _stream())
+    _lib.call("ull_window_unpartition_add_" + _SFX[win.dtype], _p(win), _p(shortcut), _p(out), B, H, W, shortcut.shape[-1], ws, _stream())
     return out
 
 
 def sam_relpos(q: torch.Tensor, q_strides, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, NB: int, nH: int, KH: int, KW: int, hd: int):
-    _chk(q, "q"); _chk(rel_pos_h, "rel_pos_h"); _chk(rel_pos_w, "rel_pos_w")
+    _chk(q, "q"); _chk(rel_pos_h, "rel_pos_h", q.dtype); _chk(rel_pos_w, "rel_pos_w", q.dtype)
     if rel_pos_h.shape[0] != 2 * KH - 1 or rel_pos_w.shape[0] != 2 * KW - 1:
         raise NotImplementedError("rel_pos interpolation (image_encoder.py:336-343) is not needed for 1024x1024 SAM inputs")
-    oh = torch.empty(NB * nH, KH * KW, KH, device=q.device, dtype=BF16)
-    ow = torch.empty(NB * nH, KH * KW, KW, device=q.device, dtype=BF16)
-    _lib.call("ull_sam_relpos_bf16", _p(q), *q_strides, _p(rel_pos_h), _p(rel_pos_w), _p(oh), _p(ow), NB, nH, KH, KW, hd, _stream())
+    oh = torch.empty(NB * nH, KH * KW, KH, device=q.device, dtype=q.dtype)
+    ow = torch.empty(NB * nH, KH * KW, KW, device=q.device, dtype=q.dtype)
+    _lib.call("ull_sam_relpos_" + _SFX[q.dtype], _p(q), *q_strides, _p(rel_pos_h), _p(rel_pos_w), _p(oh), _p(ow), NB, nH, KH, KW, hd, _stream())
     return oh, ow
 
 
 def layernorm2d_cl(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6, gelu: bool = False) -> torch.Tensor:
-    _chk(x, "x"); _chk(w, "w"); _chk(b, "b")
+    _chk(x, "x"); _chk(w, "w", x.dtype); _chk(b, "b", x.dtype)
     if not x.is_contiguous():
         raise RuntimeError("u-llava_amd.layernorm2d_cl: x must be contiguous channels-last rows")
     C = x.shape[-1]
     out = torch.empty_like(x)
-    _lib.call("ull_layernorm2d_cl_bf16", _p(x), _p(w), _p(b), _p(out), x.numel() // C, C, float(eps), int(gelu), _stream())
+    _lib.call("ull_layernorm2d_cl_" + _SFX[x.dtype], _p(x), _p(w), _p(b), _p(out), x.numel() // C, C, float(eps), int(gelu), _stream())
     return out
 
 
 def im2col3x3(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
     _chk(x, "x")
     C = x.shape[-1]
-    out = torch.empty(B * H * W, 9 * C, device=x.device, dtype=BF16)
-    _lib.call("ull_im2col3x3_bf16", _p(x), _p(out), B, H, W, C, _stream())
+    out = torch.empty(B * H * W, 9 * C, device=x.device, dtype=x.dtype)
+    _lib.call("ull_im2col3x3_" + _SFX[x.dtype], _p(x), _p(out), B, H, W, C, _stream())
     return out
 
 
 def mask_matmul(hyper: torch.Tensor, up: torch.Tensor, n: int, T: int, C: int, G: int) -> torch.Tensor:
-    _chk(hyper, "hyper"); _chk(up, "up")
-    out = torch.empty(n, T, 4 * G, 4 * G, device=up.device, dtype=BF16)
-    _lib.call("ull_mask_matmul_bf16", _p(hyper), _p(up), _p(out), n, T, C, G, _stream())
+    _chk(hyper, "hyper"); _chk(up, "up", hyper.dtype)
+    out = torch.empty(n, T, 4 * G, 4 * G, device=up.device, dtype=hyper.dtype)
+    _lib.call("ull_mask_matmul_" + _SFX[hyper.dtype], _p(hyper), _p(up), _p(out), n, T, C, G, _stream())
     return out
 
 
 def bilinear(x: torch.Tensor, in_h: int, in_w: int, out_h: int, out_w: int) -> torch.Tensor:
     """x [n, Hfull, Wfull] (bf16 or fp32, contiguous); the top-left in_h x in_w crop of every image is resized -> fp32 [n, out_h, out_w]."""
-    if not x.is_cuda or x.dtype not in (BF16, torch.float32) or not x.is_contiguous():
-        raise RuntimeError("u-llava_amd.bilinear: contiguous bf16/fp32 GPU tensor required")
+    if not x.is_cuda or x.dtype not in DT_CODE or not x.is_contiguous():
+        raise RuntimeError("u-llava_amd.bilinear: contiguous bf16/fp16/fp32 GPU tensor required")
     n, Hf, Wf = x.shape
     out = torch.empty(n, out_h, out_w, device=x.device, dtype=torch.float32)
-    _lib.call("ull_bilinear_f32", _p(x), int(x.dtype == BF16), Hf * Wf, Wf, in_h, in_w, _p(out), n, out_h, out_w, _stream())
+    _lib.call("ull_bilinear_f32", _p(x), DT_CODE[x.dtype], Hf * Wf, Wf, in_h, in_w, _p(out), n, out_h, out_w, _stream())
     return out
 
 
 def shifted_cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-    """mean CE of logits[:, :-1] against labels[:, 1:] (ignore_index -100) -> 0-dim bf16 tensor like the reference's loss."""
+    """mean CE of logits[:, :-1] against labels[:, 1:] (ignore_index -100) -> 0-dim tensor of the logits' dtype like the reference's loss."""
     _chk(logits, "logits"); _chk(labels, "labels", torch.int64)
     B, S, V = logits.shape
     acc = torch.zeros(2, device=logits.device, dtype=torch.float32)
-    _lib.call("ull_shifted_cross_entropy_bf16", _p(logits), logits.stride(1), _p(labels.contiguous()), B, S, V, _p(acc), _stream())
-    return (acc[0] / acc[1]).to(BF16)
+    _lib.call("ull_shifted_cross_entropy_" + _SFX[logits.dtype], _p(logits), logits.stride(1), _p(labels.contiguous()), B, S, V, _p(acc), _stream())
+    return (acc[0] / acc[1]).to(logits.dtype)
 
 
 def mask_loss_sums(logits: torch.Tensor, target: torch.Tensor, scale: float = 1000.0) -> torch.Tensor:
@@ -453,9 +464,9 @@ def mask_loss_sums(logits: torch.Tensor, target: torch.Tensor, scale: float = 10
 
 def box_losses(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     """fp32 [2] = {sum |pred - gt|, sum (1 - GIoU) over well-formed predictions}; pred [n,4] bf16/fp32, gt [n,4] fp32."""
-    if pred.dtype not in (BF16, torch.float32):
-        raise RuntimeError("u-llava_amd.box_losses: pred must be bf16 or fp32")
+    if pred.dtype not in DT_CODE:
+        raise RuntimeError("u-llava_amd.box_losses: pred must be bf16, fp16 or fp32")
     _chk(pred, "pred boxes", pred.dtype); _chk(gt, "gt boxes", torch.float32)
     out = torch.empty(2, device=pred.device, dtype=torch.float32)
-    _lib.call("ull_box_losses_f32", _p(pred.contiguous()), int(pred.dtype == BF16), _p(gt.contiguous()), pred.shape[0], _p(out), _stream())
+    _lib.call("ull_box_losses_f32", _p(pred.contiguous()), DT_CODE[pred.dtype], _p(gt.contiguous()), pred.shape[0], _p(out), _stream())
     return out

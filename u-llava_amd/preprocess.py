@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import ops
 from .ops import _p, _stream
 
 PRECISION_BITS = 32 - 8 - 2
@@ -106,10 +107,10 @@ def resize_u8(img: torch.Tensor, out_hw: Tuple[int, int], kind: str) -> torch.Te
 def _lut_chw(img: torch.Tensor, top: int, left: int, lut: torch.Tensor, out_hw, copy_hw, dtype) -> torch.Tensor:
     H, W, C = img.shape
     out = torch.empty(3, out_hw[0], out_hw[1], device=img.device, dtype=dtype)
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise NotImplementedError("pixel tensors are produced in fp32 (the reference's dtype) or bf16 (its .to(dtype) cast)")
+    if dtype not in ops.DT_CODE:
+        raise NotImplementedError("pixel tensors are produced in fp32 (the reference's dtype) or bf16 / fp16 (its .to(dtype) cast)")
     _lib.call("ull_u8_lut_chw", _p(img), H, W, C, top, left, _p(lut), _p(out), out_hw[0], out_hw[1], copy_hw[0], copy_hw[1],
-              int(dtype == torch.bfloat16), _stream())
+              ops.DT_CODE[dtype], _stream())
     return out
 
 

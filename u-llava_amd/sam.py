@@ -158,9 +158,9 @@ class SamEngine:
         hd = C // nH
         g = cfg.img_size // cfg.patch_size
         if pk["patch_wp"] is not None:                                       # fused: A tiles DMA'd straight from the pixels
-            x = ops.patchify(pixel_values.to(BF16).contiguous(), pk["patch_wp"], cfg.patch_size, enc.patch_embed.proj.bias)
+            x = ops.patchify(pixel_values.to(enc.pos_embed.dtype).contiguous(), pk["patch_wp"], cfg.patch_size, enc.patch_embed.proj.bias)
         else:
-            cols = ops.im2col(pixel_values.to(BF16).contiguous(), cfg.patch_size, pk["patch_w"].shape[1])
+            cols = ops.im2col(pixel_values.to(enc.pos_embed.dtype).contiguous(), cfg.patch_size, pk["patch_w"].shape[1])
             x = ops.linear(cols, pk["patch_w"], enc.patch_embed.proj.bias)       # [B*g*g, C]
         x = ops.add_rows(x, pk["pos"])
         for i, blk in enumerate(enc.blocks):
@@ -177,7 +177,7 @@ class SamEngine:
             qkv = ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)          # [NB*S, 3C]: q | k | v, heads contiguous
             strides = (S * 3 * C, hd, 3 * C)
             vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
-            att = torch.empty(NB * S, C, device=x.device, dtype=BF16)
+            att = torch.empty(NB * S, C, device=x.device, dtype=x.dtype)
             if glob and side != 64:
                 # other grid sizes: per-query bias tables from their own kernel, looked up by the attention kernel
                 rel_h, rel_w = ops.sam_relpos(qkv, strides, blk.attn.rel_pos_h, blk.attn.rel_pos_w, NB, nH, side, side, hd)
@@ -231,7 +231,7 @@ class SamEngine:
         k = ops.linear(k_in, a.k_proj.weight, a.k_proj.bias)
         v = ops.linear(v_in, a.v_proj.weight, a.v_proj.bias)
         vt = ops.transpose_v(v, Sk * Di, Di, n, Sk, H, hd)
-        att = torch.empty(n * Sq, Di, device=q.device, dtype=BF16)
+        att = torch.empty(n * Sq, Di, device=q.device, dtype=q.dtype)
         ops.attention(q, k, vt, att, n, H, Sq, Sk, hd, (Sq * Di, hd, Di), (Sk * Di, hd, Di), (Sq * Di, hd, Di), None, causal=False,
                       scale_mode=2, scale=math.sqrt(hd))
         return ops.linear(att, a.out_proj.weight, a.out_proj.bias, residual=residual)
