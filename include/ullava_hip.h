@@ -38,6 +38,8 @@ extern "C" {
 #define ULL_EPI_RESID 8                 /* out = bf16(R + bf16(linear)) : residual adds of LlamaDecoderLayer / CLIPEncoderLayer */
 #define ULL_EPI_SWIGLU 16               /* W = gate/up rows interleaved in groups of 16; out[N/2] = silu(gate)*up (hf: LlamaMLP.forward) */
 #define ULL_EPI_OUT_F32 32              /* C is float32 */
+#define ULL_EPI_BIAS_ROUNDED 256        /* with ULL_EPI_BIAS: out = round(round(X W^T) + bias), at::linear's unfused matmul + add_ path
+                                         * (non-contiguous 3-D input: SAM TwoWayTransformer layer 0 k/v/q projections of the image keys) */
 
 /* C[M,N] = epilogue(X[M,K] * W[N,K]^T).  K % 64 == 0, ldx % 8 == 0, ldw % 8 == 0.
  * Replaces every nn.Linear on the path: hf llama/modeling_llama.py LlamaAttention q/k/v/o_proj, LlamaMLP;

@@ -425,9 +425,11 @@ def prompt_encoder_text(sd, text_embeds: Tensor, emb_hw: Tuple[int, int], pfx: s
     return sparse, dense
 
 
-def _sam_attn(sd, p: str, q: Tensor, k: Tensor, v: Tensor, n_heads: int) -> Tensor:
+def _sam_attn(sd, p: str, q: Tensor, k: Tensor, v: Tensor, n_heads: int, trace: Optional[dict] = None, tag: str = "") -> Tensor:
     """transformer.py:220-242 (Attention.forward; softmax in the input dtype)."""
     q, k, v = linear(q, sd, p + "q_proj"), linear(k, sd, p + "k_proj"), linear(v, sd, p + "v_proj")
+    if trace is not None:
+        trace.update({tag + ".q": q, tag + ".k": k, tag + ".v": v})
 
     def sep(t):
         b, n, c = t.shape
@@ -439,12 +441,20 @@ def _sam_attn(sd, p: str, q: Tensor, k: Tensor, v: Tensor, n_heads: int) -> Tens
     a = torch.softmax(a, dim=-1)
     o = a @ v
     b, nh, nt, ch = o.shape
-    return linear(o.transpose(1, 2).reshape(b, nt, nh * ch), sd, p + "out_proj")
+    o = o.transpose(1, 2).reshape(b, nt, nh * ch)
+    if trace is not None:
+        trace[tag + ".att"] = o
+    return linear(o, sd, p + "out_proj")
 
 
 def two_way_transformer(sd, p: str, image_embedding: Tensor, image_pe: Tensor, point_embedding: Tensor,
-                        depth: int = 2, n_heads: int = 8):
-    """transformer.py:62-106 + TwoWayAttentionBlock :151-182."""
+                        depth: int = 2, n_heads: int = 8, trace: Optional[dict] = None):
+    """transformer.py:62-106 + TwoWayAttentionBlock :151-182.  trace: optional dict that receives the stage outputs
+    (stage-level parity tests of the HIP path)."""
+    def tr(name, t):
+        if trace is not None:
+            trace[name] = t
+        return t
     image_embedding = image_embedding.flatten(2).permute(0, 2, 1)
     image_pe = image_pe.flatten(2).permute(0, 2, 1)
     queries, keys = point_embedding, image_embedding
@@ -455,21 +465,21 @@ def two_way_transformer(sd, p: str, image_embedding: Tensor, image_pe: Tensor, p
         else:
             q = queries + point_embedding
             queries = queries + _sam_attn(sd, lp + "self_attn.", q, q, queries, n_heads)
-        queries = layer_norm(queries, sd, lp + "norm1", 1e-5)
+        queries = tr(f"l{i}.norm1", layer_norm(queries, sd, lp + "norm1", 1e-5))
         q = queries + point_embedding
         k = keys + image_pe
-        queries = queries + _sam_attn(sd, lp + "cross_attn_token_to_image.", q, k, keys, n_heads)
-        queries = layer_norm(queries, sd, lp + "norm2", 1e-5)
+        queries = queries + tr(f"l{i}.t2i", _sam_attn(sd, lp + "cross_attn_token_to_image.", q, k, keys, n_heads, trace, f"l{i}.t2i"))
+        queries = tr(f"l{i}.norm2", layer_norm(queries, sd, lp + "norm2", 1e-5))
         m = linear(F.relu(linear(queries, sd, lp + "mlp.lin1")), sd, lp + "mlp.lin2")
-        queries = layer_norm(queries + m, sd, lp + "norm3", 1e-5)
+        queries = tr(f"l{i}.norm3", layer_norm(queries + m, sd, lp + "norm3", 1e-5))
         q = queries + point_embedding
         k = keys + image_pe
-        keys = keys + _sam_attn(sd, lp + "cross_attn_image_to_token.", k, q, queries, n_heads)
-        keys = layer_norm(keys, sd, lp + "norm4", 1e-5)
+        keys = keys + tr(f"l{i}.i2t", _sam_attn(sd, lp + "cross_attn_image_to_token.", k, q, queries, n_heads))
+        keys = tr(f"l{i}.norm4", layer_norm(keys, sd, lp + "norm4", 1e-5))
     q = queries + point_embedding
     k = keys + image_pe
-    queries = queries + _sam_attn(sd, p + "final_attn_token_to_image.", q, k, keys, n_heads)
-    queries = layer_norm(queries, sd, p + "norm_final_attn", 1e-5)
+    queries = queries + tr("final.t2i", _sam_attn(sd, p + "final_attn_token_to_image.", q, k, keys, n_heads))
+    queries = tr("final.norm", layer_norm(queries, sd, p + "norm_final_attn", 1e-5))
     return queries, keys
 
 
@@ -482,8 +492,8 @@ def _mlp3(sd, p: str, x: Tensor, n: int = 3) -> Tensor:
 
 
 def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor, dense: Tensor,
-                 multimask_output: bool = False, pfx: str = "visual_model.mask_decoder."):
-    """MaskDecoder.forward/predict_masks (mask_decoder.py:75-164)."""
+                 multimask_output: bool = False, pfx: str = "visual_model.mask_decoder.", trace: Optional[dict] = None):
+    """MaskDecoder.forward/predict_masks (mask_decoder.py:75-164).  trace: optional dict receiving the stage outputs."""
     n_mask_tokens = sd[pfx + "mask_tokens.weight"].shape[0]
     out_tok = torch.cat([sd[pfx + "iou_token.weight"], sd[pfx + "mask_tokens.weight"]], dim=0)
     out_tok = out_tok.unsqueeze(0).expand(sparse.size(0), -1, -1)
@@ -492,16 +502,22 @@ def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor,
     src = src + dense
     pos_src = torch.repeat_interleave(image_pe, tokens.shape[0], dim=0)
     b, c, h, w = src.shape
-    hs, src = two_way_transformer(sd, pfx + "transformer.", src, pos_src, tokens)
+    hs, src = two_way_transformer(sd, pfx + "transformer.", src, pos_src, tokens, trace=trace)
     iou_tok = hs[:, 0, :]
     mask_toks = hs[:, 1:(1 + n_mask_tokens), :]
     src = src.transpose(1, 2).view(b, c, h, w)
     up = F.conv_transpose2d(src, sd[pfx + "output_upscaling.0.weight"], sd[pfx + "output_upscaling.0.bias"], stride=2)
+    if trace is not None:
+        trace["up0"] = up
     up = layer_norm_2d(up, sd[pfx + "output_upscaling.1.weight"], sd[pfx + "output_upscaling.1.bias"])
     up = F.gelu(up)
+    if trace is not None:
+        trace["up1"] = up
     up = F.conv_transpose2d(up, sd[pfx + "output_upscaling.3.weight"], sd[pfx + "output_upscaling.3.bias"], stride=2)
     up = F.gelu(up)
     hyper = torch.stack([_mlp3(sd, f"{pfx}output_hypernetworks_mlps.{i}.", mask_toks[:, i, :]) for i in range(n_mask_tokens)], dim=1)
+    if trace is not None:
+        trace["up2"], trace["hyper"] = up, hyper
     b, c, h, w = up.shape
     masks = (hyper @ up.view(b, c, h * w)).view(b, n_mask_tokens, h, w)
     iou = _mlp3(sd, pfx + "iou_prediction_head.", iou_tok)

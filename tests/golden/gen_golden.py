@@ -274,7 +274,8 @@ def gen_sam_decoder(name, dtype, seed, n_list=(1, 3, 10)):
                                        dense_prompt_embeddings=de, multimask_output=False)
             pm = sam.postprocess_masks(lr, input_size=(768, 1024), original_size=(480, 640))
         osp, ode = O.prompt_encoder_text(sd, text, (64, 64))
-        olr, oiou = O.mask_decoder(sd, emb, O.dense_pe(sd, (64, 64)), osp.to(dtype), ode, False)
+        otrace = {}
+        olr, oiou = O.mask_decoder(sd, emb, O.dense_pe(sd, (64, 64)), osp.to(dtype), ode, False, trace=otrace)
         eq(olr, lr, f"low_res_masks n={n}")
         eq(oiou, iou, f"iou n={n}")
         eq(O.postprocess_masks(olr, (768, 1024), (480, 640)), pm, f"postprocess n={n}")
@@ -284,6 +285,15 @@ def gen_sam_decoder(name, dtype, seed, n_list=(1, 3, 10)):
         fx["cases"].append(dict(n=n, text_embeds=text, low_res_masks=lr[:, :, ::st, ::st].contiguous(), low_res_stride=st,
                                 low_res_max=lr.float().abs().max().item(), iou=iou, post_sample=pm[:, :, ::8, ::8].contiguous(),
                                 post_sum=pm.double().sum().item(), post_abs_sum=pm.double().abs().sum().item()))
+        if n == 1:
+            # stage outputs of the two-way transformer's first block (the oracle's, whose final output was just checked bit-exact
+            # against the reference): small tensors whole, the 4096-row ones every 16th row
+            keep = {}
+            for k in ("l0.norm1", "l0.t2i.q", "l0.t2i.att", "l0.norm2", "l0.norm3", "l1.norm1"):
+                keep[k] = otrace[k]
+            for k in ("l0.t2i.k", "l0.t2i.v", "l0.norm4"):
+                keep[k] = otrace[k][:, ::16].contiguous()
+            fx["cases"][-1]["trace"] = keep
     save(name, fx)
 
 

@@ -169,9 +169,10 @@ def test_mask_decoder_fixture_g7():
         text = case["text_embeds"][:, 0].to(DEV)
         masks, iou = eng.decode(emb_tm, text)
         low = masks[:, 0:1].float().cpu()
-        sp, de = O.prompt_encoder_text(sd32, case["text_embeds"].float(), (64, 64))
+        sp, de = O.prompt_encoder_text(sd, case["text_embeds"], (64, 64))
+        sp32, de32 = O.prompt_encoder_text(sd32, case["text_embeds"].float(), (64, 64))
         # fp32 "truth": same bf16-rounded weights/inputs and the same bf16-computed dense PE (part of the reference's semantics)
-        truth, truth_iou = O.mask_decoder(sd32, emb.float(), O.dense_pe(sd, (64, 64)).float(), sp, de, False)
+        truth, truth_iou = O.mask_decoder(sd32, emb.float(), O.dense_pe(sd, (64, 64)).float(), sp32, de32, False)
         st = case["low_res_stride"]
         ref_low = case["low_res_masks"].float()
         e_ref, e_hip = rel_err(ref_low, truth[:, :, ::st, ::st]), rel_err(low, truth)
@@ -181,9 +182,15 @@ def test_mask_decoder_fixture_g7():
               f"{e_direct:.5f} (max|dlogit| / max|logit|); iou err {e_iou:.4f}")
         RESULTS.append(dict(test="g7_bf16", n=case["n"], hip_vs_reference=e_direct, hip_vs_fp32=e_hip, reference_vs_fp32=e_ref, iou=e_iou))
         assert e_hip <= max(2.0 * e_ref, 0.02)
-        # direct bound against the reference's own bf16 output: two bf16 evaluations of the same graph differ by rounding flips
-        # whose size is the bf16 path's distance from fp32 (e_ref); more than 2x that would mean a different computation
-        assert e_direct <= 2.0 * max(e_ref, 2.0 ** -8), (e_direct, e_ref)
+        # direct bound against the reference's own bf16 output.  Layer 0 of the two-way transformer is reproduced bit for bit
+        # (test_mask_decoder_stage_trace_bf16); after it single bf16 rounding flips are amplified (every image row attends to the same
+        # 6 tokens), exactly as between two host CPUs running the identical reference code: the reference's own cross-host deviation is
+        # measured here (oracle on this host vs the fixture) and HIP must not be further from the fixture than 1.6x that, nor > 2 %
+        ocross, _ = O.mask_decoder(sd, emb, O.dense_pe(sd, (64, 64)), sp.to(BF), de, False)
+        e_cross = float((ocross[:, :, ::st, ::st].float() - ref_low).abs().max()) / case["low_res_max"]
+        RESULTS[-1]["reference_cross_host"] = e_cross
+        print(f"      reference cross-host deviation (oracle on this CPU vs fixture): {e_cross:.5f}")
+        assert e_direct <= min(max(1.6 * e_cross, 2.0 ** -7), 0.02), (e_direct, e_cross)
         post = eng.postprocess(masks[:, 0].contiguous(), (768, 1024), (480, 640)).cpu()
         assert post.dtype == torch.float32 and tuple(post.shape) == (case["n"], 480, 640)
         ref_post = O.postprocess_masks(masks[:, 0:1].cpu(), (768, 1024), (480, 640))[:, 0]
@@ -399,3 +406,35 @@ def test_evaluate_sampling_path_is_seeded_and_valid():
         n_seg = int((seq[0, 1:] == fx["cfg"]["seg_token_idx"]).sum())
         assert masks[0].shape[0] == n_seg and bool(torch.isfinite(masks[0]).all())
     assert torch.equal(runs[0], runs[1]) and int(runs[0].max()) < fx["cfg"]["llm"]["vocab_size"]
+
+
+def test_mask_decoder_stage_trace_bf16_layer0_bit_exact():
+    """Stage-level parity against the reference's own intermediate tensors (G7 trace, n = 1): the first TwoWayAttentionBlock --
+    self attention, token->image attention over 4096 keys (incl. at::linear's unfused-bias path for the non-contiguous image keys),
+    MLP, image->token attention, four LayerNorms -- must reproduce the reference's bf16 tensors bit for bit, up to isolated
+    single-ulp flips from fp32 summation order (< 0.1 % of the elements of any stage; < 0.3 % for the block's last tensor, the
+    4096 x 256 keys after norm4, which collects the flips of all stages before it)."""
+    fx = load_fixture("g7_sam_decoder_bf16.pt")
+    eng, sd = _decoder_engine(fx)
+    g = torch.Generator().manual_seed(fx["image_embedding_seed"])
+    emb = torch.randn(1, 256, 64, 64, generator=g).to(BF)
+    emb_tm = emb[0].permute(1, 2, 0).reshape(4096, 256).contiguous().to(DEV)
+    case = fx["cases"][0]
+    tr = {}
+    eng.decode(emb_tm, case["text_embeds"][:, 0].to(DEV), trace=tr)
+    rows = []
+    for k, ref in case["trace"].items():
+        if k not in tr:
+            continue
+        got = tr[k].cpu()
+        got = got.reshape(1, -1, ref.shape[-1])
+        if got.shape[1] != ref.shape[1]:
+            got = got[:, ::16]
+        flips = float((got != ref).float().mean())
+        dmax = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
+        rows.append((k, flips, dmax))
+        print(f"{k:12s} differing elements {flips:.5f}  max|d|/max {dmax:.2e}")
+        RESULTS.append(dict(test="g7_trace_bf16", stage=k, frac_differing=flips, max_rel=dmax))
+        if k.startswith("l0."):
+            assert flips <= (3e-3 if k == "l0.norm4" else 1e-3) and dmax <= 2.0 ** -7, (k, flips, dmax)
+    assert len(rows) >= 8

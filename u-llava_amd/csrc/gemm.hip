@@ -36,6 +36,11 @@ constexpr int EPI_BIAS = 1, EPI_ACT_SHIFT = 1, EPI_ACT_MASK = 3 << 1;  // act: 0
 constexpr int EPI_RESID = 8, EPI_SWIGLU = 16, EPI_OUT_F32 = 32;
 // operand stored tile-major [rows/256][K/64][256][64] (every 256 x 64 K-tile = 32 contiguous KiB); big kernel only
 constexpr int EPI_W_TILED = 64, EPI_X_TILED = 128;
+// The bias is added to the ROUNDED product: out = rnd(rnd(X W^T) + b).  at::linear fuses the bias (one rounding) only for 2-D and
+// contiguous n-D inputs; a non-contiguous 3-D input goes through matmul + add_ (two roundings).  On the path that is layer 0 of
+// SAM's TwoWayTransformer, whose `keys` are still the permuted NCHW view: cross_attn_token_to_image.{k,v}_proj and
+// cross_attn_image_to_token.q_proj (transformer.py:92-93,151-182).
+constexpr int EPI_BIAS_ROUNDED = 256;
 
 struct GemmArgs {
     const elem_t* X; const elem_t* W; void* C;
@@ -79,13 +84,19 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
     const bool out_f32 = flags & EPI_OUT_F32;
     const bool has_res = flags & EPI_RESID;
     const int n_out = SWIGLU ? p.N / 2 : p.N;
-    const bool raw_f32 = !SWIGLU && out_f32 && !act && !has_res;       // fp32 result of the accumulator, never rounded
+    const bool bias_late = !SWIGLU && (flags & EPI_BIAS) && (flags & EPI_BIAS_ROUNDED);   // added in finish8, after the first rounding
+    const bool raw_f32 = !SWIGLU && out_f32 && !act && !has_res && !bias_late;   // fp32 result of the accumulator, never rounded
     const bool c_al = out_f32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0;   // 16-byte row alignment of C / R
     const bool r_al = (p.ldr & 7) == 0;
     const int ncol0 = SWIGLU ? nw0 / 2 : nw0;
 
     // finish 8 consecutive outputs of row m starting at column n: activation, residual, store
     auto finish8 = [&](float (&a)[8], int m, int n) {
+        if (bias_late) {
+#pragma unroll 1
+            for (int e = 0; e < 8; ++e)
+                if (n + e < n_out) a[e] = rnd(a[e] + e2f(p.bias[n + e]));
+        }
         if (act == 1) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_e(a[e]);
@@ -138,7 +149,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = nw0 + i * 16 + fg * 4 + r;
-            bias_v[i][r] = (!SWIGLU && (flags & EPI_BIAS) && n < p.N) ? e2f(p.bias[n]) : -0.0f;
+            bias_v[i][r] = (!SWIGLU && (flags & EPI_BIAS) && !bias_late && n < p.N) ? e2f(p.bias[n]) : -0.0f;
         }
 
     if (!raw_f32) {
@@ -647,6 +658,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = a4[r];
+                if ((flags & EPI_BIAS) && (flags & EPI_BIAS_ROUNDED)) t = rnd(t);
                 if ((flags & EPI_BIAS) && n + r < p.N) t += e2f(p.bias[n + r]);
                 if (!out_f32 || act || (flags & EPI_RESID)) t = rnd(t);
                 if (act == 1) t = act_quick_gelu_e(t);
@@ -711,6 +723,7 @@ extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int6
     const int tune_group_m = (flags >> 16) & 15;
     const bool force_small = flags & (1 << 20);
     flags &= 0xffff;
+    if ((flags & EPI_BIAS_ROUNDED) && (flags & EPI_SWIGLU)) return ULL_ERR_SHAPE;
     GemmArgs a;
     a.X = (const elem_t*)X; a.W = (const elem_t*)W; a.C = C;
     a.bias = (const elem_t*)bias; a.R = (const elem_t*)R;

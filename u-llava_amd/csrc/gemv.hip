@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int EPI_BIAS = 1, EPI_ACT_SHIFT = 1, EPI_ACT_MASK = 3 << 1, EPI_RESID = 8, EPI_SWIGLU = 16, EPI_OUT_F32 = 32;
+constexpr int EPI_BIAS_ROUNDED = 256;     // bias added to the already rounded product (at::linear's unfused matmul + add_ path)
 constexpr int MAXM = 4;
 
 constexpr int XS_MAX_BYTES = 32 * 1024;     // X (optionally RMS-normalised) is staged in LDS when M * K * 2 fits in this
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const elem_t* __restrict__ X,
                     t = rnd(rnd(act_silu(rnd(a0[m]))) * rnd(a1[m]));
                 } else {
                     t = a0[m];
+                    if ((flags & EPI_BIAS) && (flags & EPI_BIAS_ROUNDED)) t = rnd(t);
                     if (flags & EPI_BIAS) t += e2f(bias[o]);
                     if (!(flags & EPI_OUT_F32) || act || (flags & EPI_RESID)) t = rnd(t);
                     if (act == 1) t = act_quick_gelu_e(t);

@@ -15,6 +15,7 @@ F16 = torch.float16
 _SFX = {BF16: "bf16", F16: "f16"}                           # entry-point suffix of the two builds of every dtype-dependent kernel
 DT_CODE = {torch.float32: 0, BF16: 1, F16: 2}               # ULL_DT_* of the dtype-coded entry points
 EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_RELU, EPI_RESID, EPI_SWIGLU, EPI_F32 = 1, 1 << 1, 2 << 1, 3 << 1, 8, 16, 32
+EPI_BIAS_ROUNDED = 256
 ACTS = {None: 0, "quick_gelu": EPI_QGELU, "gelu": EPI_GELU, "relu": EPI_RELU}
 
 
@@ -139,10 +140,12 @@ class streamk_policy:
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
            residual: Optional[torch.Tensor] = None, swiglu: bool = False, out: Optional[torch.Tensor] = None,
-           out_f32: bool = False, rms_w: Optional[torch.Tensor] = None, rms_eps: float = 0.0, tune: int = 0) -> torch.Tensor:
+           out_f32: bool = False, rms_w: Optional[torch.Tensor] = None, rms_eps: float = 0.0, tune: int = 0,
+           bias_after_rounding: bool = False) -> torch.Tensor:
     """y = epilogue(x @ w.T).  x [..., K]; w [N, K] (nn.Linear layout).  swiglu: w is the 16-row interleaved gate/up pack.
     rms_w/rms_eps: apply LlamaRMSNorm to x first (fused into the GEMV prologue at decode shapes, a separate kernel otherwise).
-    tune: ULL_GEMM_TUNE_* bits (tools/ only)."""
+    tune: ULL_GEMM_TUNE_* bits (tools/ only).  bias_after_rounding: y = round(round(x @ w.T) + bias) -- what at::linear computes
+    for a NON-contiguous 3-D input (matmul + add_ instead of the fused addmm)."""
     _chk(x, "x"); _chk(w, "w", x.dtype)
     M, ldx = _rows(x)
     N, K = w.shape
@@ -159,7 +162,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         if out is None:
             out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
         flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | \
-            (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0)
+            (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0) | (EPI_BIAS_ROUNDED if bias_after_rounding else 0)
         ldr = _rows(residual)[1] if residual is not None else 0
         if rms_w is not None:
             _chk(rms_w, "rms_w", x.dtype)
@@ -181,7 +184,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | \
-        (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0)
+        (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0) | (EPI_BIAS_ROUNDED if bias_after_rounding else 0)
     if bias is not None:
         _chk(bias, "bias", x.dtype)
     ldr = 0

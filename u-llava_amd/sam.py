@@ -223,17 +223,22 @@ class SamEngine:
         return self._dense_pe
 
     # -- mask decoder (mask_decoder.py:75-164, transformer.py) -----------------------------------------------------
-    def _attn(self, a, q_in, k_in, v_in, n, Sq, Sk, residual=None):
+    def _attn(self, a, q_in, k_in, v_in, n, Sq, Sk, residual=None, trace=None, tag="", unfused_bias=()):
+        """transformer.py:220-242.  unfused_bias: which of "q", "k", "v" projections see a NON-contiguous 3-D input in the reference
+        (the image keys while they are still the permuted NCHW view, i.e. in layer 0): at::linear then runs matmul + add_ and the
+        bias is added to the already rounded product."""
         H = self.cfg.decoder_heads
         Di = a.q_proj.weight.shape[0]
         hd = Di // H
-        q = ops.linear(q_in, a.q_proj.weight, a.q_proj.bias)
-        k = ops.linear(k_in, a.k_proj.weight, a.k_proj.bias)
-        v = ops.linear(v_in, a.v_proj.weight, a.v_proj.bias)
+        q = ops.linear(q_in, a.q_proj.weight, a.q_proj.bias, bias_after_rounding="q" in unfused_bias)
+        k = ops.linear(k_in, a.k_proj.weight, a.k_proj.bias, bias_after_rounding="k" in unfused_bias)
+        v = ops.linear(v_in, a.v_proj.weight, a.v_proj.bias, bias_after_rounding="v" in unfused_bias)
         vt = ops.transpose_v(v, Sk * Di, Di, n, Sk, H, hd)
         att = torch.empty(n * Sq, Di, device=q.device, dtype=q.dtype)
         ops.attention(q, k, vt, att, n, H, Sq, Sk, hd, (Sq * Di, hd, Di), (Sk * Di, hd, Di), (Sq * Di, hd, Di), None, causal=False,
                       scale_mode=2, scale=math.sqrt(hd))
+        if trace is not None:
+            trace.update({tag + ".q": q, tag + ".k": k, tag + ".v": v, tag + ".att": att})
         return ops.linear(att, a.out_proj.weight, a.out_proj.bias, residual=residual)
 
     def _mlp3(self, m, x):
@@ -243,12 +248,16 @@ class SamEngine:
         return x
 
     def decode(self, image_embedding_tm: torch.Tensor, text_embeds: torch.Tensor,
-               image_index: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+               image_index: Optional[torch.Tensor] = None, trace: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """image_embedding_tm [g*g, D] (one image), text_embeds [n, D] -> (masks [n, nm, 4g, 4g] bf16, iou [n, nm]).
         Covers PromptEncoder.forward with text_embeds only (sparse = text, dense = no_mask_embed) + MaskDecoder.predict_masks.
         With image_index (int64 [n]) image_embedding_tm is [B, g*g, D] and prompt j decodes against image image_index[j]: the
         prompts of a whole batch go through ONE chain of launches (every op below is independent per prompt, so the results are
-        the per-image results)."""
+        the per-image results).  trace: optional dict that receives the stage outputs (same names as the oracle's trace)."""
+        def rec(name, t, shape=None):
+            if trace is not None:
+                trace[name] = t if shape is None else t.view(*shape)
+            return t
         md, tr, pk = self.sam.mask_decoder, self.sam.mask_decoder.transformer, self.pk()
         n, D = text_embeds.shape
         P = image_embedding_tm.shape[-2]
@@ -271,28 +280,33 @@ class SamEngine:
             else:
                 q = ops.add_rows(queries, qpe)
                 queries = self._attn(l.self_attn, q, q, queries, n, T, T, residual=queries)
-            queries = ops.layernorm(queries, l.norm1.weight, l.norm1.bias, 1e-5)
+            queries = rec(f"l{i}.norm1", ops.layernorm(queries, l.norm1.weight, l.norm1.bias, 1e-5), (n, T, D))
             q = ops.add_rows(queries, qpe)
-            k = ops.add_rows(keys, pos)
-            queries = self._attn(l.cross_attn_token_to_image, q, k, keys, n, T, P, residual=queries)
-            queries = ops.layernorm(queries, l.norm2.weight, l.norm2.bias, 1e-5)
+            k = ops.add_rows(keys, pos)                                   # keys + key_pe feeds both cross attentions of the block
+            # layer 0: `keys` / `keys + key_pe` are still non-contiguous views in the reference (image_embedding.flatten(2).permute(0, 2, 1),
+            # transformer.py:92-93) -> their projections take at::linear's unfused-bias path; norm4 makes keys contiguous afterwards
+            queries = self._attn(l.cross_attn_token_to_image, q, k, keys, n, T, P, residual=queries, trace=trace, tag=f"l{i}.t2i",
+                                 unfused_bias=("k", "v") if i == 0 else ())
+            queries = rec(f"l{i}.norm2", ops.layernorm(queries, l.norm2.weight, l.norm2.bias, 1e-5), (n, T, D))
             m = ops.linear(queries, l.mlp.lin1.weight, l.mlp.lin1.bias, act="relu")
             queries = ops.linear(m, l.mlp.lin2.weight, l.mlp.lin2.bias, residual=queries)
-            queries = ops.layernorm(queries, l.norm3.weight, l.norm3.bias, 1e-5)
+            queries = rec(f"l{i}.norm3", ops.layernorm(queries, l.norm3.weight, l.norm3.bias, 1e-5), (n, T, D))
             q = ops.add_rows(queries, qpe)
-            k = ops.add_rows(keys, pos)
-            keys = self._attn(l.cross_attn_image_to_token, k, q, queries, n, P, T, residual=keys)
-            keys = ops.layernorm(keys, l.norm4.weight, l.norm4.bias, 1e-5)
+            keys = self._attn(l.cross_attn_image_to_token, k, q, queries, n, P, T, residual=keys, unfused_bias=("q",) if i == 0 else ())
+            keys = rec(f"l{i}.norm4", ops.layernorm(keys, l.norm4.weight, l.norm4.bias, 1e-5), (n, P, D))
         q = ops.add_rows(queries, qpe)
         k = ops.add_rows(keys, pos)
         queries = self._attn(tr.final_attn_token_to_image, q, k, keys, n, T, P, residual=queries)
-        hs = ops.layernorm(queries, tr.norm_final_attn.weight, tr.norm_final_attn.bias, 1e-5).view(n, T, D)
+        hs = rec("final.norm", ops.layernorm(queries, tr.norm_final_attn.weight, tr.norm_final_attn.bias, 1e-5).view(n, T, D))
         # upscaling: ConvT(k2,s2) -> LN2d -> GELU -> ConvT(k2,s2) -> GELU, kept in blocked [cell][d1][d2][c] order
         ln = md.output_upscaling[1]
         y1 = ops.linear(keys, pk["up0_w"], pk["up0_b"])                                         # [n*P, 4*D/4]
         y1 = ops.layernorm2d_cl(y1.view(-1, D // 4), ln.weight, ln.bias, 1e-6, gelu=True)        # [n*P*4, D/4]
         y2 = ops.linear(y1, pk["up3_w"], pk["up3_b"], act="gelu")                                # [n*P*4, 4*D/8]
-        hyper = torch.stack([self._mlp3(md.output_hypernetworks_mlps[t], hs[:, 1 + t, :]) for t in range(nm)], dim=1).contiguous()
+        hyper = rec("hyper", torch.stack([self._mlp3(md.output_hypernetworks_mlps[t], hs[:, 1 + t, :]) for t in range(nm)], dim=1).contiguous())
+        if trace is not None:       # blocked [n][cell][d1][c] / [n][cell][d1][d2][c] -> NCHW like the reference's tensors
+            trace["up1"] = y1.view(n, g, g, 2, 2, D // 4).permute(0, 5, 1, 3, 2, 4).reshape(n, D // 4, 2 * g, 2 * g)
+            trace["up2"] = y2.view(n, g, g, 2, 2, 2, 2, D // 8).permute(0, 7, 1, 3, 5, 2, 4, 6).reshape(n, D // 8, 4 * g, 4 * g)
         masks = ops.mask_matmul(hyper, y2, n, nm, D // 8, g)
         iou = self._mlp3(md.iou_prediction_head, hs[:, 0, :])
         return masks, iou
