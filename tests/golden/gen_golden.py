@@ -471,6 +471,9 @@ def gen_signatures(name):
         for n in names:
             table[f"{cls.__name__}.{n}"] = sig(getattr(cls, n))
     table["registered_model_types"] = [UllavaCoreConfig.model_type, UllavaConfig.model_type]
+    import models as ref_models
+    table["models_all"] = sorted(ref_models.__all__)
+    table["models_constants"] = {k: getattr(ref_models, k) for k in ref_models.__all__ if k.startswith("DEFAULT_") or k == "IGNORE_INDEX"}
     path = os.path.join(OUT, name)
     with open(path, "w") as f:
         json.dump(dict(signatures=table, meta=META), f, indent=1, sort_keys=True)

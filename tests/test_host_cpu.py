@@ -73,6 +73,8 @@ def test_public_signatures_match_reference_fixture():
         if key == "registered_model_types":
             assert [C.UllavaCoreConfig.model_type, C.UllavaConfig.model_type] == want
             continue
+        if key in ("models_all", "models_constants"):
+            continue
         cname, mname = key.split(".")
         got = list(inspect.signature(getattr(classes[cname], mname)).parameters.values())
         want_named = [w for w in want if "VAR_" not in w[1]]
@@ -93,3 +95,116 @@ def test_public_signatures_match_reference_fixture():
                     assert repr(p.default) == w[2], (key, p.name, repr(p.default), w[2])
         checked += 1
     assert checked >= 16
+
+
+_SHIM_PROBE = r"""
+import json, sys, os, tempfile, torch
+sys.path.insert(0, os.path.join(ROOT_DIR, "u-llava_amd", "shim"))
+import models
+from models import UllavaForCausalLM, UllavaCoreForCausalLM, KeywordsStoppingCriteria, DEFAULT_IMG_END_TOKEN, DEFAULT_IMG_START_TOKEN, DEFAULT_IMG_TOKEN, DEFAULT_IMG_PATCH_TOKEN
+out = {"all": sorted(models.__all__), "consts": {k: getattr(models, k) for k in models.__all__ if k.startswith("DEFAULT_") or k == "IGNORE_INDEX"}}
+from transformers import AutoConfig, AutoModelForCausalLM
+cfg = models.UllavaCoreConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4, vocab_size=50,
+                              vision_config=dict(hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64, image_size=28, patch_size=14))
+m = UllavaCoreForCausalLM(cfg)
+for p in m.parameters():
+    p.data.zero_()
+d = tempfile.mkdtemp()
+m.save_pretrained(d)
+ac = AutoConfig.from_pretrained(d)
+out["auto_config_model_type"] = ac.model_type
+m2 = AutoModelForCausalLM.from_pretrained(d)
+out["auto_model_class"] = type(m2).__name__
+out["auto_model_hidden"] = m2.config.hidden_size
+print("RESULT" + json.dumps(out))
+"""
+
+
+def test_models_shim_is_a_drop_in_for_the_reference_package():
+    """`from models import ...` with <repo>/u-llava_amd/shim on sys.path: same exported names and constants as the reference's
+    models/__init__.py, Auto classes registered (reference models/ullava_core.py:398-399, models/ullava.py:437-438), and
+    AutoModelForCausalLM.from_pretrained on a saved checkpoint directory builds our model.  Runs in a subprocess so that `models`
+    never shadows anything in this test session."""
+    import json
+    import subprocess
+    import sys
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))["signatures"]
+    r = subprocess.run([sys.executable, "-c", f"ROOT_DIR = {ROOT!r}\n" + _SHIM_PROBE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+    assert out["all"] == ref["models_all"]
+    assert out["consts"] == ref["models_constants"]
+    assert out["auto_config_model_type"] == "ullava_core" and out["auto_model_class"] == "UllavaCoreForCausalLM" and out["auto_model_hidden"] == 64
+
+
+class _FakeTokenizer:
+    def __init__(self, n):
+        self.vocab = {f"t{i}": i for i in range(n)}
+
+    def __len__(self):
+        return len(self.vocab)
+
+    def add_tokens(self, toks, special_tokens=False):
+        new = [t for t in toks if t not in self.vocab]
+        for t in new:
+            self.vocab[t] = len(self.vocab)
+        return len(new)
+
+    def add_special_tokens(self, d):
+        return self.add_tokens(list(d.values()), True)
+
+    def __call__(self, text):
+        return type("E", (), {"input_ids": [self.vocab[text]] if text in self.vocab else [1, 2]})()
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        inv = {v: k for k, v in self.vocab.items()}
+        return [" ".join(inv[int(i)] for i in row) for row in ids]
+
+
+def _tiny_core():
+    C, M = pkg("configuration"), pkg("modeling_core")
+    cfg = C.UllavaCoreConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4, vocab_size=50,
+                             vision_config=dict(hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64, image_size=28, patch_size=14))
+    m = M.UllavaCoreForCausalLM(cfg)
+    g = torch.Generator().manual_seed(0)
+    for p in m.parameters():
+        p.data.copy_(torch.randn(p.shape, generator=g).to(p.dtype))
+    return m
+
+
+def test_resize_token_embeddings_and_helpers():
+    """train_ullava.py:156-158,212 / models/tools.py:34-117: tokenizer growth -> embed_tokens + lm_head rows, old rows kept, new rows
+    averaged by the helpers, config.vocab_size updated, packed layouts invalidated."""
+    T = pkg("tools")
+    m = _tiny_core()
+    old_in, old_out = m.get_input_embeddings().weight.data.clone(), m.get_output_embeddings().weight.data.clone()
+    tok = _FakeTokenizer(50)
+    m._packed = {"stale": True}
+    T.smart_resize_token_embedding(["[SEG]", "[LOC]"], tok, m)
+    assert len(tok) == 52 and m.config.vocab_size == 52 and m._packed is None
+    w_in, w_out = m.get_input_embeddings().weight.data, m.get_output_embeddings().weight.data
+    assert tuple(w_in.shape) == (52, 64) and tuple(w_out.shape) == (52, 64)
+    assert torch.equal(w_in[:50], old_in) and torch.equal(w_out[:50], old_out)
+    assert torch.equal(w_in[50], old_in.mean(0, keepdim=True)[0]) and torch.equal(w_out[51], old_out.mean(0, keepdim=True)[0])
+    T.multi_modal_resize_token_embedding(dict(IMG_PATCH="<ip>", VID_PATCH="<vp>", IMG_START="<ib>", IMG_END="<ie>", VID_START="<vb>", VID_END="<ve>"), tok, m)
+    assert m.config.vocab_size == 58 and m.lm_head.weight.shape[0] == 58
+    names = dict(m.named_parameters())
+    assert "lm_head.weight" in names and "model.embed_tokens.weight" in names
+    # .to(dtype) invalidates the packs and is reflected by .dtype (inference_ullava.py: from_pretrained(torch_dtype=...) then .cuda())
+    m._packed = {"stale": True}
+    m.to(torch.float16)
+    assert m.dtype == torch.float16 and m._packed is None
+
+
+def test_keywords_stopping_criteria_semantics():
+    """models/tools.py:11-31: first call only records the prompt length; then single-token keyword on row 0's last id, or keyword
+    substring in the decoded continuation."""
+    T = pkg("tools")
+    tok = _FakeTokenizer(10)
+    prompt = torch.tensor([[1, 2, 3]])
+    c = T.KeywordsStoppingCriteria(["t7", "t4 t5"], tok, prompt)
+    assert c.keyword_ids == [7]
+    assert c(torch.tensor([[1, 2, 3, 7]]), None) is False            # first call: start_len only
+    assert c(torch.tensor([[1, 2, 3, 7, 7]]), None) is True          # last id is the single-token keyword
+    assert c(torch.tensor([[1, 2, 3, 4, 6]]), None) is False
+    assert c(torch.tensor([[1, 2, 3, 4, 5, 6]]), None) is True       # "t4 t5" appears in the decoded continuation

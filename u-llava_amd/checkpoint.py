@@ -149,10 +149,23 @@ def _dtype_arg(torch_dtype):
                               "(fp32 models are not supported)")
 
 
+def _merge_config(raw: dict, config_overrides: dict) -> dict:
+    """`config=` (a config object handed over by AutoModelForCausalLM.from_pretrained, or one of ours) replaces config.json's
+    fields; other keyword overrides are applied on top; loader-only keywords of PreTrainedModel.from_pretrained are dropped."""
+    cfg_obj = config_overrides.pop("config", None)
+    for k in ("low_cpu_mem_usage", "device_map", "cache_dir", "trust_remote_code", "use_safetensors", "attn_implementation",
+              "local_files_only", "revision", "token", "use_auth_token"):
+        config_overrides.pop(k, None)
+    if cfg_obj is not None:
+        d = cfg_obj.to_dict() if hasattr(cfg_obj, "to_dict") else dict(cfg_obj)
+        raw.update({k: v for k, v in d.items() if k in raw or k in ("llm_config", "sam_config", "vision_config")})
+    raw.update(config_overrides)
+    return raw
+
+
 def core_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict: bool = True, **config_overrides):
     from .configuration import UllavaCoreConfig
-    raw = read_config(path)
-    raw.update(config_overrides)
+    raw = _merge_config(read_config(path), config_overrides)
     model = cls(UllavaCoreConfig(**raw), device=device, dtype=_dtype_arg(torch_dtype))
     load_into(model, path, strict=strict)
     model._packed = None
@@ -161,8 +174,7 @@ def core_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict: 
 
 def ullava_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict: bool = True, **config_overrides):
     from .configuration import UllavaConfig
-    raw = read_config(path)
-    raw.update(config_overrides)
+    raw = _merge_config(read_config(path), config_overrides)
     model = cls(UllavaConfig(**raw), device=device, dtype=_dtype_arg(torch_dtype))
     # stage-2 checkpoints may ship without the frozen SAM encoder (it is loaded from sam_vit_h.pth by load_visual_checkpoint,
     # reference ullava.py:134-137): tolerate exactly that family of missing keys

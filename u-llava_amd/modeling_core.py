@@ -167,7 +167,6 @@ class UllavaCoreForCausalLM(nn.Module):
             raise NotImplementedError("the MI355X path has bf16 (reference configs: bf16: true) and fp16 (inference_ullava.py --dtype fp16) "
                                       "kernel builds; fp32 is not supported")
         self.config = config
-        self.dtype = dtype
         D = config.hidden_size
         self.model = _Holder()
         self.model.embed_tokens = Embedding(config.vocab_size, D, device=device, dtype=dtype)
@@ -194,8 +193,47 @@ class UllavaCoreForCausalLM(nn.Module):
                                  Linear(hidden_dim, hidden_dim, device=device, dtype=dtype))
         raise NotImplementedError
 
+    @property
+    def dtype(self):
+        return self.lm_head.weight.dtype
+
+    @property
+    def device(self):
+        return self.lm_head.weight.device
+
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .half() / .bfloat16(): the MI355X re-layouts (fused QKV, interleaved gate/up, tile-major copies) are
+        derived from the parameters and are rebuilt from the moved / cast ones on the next forward."""
+        out = super()._apply(fn, *args, **kwargs)
+        self._packed = None
+        self._inv_freq = None
+        return out
+
     def get_input_embeddings(self):
         return self.model.embed_tokens
+
+    def resize_token_embeddings(self, new_num_tokens=None, pad_to_multiple_of=None):
+        """PreTrainedModel.resize_token_embeddings as the reference's callers use it (train_ullava.py:212, models/tools.py:45,72,
+        102,108): grow (or shrink) embed_tokens and lm_head to `new_num_tokens` rows, old rows kept, new rows ~ N(0, 0.02)
+        (LlamaPreTrainedModel._init_weights; the callers then overwrite them with the mean embedding), config.vocab_size updated."""
+        emb = self.model.embed_tokens
+        if new_num_tokens is None:
+            return emb
+        if pad_to_multiple_of:
+            new_num_tokens = -(-new_num_tokens // pad_to_multiple_of) * pad_to_multiple_of
+        old = emb.weight.shape[0]
+        if new_num_tokens != old:
+            keep = min(old, new_num_tokens)
+            for holder in (emb, self.lm_head):
+                w = holder.weight
+                nw = torch.empty(new_num_tokens, w.shape[1], device=w.device, dtype=w.dtype)
+                nw.normal_(0.0, 0.02)
+                nw[:keep] = w.data[:keep]
+                holder.weight = nn.Parameter(nw, requires_grad=w.requires_grad)
+            self.lm_head.out_features = new_num_tokens
+            self.config.vocab_size = new_num_tokens
+            self._packed = None
+        return emb
 
     def get_output_embeddings(self):
         return self.lm_head
@@ -460,8 +498,6 @@ class UllavaCoreForCausalLM(nn.Module):
             out = (logits,) + ((cache,) if cache is not None else ()) + ((all_h,) if all_h is not None else ())
             return ((loss,) + out) if loss is not None else out
         return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=all_h, attentions=None)
-
-    __call__ = forward
 
     def prepare_inputs_for_generation(self, input_ids=None, inputs_embeds=None, attention_mask=None, images=None, videos=None,
                                       labels=None, past_key_values=None, **kwargs):

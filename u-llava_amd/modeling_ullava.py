@@ -71,6 +71,20 @@ class UllavaForCausalLM(nn.Module):
         self._sam.invalidate()
         return self.visual_model.load_state_dict(sd, strict=False)
 
+    @property
+    def dtype(self):
+        return self.llm.dtype
+
+    @property
+    def device(self):
+        return self.llm.device
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)           # (the core model invalidates its own packs in its _apply)
+        self._sam.invalidate()
+        self._side = None
+        return out
+
     def _side_stream(self):
         if not self.overlap_sam_encoder:
             return torch.cuda.current_stream()
@@ -209,8 +223,6 @@ class UllavaForCausalLM(nn.Module):
         loss += bbox_loss
         return {"loss": loss, "ce_loss": ce_loss, "mask_bce_loss": mask_bce_loss, "mask_dice_loss": mask_dice_loss, "mask_loss": mask_loss,
                 "bbox_loss": bbox_loss}
-
-    __call__ = forward
 
     @torch.no_grad()
     def evaluate(self, images_sam, images, input_ids, raw_size_list, resize_list, max_new_tokens=32, temperature=0.2, top_p=None,
