@@ -59,6 +59,19 @@ extern "C" {
 int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                   int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream);
 
+/* hf: LlamaAttention q/k/v_proj (one [3D, D] matrix) + apply_rotary_pos_emb in the GEMM epilogue: C[M, N] = X W^T with the rotary
+ * embedding applied to the output columns [0, rope_cols) (q heads then k heads, head_dim = 128; the v columns pass through).  Same
+ * three roundings as ull_rope_inplace_bf16 on the Linear's bf16 output.  rope_cos / rope_sin: [M, 64] from ull_rope_table_bf16.
+ * flags: ULL_EPI_W_TILED / ULL_EPI_X_TILED / tuning bits only; ws / ws_bytes as for ull_gemm_bf16. */
+int ull_gemm_qkv_rope_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                           const void* rope_cos, const void* rope_sin, int64_t rope_cols, int64_t head_dim, int flags, void* ws,
+                           int64_t ws_bytes, void* stream);
+
+/* hf: LlamaRotaryEmbedding.forward for a flat list of positions: cos_out / sin_out bf16 [tokens, half] = bf16(cos / sin(pos * inv_freq))
+ * (fp32 trigonometry, one rounding).  positions int64 [tokens], inv_freq float32 [half]. */
+int ull_rope_table_bf16(const void* positions, const void* inv_freq, int64_t tokens, int64_t half, void* cos_out, void* sin_out,
+                        void* stream);
+
 /* Bytes of stream-K workspace that cover every shape ull_gemm_bf16 may split (256 slabs of 256 x 256 fp32 = 64 MiB). */
 int64_t ull_gemm_streamk_ws_bytes(void);
 
@@ -220,6 +233,8 @@ int ull_box_losses_f32(const void* pred, int pred_dtype, const void* gt, int64_t
  * function of the same name; every 16-bit element is an fp16 instead of a bf16 (the reference's `--dtype fp16`,
  * inference_ullava.py:26,164-168).  Both builds live in the same library; the host picks by tensor dtype. */
 int ull_gemm_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream);
+int ull_gemm_qkv_rope_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const void* rope_cos, const void* rope_sin, int64_t rope_cols, int64_t head_dim, int flags, void* ws, int64_t ws_bytes, void* stream);
+int ull_rope_table_f16(const void* positions, const void* inv_freq, int64_t tokens, int64_t half, void* cos_out, void* sin_out, void* stream);
 int ull_gemv_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 int ull_gemv_rmsnorm_f16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 int ull_rmsnorm_f16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);

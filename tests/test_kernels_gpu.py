@@ -477,3 +477,25 @@ def test_gemm_without_workspace_never_splits():
     y1 = ops.linear(x, w)
     assert_close_bf16(y0, y1.cpu(), ulps=1.0, what="split vs unsplit")
     assert torch.equal(y0[: 256 * 8], y1[: 256 * 8])         # whole-tile rounds do not depend on the policy
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,D", [(300, 256), (643 * 3, 512), (256 * 9 + 17, 1024 + 128)])
+def test_qkv_gemm_with_fused_rope_is_bit_identical_to_gemm_then_rope(M, D, dt):
+    """ull_gemm_qkv_rope == ull_gemm + ull_rope_inplace, bit for bit: 128x128 kernel, 256x256 kernel and its stream-K tail
+    (finalize kernel); q and k columns rotated, v columns untouched; positions with repeats (batched sequences)."""
+    ops = pkg("ops")
+    hd, Hn = 128, D // 128
+    K = 2048 if M > 2000 else 256
+    g = torch.Generator().manual_seed(90 + M)
+    x = torch.randn(M, K, generator=g).to(dt).to(DEV)
+    w = (torch.randn(3 * D, K, generator=g) * K ** -0.5).to(dt).to(DEV)
+    pos = (torch.arange(M) % 643).to(DEV)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(DEV)
+    ref = ops.linear(x, w)
+    v_before = ref[:, 2 * D:].clone()
+    ops.rope_inplace(ref, 3 * D, pos, inv, M, 2 * Hn, hd)
+    cs, sn = ops.rope_table(pos, inv, dt)
+    got = ops.linear_qkv_rope(x, w, cs, sn, 2 * D, hd)
+    assert torch.equal(got[:, 2 * D:], v_before), "v columns must pass through"
+    assert torch.equal(got, ref), f"fused RoPE differs: {int((got != ref).sum())} elements"

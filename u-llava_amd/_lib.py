@@ -16,6 +16,8 @@ _i64, _i32, _f32, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_
 SIGNATURES = {
     "ull_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _ptr],
     "ull_gemm_streamk_ws_bytes": [],
+    "ull_gemm_qkv_rope_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i32, _ptr, _i64, _ptr],
+    "ull_rope_table_bf16": [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
     "ull_gemv_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_gemv_rmsnorm_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],

@@ -1113,6 +1113,18 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(elem_t* __restrict__ 
     }
 }
 
+// cos / sin tables of LlamaRotaryEmbedding for a list of positions: fp32 cos / sin of pos * inv_freq cast to the element type
+// (hf modeling_llama.py:72-126).  One table serves every layer of a forward (the fused QKV epilogue reads it).
+__global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restrict__ pos, const float* __restrict__ inv_freq, long tokens,
+                                                         int half, elem_t* __restrict__ cs, elem_t* __restrict__ sn) {
+    const long total = tokens * half;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float a = (float)pos[i / half] * inv_freq[i % half];
+        cs[i] = f2e(cosf(a));
+        sn[i] = f2e(sinf(a));
+    }
+}
+
 // Decode-step variant: RoPE on q (in place) and k, and the append of the new token's k / v to the KV cache, in one launch
 // (was rope + two strided copies per layer).  qkv rows = tokens (b, s) of a step, [q | k | v] heads contiguous; the token at
 // step position s goes to cache slot past + s: K cache [B, H, smax, hd] row past + s, V^T cache [B, H, hd, smax] column
@@ -1358,6 +1370,16 @@ extern "C" int ULL_FN(ull_rope_inplace_)(void* x, int64_t row_stride, const void
     if ((hd & 15) || hd > 256 || (cpr & (cpr - 1)) || (row_stride & 7)) return ULL_ERR_SHAPE;   // 256 % (hd/16) == 0
     hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (elem_t*)x, row_stride,
                        (const int64_t*)positions, (const float*)inv_freq, (int)n_heads, (int)hd);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_rope_table_)(const void* positions, const void* inv_freq, int64_t tokens, int64_t half, void* cos_out, void* sin_out,
+                                   void* stream) {
+    if (!positions || !inv_freq || !cos_out || !sin_out || tokens <= 0 || half <= 0) return ULL_ERR_ARG;
+    const long total = tokens * half;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(rope_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)positions, (const float*)inv_freq,
+                       (long)tokens, (int)half, (elem_t*)cos_out, (elem_t*)sin_out);
     return ull_check_launch();
 }
 

@@ -53,6 +53,10 @@ struct GemmArgs {
     int t_full, sk;
     float* ws;
     int group_m;                     // tile raster: blocks walk `group_m` M-tiles before stepping to the next N-tile
+    // fused RoPE epilogue (ull_gemm_qkv_rope_*): output columns [0, rope_cols) are heads of 128 dims that get
+    // transformers' apply_rotary_pos_emb with the per-token tables rope_cos / rope_sin [M, 64] (element type, already rounded)
+    const elem_t* rope_cos; const elem_t* rope_sin;
+    int rope_cols;
 };
 
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0+1024) (lane-linear).
@@ -75,8 +79,11 @@ ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */)
 // indexed accumulators) only adds the bias, rounds and parks the sub-tile in the wave's own LDS region `reg`
 // (JT*16 rows x 144 B); everything flag-dependent runs in a small rolled loop that writes whole rows.
 // The caller has passed a block barrier after its last LDS fragment read.
-template <bool SWIGLU, int JT>
-ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg, int lane, int mrow0, int nw0) {
+// ROPE (fused q|k|v projection): a head of 128 columns is parked by two neighbouring waves (64 columns each); after a block barrier
+// every wave rotates its half against the partner's: out = rnd(x * cos) + rnd(-+x_partner * sin), rounded once more by the store --
+// the three roundings of apply_rotary_pos_emb on 16-bit tensors (hf modeling_llama.py:129-159), same as rope_inplace_kernel.
+template <bool SWIGLU, int JT, bool ROPE = false>
+ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg, int lane, int mrow0, int nw0, const char* reg_partner = nullptr) {
     constexpr int ROWS = JT * 16;
     const int fr = lane & 15, fg = lane >> 4;
     const int flags = p.flags;
@@ -184,6 +191,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region only: no block barrier needed
+        if constexpr (ROPE) __builtin_amdgcn_s_barrier();      // ... unless the partner wave's half of the head is read below
         constexpr int LPR = WCOLS / 8;                         // lanes per row (16 B each)
         constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
 #pragma unroll 2
@@ -193,6 +201,17 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
             if (m >= p.M || n >= n_out) continue;
             float a[8];
             unpack8(*(const uint4*)(reg + row * PITCH + c8 * 16), a);
+            if constexpr (ROPE) {
+                if (n < p.rope_cols) {
+                    float b[8], cs[8], sn[8];
+                    unpack8(*(const uint4*)(reg_partner + row * PITCH + c8 * 16), b);
+                    unpack8(*(const uint4*)(p.rope_cos + (long)m * 64 + c8 * 8), cs);
+                    unpack8(*(const uint4*)(p.rope_sin + (long)m * 64 + c8 * 8), sn);
+                    const bool first_half = (n & 64) == 0;         // dims 0..63 of the head: rotate_half contributes -x[d + 64]
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = rnd(a[e] * cs[e]) + rnd((first_half ? -b[e] : b[e]) * sn[e]);
+                }
+            }
             finish8(a, m, n);
         }
     } else {
@@ -227,7 +246,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
     }
 }
 
-template <bool SWIGLU>
+template <bool SWIGLU, bool ROPE = false>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -319,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
 
     // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*(l>>4) + r][m = m0 + wm*64 + j*16 + (l&15)] --------------
     __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
-    staged_epilogue<SWIGLU, 4>(p, acc, smem + wave * (64 * 144), lane, m0 + wm * 64, n0 + wn * 64);
+    staged_epilogue<SWIGLU, 4, ROPE>(p, acc, smem + wave * (64 * 144), lane, m0 + wm * 64, n0 + wn * 64, smem + (wave ^ 1) * (64 * 144));
 }
 
 
@@ -458,7 +477,7 @@ constexpr int LDS_BYTES = 8 * 128 * (64 * 2 + 16);   // 144 KiB: two 64-KiB K-ti
 
 struct Frags { uint4 w[4]; uint4 x[8]; };
 
-template <bool SWIGLU>
+template <bool SWIGLU, bool ROPE = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -605,7 +624,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         return;
     }
     __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
-    staged_epilogue<SWIGLU, 8>(p, acc, smem + wave * (128 * 144), lane, m0 + wm * 128, n0 + wn * 64);
+    staged_epilogue<SWIGLU, 8, ROPE>(p, acc, smem + wave * (128 * 144), lane, m0 + wm * 128, n0 + wn * 64, smem + (wave ^ 1) * (128 * 144));
 }
 
 // (A v_mfma_f32_32x32x16_bf16 variant of this kernel measured 6-11 % slower in this structure and was removed;
@@ -655,6 +674,23 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
                 for (int r = 0; r < 4; ++r) a4[r] += a[r];
             }
             n = n0 + qc * 4;
+            if (p.rope_cos != nullptr && n < p.rope_cols) {
+                // fused RoPE (see staged_epilogue): the partner half of the head sits 64 columns away in the same tile
+                const bool first_half = (n & 64) == 0;
+                const int qp = first_half ? qc + 16 : qc - 16;
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < p.sk; ++s) {
+                    const f32x4_t b = *(const f32x4_t*)(slab0 + (long)s * (BM * BN) + ml * BN + qp * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b4[r] += b[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float c = e2f(p.rope_cos[(long)m * 64 + ((n + r) & 63)]), sn = e2f(p.rope_sin[(long)m * 64 + ((n + r) & 63)]);
+                    const float x = rnd(a4[r]), xp = rnd(b4[r]);
+                    a4[r] = rnd(x * c) + rnd((first_half ? -xp : xp) * sn);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = a4[r];
@@ -695,6 +731,8 @@ static int gemm_device_state(int* n_cu_out) {
         const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm128_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)patchify_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
@@ -708,9 +746,9 @@ static int gemm_device_state(int* n_cu_out) {
 extern "C" int64_t ull_gemm_streamk_ws_bytes(void) { return (int64_t)256 * big::BM * big::BN * sizeof(float); }
 #endif
 
-extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
-                             const void* bias, const void* R, int64_t ldr,
-                             int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream) {
+static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
+                         int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream,
+                         const elem_t* rope_cos, const elem_t* rope_sin, int rope_cols) {
     if (!X || !W || !C || M <= 0 || N <= 0 || K <= 0 || ws_bytes < 0) return ULL_ERR_ARG;
     if (K % BK != 0 || (ldx & 7) || (ldw & 7)) return ULL_ERR_SHAPE;          // 16-byte DMA pieces
     if ((flags & EPI_BIAS) && !bias) return ULL_ERR_ARG;
@@ -729,6 +767,8 @@ extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int6
     a.bias = (const elem_t*)bias; a.R = (const elem_t*)R;
     a.ldx = ldx; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags;
+    a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.rope_cols = rope_cols;
+    const bool rope = rope_cos != nullptr;
     // short K and fewer than two rounds of 256x256 tiles (ViT patchify: K = 640, 128 / 288 tiles): the 128x128 kernel's 4x finer
     // tiles fill the chip better (measured 61 vs 70 us at B=32, 336^2)
     const bool short_and_few = K <= 768 && ((M + 255) / 256) * ((N + 255) / 256) < 512 && !(flags & (EPI_W_TILED | EPI_X_TILED));
@@ -757,6 +797,8 @@ extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int6
         const int grid = a.sk > 1 ? a.t_full + rem * a.sk : T;
         if (flags & EPI_SWIGLU)
             hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+        else if (rope)
+            hipLaunchKernelGGL((big::gemm256_kernel<false, true>), dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
         else
             hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
         if (a.sk > 1) hipLaunchKernelGGL(big::splitk_finalize_kernel, dim3(32, rem), dim3(256), 0, (hipStream_t)stream, a);
@@ -767,9 +809,31 @@ extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int6
     a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
     if (flags & EPI_SWIGLU)
         hipLaunchKernelGGL(gemm128_kernel<true>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
+    else if (rope)
+        hipLaunchKernelGGL((gemm128_kernel<false, true>), dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(gemm128_kernel<false>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
     return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
+                             const void* bias, const void* R, int64_t ldr,
+                             int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream) {
+    return gemm_dispatch(X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, ws, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+// The fused q|k|v projection of LlamaAttention (hf modeling_llama.py:214-277): C[M, N] = X W^T (no bias) with
+// apply_rotary_pos_emb applied in the epilogue to the output columns [0, rope_cols) = the q and k heads (head_dim must be 128; the v
+// columns pass through).  rope_cos / rope_sin: [M, 64] tables of the element type from ull_rope_table_*.  flags: only
+// ULL_EPI_W_TILED / ULL_EPI_X_TILED / tuning bits.
+extern "C" int ULL_FN(ull_gemm_qkv_rope_)(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                                      int64_t K, const void* rope_cos, const void* rope_sin, int64_t rope_cols, int64_t head_dim, int flags,
+                                      void* ws, int64_t ws_bytes, void* stream) {
+    if (!rope_cos || !rope_sin) return ULL_ERR_ARG;
+    if (head_dim != 128 || rope_cols <= 0 || rope_cols > N || (rope_cols & 127) || (N & 127) || (ldc & 7)) return ULL_ERR_SHAPE;
+    if (flags & (EPI_BIAS | EPI_ACT_MASK | EPI_RESID | EPI_SWIGLU | EPI_OUT_F32 | EPI_BIAS_ROUNDED)) return ULL_ERR_ARG;
+    return gemm_dispatch(X, ldx, W, ldw, C, ldc, nullptr, nullptr, 0, M, N, K, flags, ws, ws_bytes, stream, (const elem_t*)rope_cos,
+                         (const elem_t*)rope_sin, (int)rope_cols);
 }
 
 // out[(b, py, px), n] = bias[n] + sum_{c,ky,kx} img[b, c, py*ps+ky, px*ps+kx] * w[n, c, ky, kx]   (bf16 in / out, fp32 accumulate)
@@ -792,6 +856,7 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
     a.M = (int)M; a.N = (int)N; a.K = (int)Kp; a.flags = bias ? EPI_BIAS : 0;
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
+    a.rope_cos = a.rope_sin = nullptr; a.rope_cols = 0;
     int n_cu = 0;
     if (const int rc = gemm_device_state(&n_cu)) return rc;
     hipLaunchKernelGGL(patchify_gemm_kernel<0>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a, q);

@@ -428,12 +428,19 @@ class UllavaCoreForCausalLM(nn.Module):
         inv_freq = self._rope_inv_freq(dev)
         x = inputs_embeds.reshape(B * S, D)
         T = B * S
+        # prefill with LLaMA's head_dim: RoPE runs inside the QKV GEMM's epilogue from one cos / sin table per forward (the
+        # positions are the same for every layer); other shapes (tiny test models, decode steps) use the stand-alone kernels
+        fuse_rope = hd == 128 and T > 4 and D % 64 == 0 and not (cache is not None and past > 0)
+        rope_cs = ops.rope_table(pos, inv_freq, x.dtype) if fuse_rope else None
         all_h = []
         for li, w in enumerate(pk["llama"]):
             if output_hidden_states:
                 all_h.append(x.view(B, S, D))
             decode = cache is not None and past > 0
-            qkv = ops.linear(x, w["w_qkv"], rms_w=w["ln1"], rms_eps=cfg.rms_norm_eps)      # input_layernorm -> q|k|v
+            if fuse_rope:
+                qkv = ops.linear_qkv_rope(ops.rmsnorm(x, w["ln1"], cfg.rms_norm_eps), w["w_qkv"], rope_cs[0], rope_cs[1], 2 * D, hd)
+            else:
+                qkv = ops.linear(x, w["w_qkv"], rms_w=w["ln1"], rms_eps=cfg.rms_norm_eps)      # input_layernorm -> q|k|v
             att = torch.empty(T, D, device=dev, dtype=x.dtype)
             if decode:
                 # generation step: RoPE + cache append in one launch, then the split-key attention over the cache
@@ -442,7 +449,8 @@ class UllavaCoreForCausalLM(nn.Module):
                 ops.attention(qkv, kc, vtc, att, B, H, S, past + S, hd, (S * 3 * D, hd, 3 * D), (H * cache.smax * hd, cache.smax * hd, hd),
                               (S * D, hd, D), key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
             else:
-                ops.rope_inplace(qkv, 3 * D, pos, inv_freq, T, 2 * H, hd)
+                if not fuse_rope:
+                    ops.rope_inplace(qkv, 3 * D, pos, inv_freq, T, 2 * H, hd)
                 if cache is None:
                     vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
                 else:                                            # prefill that also fills the cache

@@ -209,6 +209,47 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def rope_table(positions: torch.Tensor, inv_freq: torch.Tensor, dtype) -> tuple:
+    """(cos, sin) [tokens, hd/2] of `dtype` for int64 positions [tokens]: LlamaRotaryEmbedding's fp32 cos / sin cast to the model dtype."""
+    _chk(positions, "positions", torch.int64); _chk(inv_freq, "inv_freq", torch.float32)
+    if dtype not in _SFX:
+        raise RuntimeError("u-llava_amd.rope_table: dtype must be bf16 or fp16")
+    T, half = positions.numel(), inv_freq.numel()
+    cs = torch.empty(T, half, device=positions.device, dtype=dtype)
+    sn = torch.empty(T, half, device=positions.device, dtype=dtype)
+    _lib.call("ull_rope_table_" + _SFX[dtype], _p(positions), _p(inv_freq), T, half, _p(cs), _p(sn), _stream())
+    return cs, sn
+
+
+def linear_qkv_rope(x: torch.Tensor, w: torch.Tensor, rope_cos: torch.Tensor, rope_sin: torch.Tensor, rope_cols: int, head_dim: int,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused q|k|v projection + RoPE on the first `rope_cols` output columns (q and k heads), head_dim 128, K % 64 == 0, M > 4.
+    Bit-identical to linear() followed by rope_inplace()."""
+    _chk(x, "x"); _chk(w, "w", x.dtype); _chk(rope_cos, "rope_cos", x.dtype); _chk(rope_sin, "rope_sin", x.dtype)
+    M, ldx = _rows(x)
+    N, K = w.shape
+    if x.shape[-1] != K or K % 64 or head_dim != 128 or rope_cos.shape != (M, 64) or not rope_cos.is_contiguous() or not rope_sin.is_contiguous():
+        raise RuntimeError("u-llava_amd.linear_qkv_rope: needs K % 64 == 0, head_dim == 128 and [M, 64] contiguous tables")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=x.dtype)
+    _, ldc = _rows(out)
+    big = M >= 1024 and N >= 512 and K >= 128
+    wt = _tiled_of(w) if big else None
+    st = _stream()
+    ws_ptr, ws_bytes = None, 0
+    min_k = _SK_MIN_K[0]
+    if big and min_k is not None and K >= min_k:
+        ws = _streamk_ws(x.device, st)
+        ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
+    if wt is not None:
+        _lib.call("ull_gemm_qkv_rope_" + _SFX[x.dtype], _p(x), ldx, _p(wt), K, _p(out), ldc, M, N, K, _p(rope_cos), _p(rope_sin), rope_cols,
+                  head_dim, EPI_W_TILED, ws_ptr, ws_bytes, st)
+    else:
+        _lib.call("ull_gemm_qkv_rope_" + _SFX[x.dtype], _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, M, N, K, _p(rope_cos), _p(rope_sin),
+                  rope_cols, head_dim, 0, ws_ptr, ws_bytes, st)
+    return out
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(x, "x"); _chk(w, "w", x.dtype)
     rows, ldx = _rows(x)
