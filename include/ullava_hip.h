@@ -228,6 +228,44 @@ int ull_mask_loss_sums_f32(const void* logits, const void* target, int64_t n_mas
  * predictions with x1 >= x0 and y1 >= y0}.  pred [n,4] of dtype pred_dtype (ULL_DT_*), gt [n,4] fp32, xyxy. */
 int ull_box_losses_f32(const void* pred, int pred_dtype, const void* gt, int64_t n, void* out, void* stream);
 
+/* ---- backward kernels (train_ullava.py / train_ullava_core.py; torch autograd of the cited forward ops) --------
+ * Gradients are evaluated in fp32 from the stored 16-bit tensors and rounded once on output.  Linear layers need no entry point of
+ * their own: dX = dY W and dW = dY^T X are ull_gemm_bf16 on transposed operands. */
+
+/* hf LlamaRMSNorm backward: dx [rows, D]; dw float32 [D] += sum over rows (caller zeroes it; may be NULL). */
+int ull_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw,
+                         int64_t rows, int64_t D, float eps, void* stream);
+
+/* hf LlamaMLP activation on the UNFUSED gate/up projection kept in ULL_EPI_SWIGLU's interleaved column order (groups of 16 gate |
+ * 16 up): a [M, I] = silu(gate) * up with the reference's two roundings; backward: dgu [M, 2I] from da [M, I]. */
+int ull_swiglu_fwd_bf16(const void* gu, void* a, int64_t M, int64_t I, void* stream);
+int ull_swiglu_bwd_bf16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream);
+
+/* Backward of ull_rope_inplace_bf16 (the rotation is orthogonal: the transposed rotation of the gradient), in place. */
+int ull_rope_bwd_inplace_bf16(void* dx, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads,
+                              int64_t hd, void* stream);
+
+/* Backward of O = softmax(mult * Q K^T + mask) V (hf eager_attention_forward; SAM transformer.py:220-242 with mult = 1/sqrt(hd)).
+ * All tensors [B, H, S, hd] by element strides (batch, head, seq), hd contiguous: strides = int64[24] for Q, K, V, O, dO, dQ, dK, dV.
+ * causal / key_mask as in ull_attention_bf16.  scratch: float32 [2 * B * H * Sq].  Sk <= ~4900 (LDS). */
+int ull_attention_bwd_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK, void* dV,
+                           const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal,
+                           float mult, void* scratch, void* stream);
+
+/* Backward of ull_shifted_cross_entropy_bf16: dlogits [B, S, V] (same ld); stats = the forward's float[2]; gout = upstream gradient
+ * of the mean loss (one float32 on the device). */
+int ull_shifted_cross_entropy_bwd_bf16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, const void* stats,
+                                       const void* gout, void* dlogits, void* stream);
+
+/* Backward of ull_embed_splice_bf16: demb [B, S, D] -> d_table float32 [vocab, D] += (caller zeroes; NULL = not needed), d_img /
+ * d_vid = gradients of the projected visual features (same layouts as the forward's inputs; NULL = not needed). */
+int ull_embed_splice_bwd_bf16(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch,
+                              int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab,
+                              void* stream);
+
+/* out float32 [N] = column sums of x [rows, N] (bias gradients). */
+int ull_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
+
 /* ==== BEGIN fp16 twins (generated by tools/gen_header_f16.py) ==== */
 /* IEEE binary16 build of every dtype-dependent entry point: same arguments, layouts, flags and rounding points as the *_bf16
  * function of the same name; every 16-bit element is an fp16 instead of a bf16 (the reference's `--dtype fp16`,
@@ -257,6 +295,14 @@ int ull_layernorm2d_cl_f16(const void* x, const void* w, const void* b, void* y,
 int ull_im2col3x3_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 int ull_mask_matmul_f16(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
 int ull_patchify_f16(const void* img, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, const void* Wp, int64_t Kp, const void* bias, void* out, int64_t ldc, int64_t N, const void* zeros, void* stream);
+int ull_rmsnorm_bwd_f16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, int64_t rows, int64_t D, float eps, void* stream);
+int ull_swiglu_fwd_f16(const void* gu, void* a, int64_t M, int64_t I, void* stream);
+int ull_swiglu_bwd_f16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream);
+int ull_rope_bwd_inplace_f16(void* dx, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads, int64_t hd, void* stream);
+int ull_attention_bwd_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
+int ull_shifted_cross_entropy_bwd_f16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, const void* stats, const void* gout, void* dlogits, void* stream);
+int ull_embed_splice_bwd_f16(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
+int ull_colsum_f16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
 /* ==== END fp16 twins ==== */
 
 #ifdef __cplusplus

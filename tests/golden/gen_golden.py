@@ -451,6 +451,46 @@ def gen_evaluate(name, dtype, seed):
                     pred_mask_max=pm.abs().max().item(), pred_boxes=boxes))
 
 
+# --------------------------------------------------------------------------- G12 gradients of the core model (Stage-I / LLM side of Stage II)
+def gen_core_grads(name, dtype, seed):
+    """loss.backward() of UllavaCoreForCausalLM.forward(labels=...) with the language model, lm_head and the projector trainable and the
+    CLIP tower frozen (train_ullava.py:207-210,239-245 without LoRA): reference .grad of every trainable parameter.  The oracle is run
+    under autograd with the same leaves and must produce the same gradients bit for bit (same forward ops -> same backward ops)."""
+    print(f"[{name}]")
+    cd = core_cfg_dict()
+    m = build_ref_core(cd)
+    shapes, sd = load_seeded(m, seed, dtype)
+    m.train()
+    for n_, p_ in m.named_parameters():
+        p_.requires_grad = not n_.startswith("vision_encoder.")
+    n_patch = 4
+    a = img_ids(n_patch, 6, seed=1)
+    b = img_ids(n_patch, 3, seed=2)
+    S = len(a)
+    ids = torch.tensor([a, b + [0] * (S - len(b))])
+    mask = torch.tensor([[1] * S, [1] * len(b) + [0] * (S - len(b))])
+    labels = ids.clone()
+    labels[:, :7] = -100
+    labels[mask == 0] = -100
+    g = torch.Generator().manual_seed(seed + 7)
+    images = torch.randn(2, 3, 28, 28, generator=g).to(dtype)
+    r = m(input_ids=ids, attention_mask=mask, images=images, labels=labels)
+    r.loss.backward()
+    ref_grads = {n_: p_.grad.detach().clone() for n_, p_ in m.named_parameters() if p_.grad is not None}
+    leaves = {k: (v.clone().requires_grad_(True) if (not k.startswith("vision_encoder.") and v.is_floating_point()) else v) for k, v in sd.items()}
+    o = O.core_forward(leaves, cd, ids, mask, images, labels=labels)
+    eq(o["loss"].detach(), r.loss.detach(), "loss")
+    o["loss"].backward()
+    n_checked = 0
+    for k, gr in ref_grads.items():
+        assert leaves[k].grad is not None, k
+        eq(leaves[k].grad, gr, f"grad[{k}]")
+        n_checked += 1
+    print(f"   loss {float(r.loss):.5f}; {n_checked} parameter gradients bit-exact between reference and oracle autograd")
+    save(name, dict(cfg=cd, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=ids, attention_mask=mask, labels=labels, images=images,
+                    loss=r.loss.detach(), grads=ref_grads))
+
+
 def gen_signatures(name):
     """inspect.signature of the reference's public model surface: parameter names, order and defaults."""
     import inspect
@@ -505,6 +545,9 @@ if __name__ == "__main__":
         gen_sam_blocks("g9_sam_blocks_bf16.pt", torch.bfloat16, 9)
     if want("evaluate"):
         gen_evaluate("g11_evaluate_bf16.pt", torch.bfloat16, 8)
+    if want("grads"):
+        gen_core_grads("g12_core_grads_fp32.pt", torch.float32, 12)
+        gen_core_grads("g12_core_grads_bf16.pt", torch.bfloat16, 12)
     if want("signatures"):
         gen_signatures("reference_signatures.json")
     if want("losses"):

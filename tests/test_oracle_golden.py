@@ -147,3 +147,17 @@ def test_evaluate_g11():
     assert torch.equal(seq, fx["sequences"])
     _eq(masks[0][:, ::4, ::4].contiguous(), fx["pred_mask_sample"])
     _eq(boxes[0], fx["pred_boxes"])
+
+
+@pytest.mark.parametrize("name", ["g12_core_grads_fp32.pt", "g12_core_grads_bf16.pt"])
+def test_core_gradients_g12(name):
+    """autograd through the oracle == the reference's loss.backward() (every trainable parameter, bit-exact)."""
+    fx = load_fixture(name)
+    sd = fixture_state_dict(fx)
+    leaves = {k: (v.clone().requires_grad_(True) if not k.startswith("vision_encoder.") else v) for k, v in sd.items()}
+    o = O.core_forward(leaves, fx["cfg"], fx["input_ids"], fx["attention_mask"], fx["images"], labels=fx["labels"])
+    _eq(o["loss"].detach(), fx["loss"])
+    o["loss"].backward()
+    assert len(fx["grads"]) == 23
+    for k, g in fx["grads"].items():
+        _eq(leaves[k].grad, g)

@@ -18,6 +18,15 @@ SIGNATURES = {
     "ull_gemm_streamk_ws_bytes": [],
     "ull_gemm_qkv_rope_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i32, _ptr, _i64, _ptr],
     "ull_rope_table_bf16": [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
+    "ull_rmsnorm_bwd_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _f32, _ptr],
+    "ull_swiglu_fwd_bf16": [_ptr, _ptr, _i64, _i64, _ptr],
+    "ull_swiglu_bwd_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _ptr],
+    "ull_rope_bwd_inplace_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "ull_attention_bwd_bf16": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.POINTER(_i64), _ptr, _i64, _i64, _i64, _i64, _i64, _i32,
+                               _f32, _ptr, _ptr],
+    "ull_shifted_cross_entropy_bwd_bf16": [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
+    "ull_embed_splice_bwd_bf16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr],
+    "ull_colsum_bf16": [_ptr, _i64, _i64, _i64, _ptr, _ptr],
     "ull_gemv_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_gemv_rmsnorm_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],

@@ -1,0 +1,182 @@
+"""torch.autograd.Function wrappers that give the HIP forward ops a HIP backward.
+
+The inference path calls `ops.*` directly and never builds a graph.  When gradients are enabled and a parameter requires them
+(reference: `train_ullava.py:207-261`, `train_ullava_core.py`), the models route through these functions instead: every forward is the
+same HIP kernel as in inference (un-fused where the backward needs an intermediate: the SwiGLU pre-activations), every backward is a
+HIP kernel from csrc/backward.hip or the forward GEMM on transposed operands.  torch supplies only the tape, the tensor plumbing
+(cat / transpose / pad / where, which are data movement) and `.grad` accumulation.
+"""
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+def _t(x: torch.Tensor) -> torch.Tensor:
+    """[R, C] -> contiguous [C, R] (data movement for the transposed-operand GEMMs of Linear backward)."""
+    return x.t().contiguous()
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ w.T (+ bias) (relu) (+ residual).  dX = dY @ W, dW = dY^T @ X, db = colsum(dY): the forward GEMM on transposed operands."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, relu, bias_after_rounding):
+        if relu and residual is not None:
+            raise NotImplementedError("relu + residual in one epilogue hides the pre-residual sign needed by the backward")
+        y = ops.linear(x, w, bias, act="relu" if relu else None, residual=residual, bias_after_rounding=bias_after_rounding)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_bias, ctx.has_res, ctx.relu = bias is not None, residual is not None, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = torch.where(y > 0, dy, torch.zeros_like(dy)) if ctx.relu else dy          # selection, no arithmetic
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(g2, _t(w)).view(x.shape)                                     # [M, N] x [K, N]^T
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear(_t(g2), _t(x2))                                              # [N, M] x [K, M]^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(g2).to(w.dtype)
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None, None
+
+
+def linear(x, w, bias=None, residual=None, relu: bool = False, bias_after_rounding: bool = False):
+    return _Linear.apply(x, w, bias, residual, relu, bias_after_rounding)
+
+
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return ops.rmsnorm(x, w, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw = ops.rmsnorm_bwd(x, w, dy.contiguous(), ctx.eps, need_dw=ctx.needs_input_grad[1])
+        return dx, (dw.to(w.dtype) if dw is not None else None), None
+
+
+def rmsnorm(x, w, eps):
+    return _RMSNorm.apply(x, w, eps)
+
+
+class _SwiGLU(torch.autograd.Function):
+    """gu [M, 2I] (interleaved gate/up columns) -> silu(gate) * up."""
+
+    @staticmethod
+    def forward(ctx, gu):
+        ctx.save_for_backward(gu)
+        return ops.swiglu_fwd(gu)
+
+    @staticmethod
+    def backward(ctx, da):
+        (gu,) = ctx.saved_tensors
+        return ops.swiglu_bwd(gu, da.contiguous())
+
+
+def swiglu(gu):
+    return _SwiGLU.apply(gu)
+
+
+class _Rope(torch.autograd.Function):
+    """apply_rotary_pos_emb on the first n_heads heads of every row of a fused [T, 3D] q|k|v buffer (functional: returns a new tensor)."""
+
+    @staticmethod
+    def forward(ctx, qkv, positions, inv_freq, n_heads, hd):
+        out = qkv.clone()
+        T = out.shape[0]
+        ops.rope_inplace(out, out.stride(0), positions, inv_freq, T, n_heads, hd)
+        ctx.save_for_backward(positions, inv_freq)
+        ctx.n_heads, ctx.hd = n_heads, hd
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        positions, inv_freq = ctx.saved_tensors
+        d = dout.contiguous().clone()
+        ops.rope_bwd_inplace(d, d.stride(0), positions, inv_freq, d.shape[0], ctx.n_heads, ctx.hd)
+        return d, None, None, None, None
+
+
+def rope(qkv, positions, inv_freq, n_heads, hd):
+    return _Rope.apply(qkv, positions, inv_freq, n_heads, hd)
+
+
+class _SelfAttention(torch.autograd.Function):
+    """Causal / masked self attention on a fused, already rotated [B*S, 3D] q|k|v buffer (hf eager_attention_forward: scores * hd^-0.5)."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_mask, B, S, H, hd, causal):
+        D = H * hd
+        T = B * S
+        vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
+        att = torch.empty(T, D, device=qkv.device, dtype=qkv.dtype)
+        st = (S * 3 * D, hd, 3 * D)
+        ops.attention(qkv, qkv[:, D:], vt, att, B, H, S, S, hd, st, st, (S * D, hd, D), key_mask, causal=causal, scale_mode=1, scale=hd ** -0.5)
+        ctx.save_for_backward(qkv, att, key_mask)
+        ctx.dims = (B, S, H, hd, causal)
+        return att
+
+    @staticmethod
+    def backward(ctx, datt):
+        qkv, att, key_mask = ctx.saved_tensors
+        B, S, H, hd, causal = ctx.dims
+        D = H * hd
+        datt = datt.contiguous()
+        dqkv = torch.empty_like(qkv)
+        s3, s1 = (S * 3 * D, hd, 3 * D), (S * D, hd, D)
+        ops.attention_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], att, datt, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], (s3, s3, s3, s1, s1, s3, s3, s3), key_mask,
+                          B, H, S, S, hd, causal, hd ** -0.5)
+        return dqkv, None, None, None, None, None, None
+
+
+def self_attention(qkv, key_mask, B, S, H, hd, causal=True):
+    return _SelfAttention.apply(qkv, key_mask, B, S, H, hd, causal)
+
+
+class _ShiftedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        stats = ops.shifted_cross_entropy_stats(logits, labels)
+        ctx.save_for_backward(logits, labels, stats)
+        return (stats[0] / stats[1]).to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, stats = ctx.saved_tensors
+        return ops.shifted_cross_entropy_bwd(logits, labels, stats, g.float().reshape(1).contiguous()), None
+
+
+def shifted_cross_entropy(logits, labels):
+    return _ShiftedCE.apply(logits, labels)
+
+
+class _EmbedSplice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off):
+        ctx.save_for_backward(ids, spans)
+        ctx.meta = (table.shape[0], None if img_feat is None else tuple(img_feat.shape), None if vid_feat is None else tuple(vid_feat.shape),
+                    img_tokens, img_pitch, img_off, table.dtype)
+        return ops.embed_splice(ids, table, img_feat, vid_feat, spans, img_tokens, img_pitch, img_off)
+
+    @staticmethod
+    def backward(ctx, demb):
+        ids, spans = ctx.saved_tensors
+        vocab, img_shape, vid_shape, img_tokens, img_pitch, img_off, dt = ctx.meta
+        d_table, d_img, d_vid = ops.embed_splice_bwd(ids, demb.contiguous(), vocab, img_shape if ctx.needs_input_grad[1] else None,
+                                                     vid_shape if ctx.needs_input_grad[2] else None, spans, img_tokens, img_pitch, img_off,
+                                                     need_table=ctx.needs_input_grad[0])
+        return (d_table.to(dt) if d_table is not None else None), d_img, d_vid, None, None, None, None, None
+
+
+def embed_splice(table, img_feat, vid_feat, ids, spans, img_tokens=0, img_pitch=0, img_off=0):
+    return _EmbedSplice.apply(table, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off)

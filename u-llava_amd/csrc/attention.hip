@@ -1082,8 +1082,9 @@ __global__ __launch_bounds__(1024) void attn_fewq_kernel(AttnArgs p) {
 // RoPE in place on the q|k part of a fused QKV buffer (transformers apply_rotary_pos_emb on bf16
 // tensors: q*cos -> bf16, rotate_half(q)*sin -> bf16, sum -> bf16; cos/sin are fp32 values cast to bf16).
 // One block per token; thread t owns the 8-wide dim chunk (t % (hd/16)) of head-instances t / (hd/16), ...
+// sin_sign = -1 applies the transposed rotation: the backward of apply_rotary_pos_emb (the rotation is orthogonal).
 __global__ __launch_bounds__(256) void rope_inplace_kernel(elem_t* __restrict__ x, long row_stride, const int64_t* __restrict__ pos,
-                                                           const float* __restrict__ inv_freq, int n_heads, int hd) {
+                                                           const float* __restrict__ inv_freq, int n_heads, int hd, float sin_sign) {
     const long tok = blockIdx.x;
     const int half = hd >> 1;
     const int cpr = half >> 3;                   // 8-wide chunks per half head (hd % 16 == 0)
@@ -1094,7 +1095,7 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(elem_t* __restrict__ 
     for (int j = 0; j < 8; ++j) {
         const float a = pf * inv_freq[c * 8 + j];
         cs[j] = rnd(cosf(a));
-        sn[j] = rnd(sinf(a));
+        sn[j] = rnd(sinf(a)) * sin_sign;
     }
     elem_t* xr = x + tok * row_stride;
     for (int hh = threadIdx.x / cpr; hh < n_heads; hh += blockDim.x / cpr) {
@@ -1369,7 +1370,18 @@ extern "C" int ULL_FN(ull_rope_inplace_)(void* x, int64_t row_stride, const void
     const int64_t cpr = hd >> 4;
     if ((hd & 15) || hd > 256 || (cpr & (cpr - 1)) || (row_stride & 7)) return ULL_ERR_SHAPE;   // 256 % (hd/16) == 0
     hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (elem_t*)x, row_stride,
-                       (const int64_t*)positions, (const float*)inv_freq, (int)n_heads, (int)hd);
+                       (const int64_t*)positions, (const float*)inv_freq, (int)n_heads, (int)hd, 1.0f);
+    return ull_check_launch();
+}
+
+// Backward of ull_rope_inplace: dx <- R(pos)^T dx (same kernel with the sine negated), in place on the gradient of the q|k heads.
+extern "C" int ULL_FN(ull_rope_bwd_inplace_)(void* dx, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens,
+                                         int64_t n_heads, int64_t hd, void* stream) {
+    if (!dx || !positions || !inv_freq || tokens <= 0) return ULL_ERR_ARG;
+    const int64_t cpr = hd >> 4;
+    if ((hd & 15) || hd > 256 || (cpr & (cpr - 1)) || (row_stride & 7)) return ULL_ERR_SHAPE;
+    hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (elem_t*)dx, row_stride,
+                       (const int64_t*)positions, (const float*)inv_freq, (int)n_heads, (int)hd, -1.0f);
     return ull_check_launch();
 }
 

@@ -1,0 +1,426 @@
+// Backward kernels of the u-LLaVA path for gfx950 (what `train_ullava.py` / `train_ullava_core.py` need beyond the
+// forward): RMSNorm, SwiGLU, RoPE, attention, shifted cross-entropy and the embedding splice, plus the column sums of bias
+// gradients.  Linear backward needs no kernel of its own: dX = dY W and dW = dY^T X are the forward GEMM on transposed operands.
+//
+// Reference semantics: torch autograd of the ops cited at each kernel (hf modeling_llama.py LlamaRMSNorm / LlamaMLP /
+// apply_rotary_pos_emb / eager_attention_forward, models/ullava_core.py:182-277,327-338).  Gradients are computed in fp32 from the
+// 16-bit tensors the forward stored and rounded once to the element type on output (autograd's bf16 backward rounds after every
+// elementary op; the fp32 evaluation here is closer to the exact gradient -- tests compare both against an fp32 reference).
+// Correctness-first kernels (VALU, one block per row / row group): the training step is not on the benchmarked forward path yet.
+#include "ull_common.h"
+
+namespace {
+
+ULL_DEV float block_sum(float v, float* red) {          // 256 threads; red: >= 4 floats of LDS
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+ULL_DEV float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---- LlamaRMSNorm backward: y = w * rnd(x * r), r = rsqrt(mean(x^2) + eps) --------------------------------------------------------
+// dx = r * (g - xh * mean(g * xh)) with g = dy * w, xh = x * r;  dw[c] += dy[c] * rnd(xh[c]).  dw: fp32 [D], zeroed by the caller.
+constexpr int RN_MAXC = 32;                              // columns per thread: D <= 8192
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const elem_t* __restrict__ x, long ldx, const elem_t* __restrict__ w,
+                                                          const elem_t* __restrict__ dy, long lddy, elem_t* __restrict__ dx, long lddx,
+                                                          float* __restrict__ dw, long rows, int D, float eps) {
+    __shared__ float red[4];
+    float dwp[RN_MAXC];
+#pragma unroll
+    for (int i = 0; i < RN_MAXC; ++i) dwp[i] = 0.f;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const elem_t* xr = x + row * ldx;
+        const elem_t* gr = dy + row * lddy;
+        float s2 = 0.f;
+        for (int c = threadIdx.x; c < D; c += 256) { const float v = e2f(xr[c]); s2 += v * v; }
+        s2 = block_sum(s2, red);
+        const float r = rsqrtf(s2 / (float)D + eps);
+        float dot = 0.f;
+        for (int c = threadIdx.x; c < D; c += 256) dot += e2f(gr[c]) * e2f(w[c]) * (e2f(xr[c]) * r);
+        dot = block_sum(dot, red) / (float)D;
+#pragma unroll
+        for (int i = 0; i < RN_MAXC; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < D) {
+                const float xh = e2f(xr[c]) * r, g = e2f(gr[c]);
+                dx[row * lddx + c] = f2e(r * (g * e2f(w[c]) - xh * dot));
+                dwp[i] += g * rnd(xh);
+            }
+        }
+    }
+    if (dw != nullptr) {
+#pragma unroll
+        for (int i = 0; i < RN_MAXC; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < D) atomicAdd(dw + c, dwp[i]);
+        }
+    }
+}
+
+// ---- LlamaMLP activation on the interleaved gate/up layout (groups of 16 gate | 16 up columns, ULL_EPI_SWIGLU's weight order) -----
+// forward: a[m, 16g + j] = rnd(rnd(silu(gate)) * up);  backward: d_gate = da * up * silu'(gate), d_up = da * silu(gate).
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const elem_t* __restrict__ gu, elem_t* __restrict__ a, long M, int I) {
+    const long total = M * I;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / I;
+        const int c = (int)(i % I), g = c >> 4, j = c & 15;
+        const float gate = e2f(gu[m * 2 * I + g * 32 + j]), up = e2f(gu[m * 2 * I + g * 32 + 16 + j]);
+        a[i] = f2e(rnd(act_silu(gate)) * up);
+    }
+}
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const elem_t* __restrict__ gu, const elem_t* __restrict__ da, elem_t* __restrict__ dgu,
+                                                         long M, int I) {
+    const long total = M * I;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / I;
+        const int c = (int)(i % I), g = c >> 4, j = c & 15;
+        const long ig = m * 2 * I + g * 32 + j, iu = ig + 16;
+        const float gate = e2f(gu[ig]), up = e2f(gu[iu]), d = e2f(da[i]);
+        const float s = act_sigmoid(gate);
+        dgu[ig] = f2e(d * up * (s * (1.0f + gate * (1.0f - s))));
+        dgu[iu] = f2e(d * (gate * s));
+    }
+}
+
+// ---- attention backward -----------------------------------------------------------------------------------------------------------
+// O = softmax(mult * Q K^T + mask) V per (batch, head); causal: key j visible to query i iff j <= i + (Sk - Sq); key_mask int32 [B, Sk].
+// Two kernels without atomics: (1) one block per 8 query rows: scores in LDS, softmax statistics (lse), delta = rowsum(dO * O), dQ;
+// (2) one block per 8 keys: recomputes P from lse, accumulates dK / dV over all queries.
+struct AttnBwdArgs {
+    const elem_t *Q, *K, *V, *O, *dO;
+    elem_t *dQ, *dK, *dV;
+    long q_bs, q_hs, q_ss, k_bs, k_hs, k_ss, v_bs, v_hs, v_ss, o_bs, o_hs, o_ss, g_bs, g_hs, g_ss;      // element strides (batch, head, seq)
+    long dq_bs, dq_hs, dq_ss, dk_bs, dk_hs, dk_ss, dv_bs, dv_hs, dv_ss;
+    const int32_t* key_mask;
+    float* lse; float* delta;              // [B, H, Sq] scratch
+    int B, H, Sq, Sk, hd, causal;
+    float mult;                            // S = mult * Q K^T
+};
+constexpr int AB_R = 8;                    // query rows (kernel 1) / keys (kernel 2) per block
+
+ULL_DEV bool attn_visible(const AttnBwdArgs& p, int b, int i, int j) {
+    if (p.causal && j > i + (p.Sk - p.Sq)) return false;
+    return p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = (float*)smem;                            // [AB_R][Sk]
+    float* qs = sc + (long)AB_R * p.Sk;                  // [AB_R][hd]
+    float* gs = qs + AB_R * p.hd;                        // [AB_R][hd]  dO rows
+    float* st = gs + AB_R * p.hd;                        // [AB_R][4]: max, sum, delta, -
+    __shared__ float red[4];
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int i0 = blockIdx.x * AB_R;
+    const int nr = min(AB_R, p.Sq - i0);
+    const int hd = p.hd, Sk = p.Sk, tid = threadIdx.x;
+    for (int e = tid; e < AB_R * hd; e += 256) {
+        const int r = e / hd, d = e % hd;
+        float q = 0.f, g = 0.f;
+        if (r < nr) {
+            q = e2f(p.Q[b * p.q_bs + h * p.q_hs + (long)(i0 + r) * p.q_ss + d]);
+            g = e2f(p.dO[b * p.g_bs + h * p.g_hs + (long)(i0 + r) * p.g_ss + d]);
+        }
+        qs[e] = q; gs[e] = g;
+    }
+    __syncthreads();
+    for (int r = 0; r < AB_R; ++r) {                     // delta_r = sum_d dO * O
+        float v = 0.f;
+        if (r < nr)
+            for (int d = tid; d < hd; d += 256) v += gs[r * hd + d] * e2f(p.O[b * p.o_bs + h * p.o_hs + (long)(i0 + r) * p.o_ss + d]);
+        v = block_sum(v, red);
+        if (tid == 0) st[r * 4 + 2] = v;
+    }
+    // scores
+    for (int j = tid; j < Sk; j += 256) {
+        const elem_t* kp = p.K + b * p.k_bs + h * p.k_hs + (long)j * p.k_ss;
+        float acc[AB_R];
+#pragma unroll
+        for (int r = 0; r < AB_R; ++r) acc[r] = 0.f;
+        for (int d = 0; d < hd; ++d) {
+            const float kv = e2f(kp[d]);
+#pragma unroll
+            for (int r = 0; r < AB_R; ++r) acc[r] += qs[r * hd + d] * kv;
+        }
+#pragma unroll
+        for (int r = 0; r < AB_R; ++r) sc[(long)r * Sk + j] = (r < nr && attn_visible(p, b, i0 + r, j)) ? acc[r] * p.mult : -INFINITY;
+    }
+    __syncthreads();
+    for (int r = 0; r < AB_R; ++r) {
+        float m = -INFINITY;
+        for (int j = tid; j < Sk; j += 256) m = fmaxf(m, sc[(long)r * Sk + j]);
+        m = block_max(m, red);
+        float l = 0.f;
+        for (int j = tid; j < Sk; j += 256) {
+            const float s = sc[(long)r * Sk + j];
+            const float e = (s == -INFINITY) ? 0.f : __expf(s - m);
+            sc[(long)r * Sk + j] = e;
+            l += e;
+        }
+        l = block_sum(l, red);
+        if (tid == 0) { st[r * 4] = m; st[r * 4 + 1] = l; }
+        __syncthreads();
+    }
+    if (tid < nr) {
+        p.lse[(long)bh * p.Sq + i0 + tid] = st[tid * 4] + __logf(st[tid * 4 + 1]);
+        p.delta[(long)bh * p.Sq + i0 + tid] = st[tid * 4 + 2];
+    }
+    // dS = P * (dP - delta) * mult, dP = dO V^T
+    for (int j = tid; j < Sk; j += 256) {
+        const elem_t* vp = p.V + b * p.v_bs + h * p.v_hs + (long)j * p.v_ss;
+        float acc[AB_R];
+#pragma unroll
+        for (int r = 0; r < AB_R; ++r) acc[r] = 0.f;
+        for (int d = 0; d < hd; ++d) {
+            const float vv = e2f(vp[d]);
+#pragma unroll
+            for (int r = 0; r < AB_R; ++r) acc[r] += gs[r * hd + d] * vv;
+        }
+#pragma unroll
+        for (int r = 0; r < AB_R; ++r) {
+            const float l = st[r * 4 + 1];
+            const float pr = l > 0.f ? sc[(long)r * Sk + j] / l : 0.f;
+            sc[(long)r * Sk + j] = pr * (acc[r] - st[r * 4 + 2]) * p.mult;
+        }
+    }
+    __syncthreads();
+    // dQ[r][d] = sum_j dS[r][j] K[j][d]
+    for (int e = tid; e < AB_R * hd; e += 256) {
+        const int r = e / hd, d = e % hd;
+        if (r >= nr) continue;
+        const elem_t* kp = p.K + b * p.k_bs + h * p.k_hs + d;
+        float acc = 0.f;
+        for (int j = 0; j < Sk; ++j) acc += sc[(long)r * Sk + j] * e2f(kp[(long)j * p.k_ss]);
+        p.dQ[b * p.dq_bs + h * p.dq_hs + (long)(i0 + r) * p.dq_ss + d] = f2e(acc);
+    }
+}
+
+constexpr int AB_QC = 32;                                // queries staged per iteration of kernel 2
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int hd = p.hd;
+    float* ks = (float*)smem;                            // [AB_R][hd]
+    float* vs = ks + AB_R * hd;                          // [AB_R][hd]
+    float* qs = vs + AB_R * hd;                          // [AB_QC][hd]
+    float* gs = qs + AB_QC * hd;                         // [AB_QC][hd]
+    float* pb = gs + AB_QC * hd;                         // [AB_QC][AB_R]  P
+    float* db = pb + AB_QC * AB_R;                       // [AB_QC][AB_R]  dS
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int j0 = blockIdx.x * AB_R;
+    const int nk = min(AB_R, p.Sk - j0);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < AB_R * hd; e += 256) {
+        const int r = e / hd, d = e % hd;
+        ks[e] = r < nk ? e2f(p.K[b * p.k_bs + h * p.k_hs + (long)(j0 + r) * p.k_ss + d]) : 0.f;
+        vs[e] = r < nk ? e2f(p.V[b * p.v_bs + h * p.v_hs + (long)(j0 + r) * p.v_ss + d]) : 0.f;
+    }
+    // each thread owns up to 4 (key, dim) outputs of dK and dV
+    float dk[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nout = AB_R * hd;                          // <= 1024
+    for (int i0 = 0; i0 < p.Sq; i0 += AB_QC) {
+        const int nq = min(AB_QC, p.Sq - i0);
+        __syncthreads();
+        for (int e = tid; e < AB_QC * hd; e += 256) {
+            const int r = e / hd, d = e % hd;
+            qs[e] = r < nq ? e2f(p.Q[b * p.q_bs + h * p.q_hs + (long)(i0 + r) * p.q_ss + d]) : 0.f;
+            gs[e] = r < nq ? e2f(p.dO[b * p.g_bs + h * p.g_hs + (long)(i0 + r) * p.g_ss + d]) : 0.f;
+        }
+        __syncthreads();
+        {   // one (query, key) pair per thread
+            const int qi = tid / AB_R, kj = tid % AB_R;
+            float pr = 0.f, ds = 0.f;
+            if (qi < nq && kj < nk && attn_visible(p, b, i0 + qi, j0 + kj)) {
+                float s = 0.f, dp = 0.f;
+                for (int d = 0; d < hd; ++d) { s += qs[qi * hd + d] * ks[kj * hd + d]; dp += gs[qi * hd + d] * vs[kj * hd + d]; }
+                pr = __expf(s * p.mult - p.lse[(long)bh * p.Sq + i0 + qi]);
+                ds = pr * (dp - p.delta[(long)bh * p.Sq + i0 + qi]) * p.mult;
+            }
+            pb[qi * AB_R + kj] = pr;
+            db[qi * AB_R + kj] = ds;
+        }
+        __syncthreads();
+        for (int o = 0; o < 4; ++o) {
+            const int e = tid + o * 256;
+            if (e >= nout) break;
+            const int kj = e / hd, d = e % hd;
+            float a = 0.f, c = 0.f;
+            for (int qi = 0; qi < nq; ++qi) { a += db[qi * AB_R + kj] * qs[qi * hd + d]; c += pb[qi * AB_R + kj] * gs[qi * hd + d]; }
+            dk[o] += a; dv[o] += c;
+        }
+    }
+    for (int o = 0; o < 4; ++o) {
+        const int e = tid + o * 256;
+        if (e >= nout) break;
+        const int kj = e / hd, d = e % hd;
+        if (kj >= nk) continue;
+        p.dK[b * p.dk_bs + h * p.dk_hs + (long)(j0 + kj) * p.dk_ss + d] = f2e(dk[o]);
+        p.dV[b * p.dv_bs + h * p.dv_hs + (long)(j0 + kj) * p.dv_ss + d] = f2e(dv[o]);
+    }
+}
+
+// ---- models/ullava_core.py:327-338 backward: d/dlogits of mean CE(logits[:, :-1], labels[:, 1:]) ----------------------------------
+// dlogits[b, s, :] = (softmax(logits[b, s]) - onehot(labels[b, s + 1])) * g / count for counted positions, 0 elsewhere.
+// stats float[2] = {sum of token losses, counted tokens} from the forward; gout = pointer to the upstream gradient (one float).
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const elem_t* __restrict__ logits, long ld, const int64_t* __restrict__ labels, int S, int V,
+                                                     const float* __restrict__ stats, const float* __restrict__ gout, elem_t* __restrict__ dl) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;                         // (b, s)
+    const int s = (int)(row % S);
+    const elem_t* lr = logits + row * ld;
+    elem_t* dr = dl + row * ld;
+    const long lab = (s + 1 < S) ? labels[row + 1] : -100;
+    if (lab < 0 || lab >= V) {
+        for (int c = threadIdx.x; c < V; c += 256) dr[c] = f2e(0.f);
+        return;
+    }
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < V; c += 256) m = fmaxf(m, e2f(lr[c]));
+    m = block_max(m, red);
+    float l = 0.f;
+    for (int c = threadIdx.x; c < V; c += 256) l += __expf(e2f(lr[c]) - m);
+    l = block_sum(l, red);
+    const float sc = gout[0] / stats[1];
+    for (int c = threadIdx.x; c < V; c += 256) {
+        const float pr = __expf(e2f(lr[c]) - m) / l;
+        dr[c] = f2e((pr - (c == lab ? 1.f : 0.f)) * sc);
+    }
+}
+
+// ---- models/ullava_core.py:191,243-245 backward of the embedding lookup + visual-token splice --------------------------------------
+// rows that came from the token table add into d_table (fp32 [vocab, D], atomics: ids repeat); rows of the spliced span are the
+// gradient of the projected visual features (each written once).
+__global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const int64_t* __restrict__ ids, const elem_t* __restrict__ demb, float* __restrict__ d_table,
+                                                               elem_t* __restrict__ d_img, int n_img_tok, int img_pitch, int img_off,
+                                                               elem_t* __restrict__ d_vid, int n_vid_tok, const int32_t* __restrict__ spans, int S,
+                                                               int D, long vocab) {
+    const long row = blockIdx.x;
+    const int b = (int)(row / S), s = (int)(row % S);
+    const elem_t* g = demb + row * D;
+    if (spans != nullptr) {
+        const int kind = spans[b * 4], pos = spans[b * 4 + 1], idx = spans[b * 4 + 2];
+        if (kind == 1 && d_img != nullptr && s > pos && s <= pos + n_img_tok) {
+            elem_t* o = d_img + ((long)idx * img_pitch + img_off + (s - pos - 1)) * D;
+            for (int c = threadIdx.x; c < D; c += 256) o[c] = g[c];
+            return;
+        }
+        if (kind == 2 && d_vid != nullptr && s > pos && s <= pos + n_vid_tok) {
+            elem_t* o = d_vid + ((long)idx * n_vid_tok + (s - pos - 1)) * D;
+            for (int c = threadIdx.x; c < D; c += 256) o[c] = g[c];
+            return;
+        }
+    }
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    if (d_table != nullptr)
+        for (int c = threadIdx.x; c < D; c += 256) atomicAdd(d_table + id * D + c, e2f(g[c]));
+}
+
+// out[c] = sum_r x[r, c]  (bias gradients), fp32, one block per 64 columns
+__global__ __launch_bounds__(256) void colsum_kernel(const elem_t* __restrict__ x, long ld, long rows, int N, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < N)
+        for (long r = w; r < rows; r += 4) acc += e2f(x[r * ld + c]);
+    part[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && c < N) out[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+inline unsigned nblk(long total, long cap = 16384) {
+    long b = (total + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int ULL_FN(ull_rmsnorm_bwd_)(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw,
+                                    int64_t rows, int64_t D, float eps, void* stream) {
+    if (!x || !w || !dy || !dx || rows <= 0 || D <= 0) return ULL_ERR_ARG;
+    if (D > 256 * RN_MAXC) return ULL_ERR_SHAPE;
+    const unsigned blocks = (unsigned)(rows < 1024 ? rows : 1024);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, ldx, (const elem_t*)w,
+                       (const elem_t*)dy, lddy, (elem_t*)dx, lddx, (float*)dw, (long)rows, (int)D, eps);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_swiglu_fwd_)(const void* gu, void* a, int64_t M, int64_t I, void* stream) {
+    if (!gu || !a || M <= 0 || I <= 0) return ULL_ERR_ARG;
+    if (I & 15) return ULL_ERR_SHAPE;
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(nblk(M * I)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)gu, (elem_t*)a, (long)M, (int)I);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_swiglu_bwd_)(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream) {
+    if (!gu || !da || !dgu || M <= 0 || I <= 0) return ULL_ERR_ARG;
+    if (I & 15) return ULL_ERR_SHAPE;
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(nblk(M * I)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)gu, (const elem_t*)da, (elem_t*)dgu,
+                       (long)M, (int)I);
+    return ull_check_launch();
+}
+
+// strides: 5 x (batch, head, seq) for Q, K, V, O, dO then 3 x for dQ, dK, dV = int64[24]; scratch: float [2, B, H, Sq].
+extern "C" int ULL_FN(ull_attention_bwd_)(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK, void* dV,
+                                      const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd,
+                                      int causal, float mult, void* scratch, void* stream) {
+    if (!Q || !K || !V || !O || !dO || !dQ || !dK || !dV || !strides || !scratch || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return ULL_ERR_ARG;
+    if (hd <= 0 || hd > 128) return ULL_ERR_SHAPE;
+    AttnBwdArgs p;
+    p.Q = (const elem_t*)Q; p.K = (const elem_t*)K; p.V = (const elem_t*)V; p.O = (const elem_t*)O; p.dO = (const elem_t*)dO;
+    p.dQ = (elem_t*)dQ; p.dK = (elem_t*)dK; p.dV = (elem_t*)dV;
+    const int64_t* s = strides;
+    p.q_bs = s[0]; p.q_hs = s[1]; p.q_ss = s[2]; p.k_bs = s[3]; p.k_hs = s[4]; p.k_ss = s[5]; p.v_bs = s[6]; p.v_hs = s[7]; p.v_ss = s[8];
+    p.o_bs = s[9]; p.o_hs = s[10]; p.o_ss = s[11]; p.g_bs = s[12]; p.g_hs = s[13]; p.g_ss = s[14];
+    p.dq_bs = s[15]; p.dq_hs = s[16]; p.dq_ss = s[17]; p.dk_bs = s[18]; p.dk_hs = s[19]; p.dk_ss = s[20]; p.dv_bs = s[21]; p.dv_hs = s[22]; p.dv_ss = s[23];
+    p.key_mask = (const int32_t*)key_mask;
+    p.lse = (float*)scratch; p.delta = (float*)scratch + B * H * Sq;
+    p.B = (int)B; p.H = (int)H; p.Sq = (int)Sq; p.Sk = (int)Sk; p.hd = (int)hd; p.causal = causal; p.mult = mult;
+    const size_t lds1 = ((size_t)AB_R * Sk + 2 * AB_R * hd + AB_R * 4) * sizeof(float);
+    constexpr int MAX_DYN_LDS = 160 * 1024 - 256;        // the kernels also hold a few static LDS words
+    if (lds1 > MAX_DYN_LDS) return ULL_ERR_LDS;
+    static UllOncePerDevice once;
+    if (once.first()) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_DYN_LDS) != hipSuccess) {
+            (void)hipGetLastError();
+            return ULL_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((Sq + AB_R - 1) / AB_R), (unsigned)(B * H)), dim3(256), lds1, (hipStream_t)stream, p);
+    const size_t lds2 = ((size_t)2 * AB_R * hd + 2 * AB_QC * hd + 2 * AB_QC * AB_R) * sizeof(float);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((Sk + AB_R - 1) / AB_R), (unsigned)(B * H)), dim3(256), lds2, (hipStream_t)stream, p);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_shifted_cross_entropy_bwd_)(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V,
+                                                  const void* stats, const void* gout, void* dlogits, void* stream) {
+    if (!logits || !labels || !stats || !gout || !dlogits || B <= 0 || S <= 0 || V <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)logits, ld, (const int64_t*)labels,
+                       (int)S, (int)V, (const float*)stats, (const float*)gout, (elem_t*)dlogits);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_embed_splice_bwd_)(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch,
+                                         int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D,
+                                         int64_t vocab, void* stream) {
+    if (!ids || !demb || B <= 0 || S <= 0 || D <= 0 || vocab <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(embed_splice_bwd_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, (const elem_t*)demb,
+                       (float*)d_table, (elem_t*)d_img, (int)n_img_tok, (int)img_pitch, (int)img_off, (elem_t*)d_vid, (int)n_vid_tok,
+                       (const int32_t*)spans, (int)S, (int)D, (long)vocab);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_colsum_)(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream) {
+    if (!x || !out || rows <= 0 || N <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, ld, (long)rows, (int)N,
+                       (float*)out);
+    return ull_check_launch();
+}

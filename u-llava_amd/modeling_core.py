@@ -18,6 +18,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from . import autograd_ops as A
 from . import ops
 from .configuration import UllavaCoreConfig
 
@@ -363,9 +364,69 @@ class UllavaCoreForCausalLM(nn.Module):
 
     def _project(self, x: torch.Tensor) -> torch.Tensor:
         vp = self.vision_projector
+        if self._training_graph():
+            if not isinstance(vp, Linear):
+                raise NotImplementedError("training path: projector_type 'mlp' (the configured type, configs/train/ullava_core.yaml:5)")
+            return A.linear(x, vp.weight, vp.bias)
         if isinstance(vp, Linear):
             return ops.linear(x, vp.weight, vp.bias)
         return ops.linear(ops.linear(x, vp[0].weight, vp[0].bias, act="gelu"), vp[2].weight, vp[2].bias)
+
+    # -- training path ---------------------------------------------------------------------------------------
+    def _training_graph(self) -> bool:
+        """True when this call must build an autograd graph: gradients enabled and some parameter of the language model or the
+        projector asks for one (the reference freezes / unfreezes by `requires_grad`, train_ullava.py:207-261).  The CLIP tower
+        is frozen by both training scripts and always runs the inference kernels without a graph."""
+        if not torch.is_grad_enabled():
+            return False
+        return any(p.requires_grad for p in self.lm_head.parameters()) or any(p.requires_grad for p in self.model.parameters()) or \
+            any(p.requires_grad for p in self.vision_projector.parameters())
+
+    def enable_input_require_grads(self):
+        """PreTrainedModel API used by train_ullava.py:214 (makes checkpointed segments differentiable in HF); the HIP training path
+        needs nothing here."""
+        return None
+
+    def gradient_checkpointing_enable(self, *args, **kwargs):
+        """train_ullava.py:215.  Activations are kept (288 GB of HBM per GPU): accepted and recorded, not acted upon."""
+        self.config.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.config.gradient_checkpointing = False
+
+    def _llama_train(self, inputs_embeds, attention_mask, position_ids, output_hidden_states):
+        """LlamaModel.forward with an autograd graph: the same HIP forward kernels (SwiGLU un-fused, RoPE stand-alone, weights
+        re-packed under autograd so gradients reach q/k/v/gate/up_proj), HIP backward kernels (autograd_ops.py)."""
+        cfg = self.config
+        B, S, D = inputs_embeds.shape
+        H = cfg.num_attention_heads
+        hd = D // H
+        dev = inputs_embeds.device
+        if position_ids is None:
+            pos = torch.arange(S, device=dev, dtype=torch.int64).repeat(B)
+        else:
+            pos = position_ids.to(torch.int64).expand(B, S).reshape(-1).contiguous()
+        key_mask = None if attention_mask is None else attention_mask.to(torch.int32).contiguous()
+        inv_freq = self._rope_inv_freq(dev)
+        x = inputs_embeds.reshape(B * S, D)
+        all_h = []
+        for l in self.model.layers:
+            if output_hidden_states:
+                all_h.append(x.view(B, S, D))
+            a, m = l.self_attn, l.mlp
+            w_qkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)
+            h = A.rmsnorm(x, l.input_layernorm.weight, cfg.rms_norm_eps)
+            qkv = A.rope(A.linear(h, w_qkv), pos, inv_freq, 2 * H, hd)
+            att = A.self_attention(qkv, key_mask, B, S, H, hd, True)
+            x = A.linear(att, a.o_proj.weight, residual=x)
+            h = A.rmsnorm(x, l.post_attention_layernorm.weight, cfg.rms_norm_eps)
+            gu = A.linear(h, interleave_gate_up(m.gate_proj.weight, m.up_proj.weight))
+            x = A.linear(A.swiglu(gu), m.down_proj.weight, residual=x)
+        x = A.rmsnorm(x, self.model.norm.weight, cfg.rms_norm_eps)
+        last = x.view(B, S, D)
+        if output_hidden_states:
+            all_h.append(last)
+        return last, (tuple(all_h) if output_hidden_states else None)
 
     # -- embedding + splice ----------------------------------------------------------------------------------
     def embed_images_videos(self, input_ids=None, images=None, videos=None):
@@ -377,11 +438,13 @@ class UllavaCoreForCausalLM(nn.Module):
         img_feat = vid_feat = None
         img_tokens = img_pitch = img_off = 0
         if images is not None:
-            h = self._clip_hidden(images)                   # [n, P+1, Dv]; the projector also runs on the CLS row,
+            with torch.no_grad():                           # the CLIP tower is frozen (train_ullava.py:207-208, ullava_core.py:148)
+                h = self._clip_hidden(images)               # [n, P+1, Dv]; the projector also runs on the CLS row,
             img_feat = self._project(h.view(-1, h.shape[-1])).view(h.shape[0], h.shape[1], -1)   # which the splice skips
             img_pitch, img_off, img_tokens = h.shape[1], 1, h.shape[1] - 1
         if videos is not None:
-            v = self.encode_video(videos)
+            with torch.no_grad():
+                v = self.encode_video(videos)
             vid_feat = self._project(v.view(-1, v.shape[-1])).view(v.shape[0], v.shape[1], -1)
         spans = None
         if mm is not None or self.strict_checks:
@@ -397,7 +460,10 @@ class UllavaCoreForCausalLM(nn.Module):
                     raise IndexError("fewer images/videos than samples that reference one")
             if mm is None:
                 spans = None
-        emb = ops.embed_splice(ids, self.model.embed_tokens.weight, img_feat, vid_feat, spans, img_tokens, img_pitch, img_off)
+        if self._training_graph():
+            emb = A.embed_splice(self.model.embed_tokens.weight, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off)
+        else:
+            emb = ops.embed_splice(ids, self.model.embed_tokens.weight, img_feat, vid_feat, spans, img_tokens, img_pitch, img_off)
         return None, emb
 
     # -- LLaMA ---------------------------------------------------------------------------------------------
@@ -496,11 +562,16 @@ class UllavaCoreForCausalLM(nn.Module):
             cache = KVCache(self.config.num_hidden_layers, B_, self.config.num_attention_heads,
                             self.config.hidden_size // self.config.num_attention_heads,
                             max(S_ + getattr(self, "_cache_headroom", 512), 64), inputs_embeds.device, inputs_embeds.dtype)
-        last, all_h = self._llama(inputs_embeds, attention_mask, position_ids, output_hidden_states, cache)
-        logits = ops.linear(last, self.lm_head.weight)
-        loss = None
-        if labels is not None:
-            loss = ops.shifted_cross_entropy(logits, labels)      # forward-only (no autograd on this path)
+        if self._training_graph():
+            if cache is not None:
+                raise NotImplementedError("use_cache / past_key_values are inference features (the training scripts set use_cache=False)")
+            last, all_h = self._llama_train(inputs_embeds, attention_mask, position_ids, output_hidden_states)
+            logits = A.linear(last, self.lm_head.weight)
+            loss = A.shifted_cross_entropy(logits, labels) if labels is not None else None
+        else:
+            last, all_h = self._llama(inputs_embeds, attention_mask, position_ids, output_hidden_states, cache)
+            logits = ops.linear(last, self.lm_head.weight)
+            loss = ops.shifted_cross_entropy(logits, labels) if labels is not None else None
         if not return_dict:
             # reference :346-348: (loss,) + (logits,) + LlamaModel outputs[1:] = past_key_values / hidden_states when requested
             out = (logits,) + ((cache,) if cache is not None else ()) + ((all_h,) if all_h is not None else ())

@@ -514,3 +514,94 @@ def box_losses(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     out = torch.empty(2, device=pred.device, dtype=torch.float32)
     _lib.call("ull_box_losses_f32", _p(pred.contiguous()), DT_CODE[pred.dtype], _p(gt.contiguous()), pred.shape[0], _p(out), _stream())
     return out
+
+
+# ---- backward kernels (training path; see autograd_ops.py) ----------------------------------------------------------------------------
+def rmsnorm_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, need_dw: bool = True):
+    """-> (dx like x, dw float32 [D] or None)."""
+    _chk(x, "x"); _chk(w, "w", x.dtype); _chk(dy, "dy", x.dtype)
+    rows, ldx = _rows(x)
+    D = x.shape[-1]
+    dx = torch.empty_like(x)
+    dw = torch.zeros(D, device=x.device, dtype=torch.float32) if need_dw else None
+    _lib.call("ull_rmsnorm_bwd_" + _SFX[x.dtype], _p(x), ldx, _p(w), _p(dy), _rows(dy)[1], _p(dx), _rows(dx)[1], _p(dw), rows, D, float(eps), _stream())
+    return dx, dw
+
+
+def swiglu_fwd(gu: torch.Tensor) -> torch.Tensor:
+    """gu [M, 2I] in the interleaved gate/up column order -> silu(gate) * up [M, I]."""
+    _chk(gu, "gu")
+    M, I = gu.numel() // gu.shape[-1], gu.shape[-1] // 2
+    a = torch.empty(*gu.shape[:-1], I, device=gu.device, dtype=gu.dtype)
+    _lib.call("ull_swiglu_fwd_" + _SFX[gu.dtype], _p(gu.contiguous()), _p(a), M, I, _stream())
+    return a
+
+
+def swiglu_bwd(gu: torch.Tensor, da: torch.Tensor) -> torch.Tensor:
+    _chk(gu, "gu"); _chk(da, "da", gu.dtype)
+    M, I = gu.numel() // gu.shape[-1], gu.shape[-1] // 2
+    dgu = torch.empty_like(gu)
+    _lib.call("ull_swiglu_bwd_" + _SFX[gu.dtype], _p(gu.contiguous()), _p(da.contiguous()), _p(dgu), M, I, _stream())
+    return dgu
+
+
+def rope_bwd_inplace(dx: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_freq: torch.Tensor, tokens: int, n_heads: int, hd: int):
+    _chk(dx, "dx"); _chk(positions, "positions", torch.int64); _chk(inv_freq, "inv_freq", torch.float32)
+    _lib.call("ull_rope_bwd_inplace_" + _SFX[dx.dtype], _p(dx), row_stride, _p(positions), _p(inv_freq), tokens, n_heads, hd, _stream())
+
+
+def attention_bwd(q, k, v, o, do, dq, dk, dv, strides, key_mask, B: int, H: int, Sq: int, Sk: int, hd: int, causal: bool, mult: float):
+    """strides: 8 triples (batch, head, seq) of element strides for q, k, v, o, do, dq, dk, dv (hd contiguous everywhere)."""
+    import ctypes
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (do, "do"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk(t, n, q.dtype if t is not q else None)
+    if key_mask is not None:
+        _chk(key_mask, "key_mask", torch.int32)
+    flat = [int(x) for tr in strides for x in tr]
+    assert len(flat) == 24
+    arr = (ctypes.c_int64 * 24)(*flat)
+    scratch = torch.empty(2 * B * H * Sq, device=q.device, dtype=torch.float32)
+    _lib.call("ull_attention_bwd_" + _SFX[q.dtype], _p(q), _p(k), _p(v), _p(o), _p(do), _p(dq), _p(dk), _p(dv), arr, _p(key_mask), B, H, Sq, Sk, hd,
+              int(causal), float(mult), _p(scratch), _stream())
+
+
+def shifted_cross_entropy_stats(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """float32 [2] = {sum of token losses, counted tokens} of the shifted CE (the loss is stats[0] / stats[1])."""
+    _chk(logits, "logits"); _chk(labels, "labels", torch.int64)
+    B, S, V = logits.shape
+    acc = torch.zeros(2, device=logits.device, dtype=torch.float32)
+    _lib.call("ull_shifted_cross_entropy_" + _SFX[logits.dtype], _p(logits), logits.stride(1), _p(labels.contiguous()), B, S, V, _p(acc), _stream())
+    return acc
+
+
+def shifted_cross_entropy_bwd(logits: torch.Tensor, labels: torch.Tensor, stats: torch.Tensor, gout: torch.Tensor) -> torch.Tensor:
+    _chk(logits, "logits"); _chk(labels, "labels", torch.int64); _chk(stats, "stats", torch.float32); _chk(gout, "gout", torch.float32)
+    B, S, V = logits.shape
+    dl = torch.empty_like(logits)
+    _lib.call("ull_shifted_cross_entropy_bwd_" + _SFX[logits.dtype], _p(logits), logits.stride(1), _p(labels.contiguous()), B, S, V, _p(stats),
+              _p(gout), _p(dl), _stream())
+    return dl
+
+
+def embed_splice_bwd(ids, demb, vocab: int, img_shape=None, vid_shape=None, spans=None, img_tokens: int = 0, img_pitch: int = 0, img_off: int = 0,
+                     need_table: bool = True):
+    """-> (d_table float32 [vocab, D] or None, d_img [n_img, pitch, D] or None, d_vid or None); rows not written stay zero."""
+    _chk(ids, "input_ids", torch.int64); _chk(demb, "demb")
+    B, S = ids.shape
+    D = demb.shape[-1]
+    d_table = torch.zeros(vocab, D, device=demb.device, dtype=torch.float32) if need_table else None
+    d_img = torch.zeros(img_shape, device=demb.device, dtype=demb.dtype) if img_shape is not None else None
+    d_vid = torch.zeros(vid_shape, device=demb.device, dtype=demb.dtype) if vid_shape is not None else None
+    n_vid = vid_shape[-2] if vid_shape is not None else 0
+    _lib.call("ull_embed_splice_bwd_" + _SFX[demb.dtype], _p(ids), _p(demb.contiguous()), _p(d_table), _p(d_img), img_tokens, img_pitch, img_off,
+              _p(d_vid), n_vid, _p(spans), B, S, D, vocab, _stream())
+    return d_table, d_img, d_vid
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """float32 [N] column sums of x [rows, N]."""
+    _chk(x, "x")
+    rows, ld = _rows(x)
+    out = torch.empty(x.shape[-1], device=x.device, dtype=torch.float32)
+    _lib.call("ull_colsum_" + _SFX[x.dtype], _p(x), ld, rows, x.shape[-1], _p(out), _stream())
+    return out
