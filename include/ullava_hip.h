@@ -263,6 +263,11 @@ int ull_embed_splice_bwd_bf16(const void* ids, const void* demb, void* d_table, 
                               int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab,
                               void* stream);
 
+/* out[i] = scale * sum_r x[r, i] over R contiguous slabs of n elements (fp32 accumulation, one rounding): the local reduction of the
+ * direct-exchange gradient reduce-scatter over xGMI (u-llava_amd/dist.py; the reference delegates this to DeepSpeed ZeRO-2,
+ * configs/deepspeed/bf16_zero2.json:5-11). */
+int ull_sum_slabs_bf16(const void* x, void* out, int64_t R, int64_t n, float scale, void* stream);
+
 /* out float32 [N] = column sums of x [rows, N] (bias gradients). */
 int ull_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
 
@@ -302,6 +307,7 @@ int ull_rope_bwd_inplace_f16(void* dx, int64_t row_stride, const void* positions
 int ull_attention_bwd_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
 int ull_shifted_cross_entropy_bwd_f16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, const void* stats, const void* gout, void* dlogits, void* stream);
 int ull_embed_splice_bwd_f16(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
+int ull_sum_slabs_f16(const void* x, void* out, int64_t R, int64_t n, float scale, void* stream);
 int ull_colsum_f16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
 /* ==== END fp16 twins ==== */
 

@@ -83,3 +83,40 @@ def test_bench_rejects_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--backend", "gloo"], capture_output=True,
                        text=True, timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "launcher started 1 rank" in (r.stderr + r.stdout)
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D = importlib.import_module("u-llava_amd.dist")
+    D.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((7, 5), (33,), (4, 4, 3), (1,))]
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g)
+    params.append(torch.nn.Parameter(torch.zeros(3)))            # no gradient: skipped
+    nb = D.allreduce_gradients(params, bucket_bytes=200)         # forces several buckets
+    q.put((rank, nb, [p.grad.clone() for p in params[:-1]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    """data-parallel gradient averaging (bucketed) over 2 CPU ranks: every rank ends with the mean of the per-rank gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = ((7, 5), (33,), (4, 4, 3), (1,))
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]
+    per_rank = [[torch.randn(s, generator=gens[r]) for s in shapes] for r in range(2)]
+    for (rank, nb, grads) in out:
+        assert nb >= 2
+        for i, g in enumerate(grads):
+            torch.testing.assert_close(g, (per_rank[0][i] + per_rank[1][i]) / 2, rtol=1e-6, atol=1e-6)

@@ -335,6 +335,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const elem_t* __restrict__ 
     if (w == 0 && c < N) out[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
+// out[i] = rnd(scale * sum_r x[r, i]) over R contiguous slabs of n elements, fp32 accumulation: the local reduction of the
+// direct-exchange reduce-scatter of the gradient buckets (every rank receives its shard from every peer, dist.py).
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const elem_t* __restrict__ x, elem_t* __restrict__ out, int R, long n, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += e2f(x[(long)r * n + i]);
+        out[i] = f2e(acc * scale);
+    }
+}
+
 inline unsigned nblk(long total, long cap = 16384) {
     long b = (total + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -422,5 +432,11 @@ extern "C" int ULL_FN(ull_colsum_)(const void* x, int64_t ld, int64_t rows, int6
     if (!x || !out || rows <= 0 || N <= 0) return ULL_ERR_ARG;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, ld, (long)rows, (int)N,
                        (float*)out);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_sum_slabs_)(const void* x, void* out, int64_t R, int64_t n, float scale, void* stream) {
+    if (!x || !out || R <= 0 || n <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (elem_t*)out, (int)R, (long)n, scale);
     return ull_check_launch();
 }

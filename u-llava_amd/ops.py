@@ -605,3 +605,13 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(x.shape[-1], device=x.device, dtype=torch.float32)
     _lib.call("ull_colsum_" + _SFX[x.dtype], _p(x), ld, rows, x.shape[-1], _p(out), _stream())
     return out
+
+
+def sum_slabs(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """x [R, n] -> scale * sum over R (fp32 accumulation), same dtype."""
+    _chk(x, "x")
+    if not x.is_contiguous() or x.dim() != 2:
+        raise RuntimeError("u-llava_amd.sum_slabs: contiguous [R, n] required")
+    out = torch.empty(x.shape[1], device=x.device, dtype=x.dtype)
+    _lib.call("ull_sum_slabs_" + _SFX[x.dtype], _p(x), _p(out), x.shape[0], x.shape[1], float(scale), _stream())
+    return out
