@@ -263,6 +263,22 @@ int ull_embed_splice_bwd_bf16(const void* ids, const void* demb, void* d_table, 
                               int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab,
                               void* stream);
 
+/* torch.nn.LayerNorm backward (SAM transformer.py norm1-4 / norm_final_attn): dx; dw, db float32 [D] += (caller zeroes; may be NULL). */
+int ull_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, void* db,
+                           int64_t rows, int64_t D, float eps, void* stream);
+
+/* common.py:31-43 LayerNorm2d backward on channels-last rows; gelu != 0: dy is the gradient AFTER the fused nn.GELU. */
+int ull_layernorm2d_cl_bwd_bf16(const void* x, const void* w, const void* b, const void* dy, void* dx, void* dw, void* db, int64_t rows,
+                                int64_t C, float eps, int gelu, void* stream);
+
+/* torch.nn.GELU (erf) as a stand-alone op of the training path, and its backward. */
+int ull_gelu_fwd_bf16(const void* x, void* y, int64_t n, void* stream);
+int ull_gelu_bwd_bf16(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+
+/* Backward of ull_mask_matmul_bf16: dhyper float32 [n, T, C] += (caller zeroes), dup in `up`'s blocked layout.  T <= 8, C <= 32. */
+int ull_mask_matmul_bwd_bf16(const void* hyper, const void* up, const void* dmasks, void* dhyper, void* dup, int64_t n, int64_t T, int64_t C,
+                             int64_t G, void* stream);
+
 /* out[i] = scale * sum_r x[r, i] over R contiguous slabs of n elements (fp32 accumulation, one rounding): the local reduction of the
  * direct-exchange gradient reduce-scatter over xGMI (u-llava_amd/dist.py; the reference delegates this to DeepSpeed ZeRO-2,
  * configs/deepspeed/bf16_zero2.json:5-11). */
@@ -270,6 +286,14 @@ int ull_sum_slabs_bf16(const void* x, void* out, int64_t R, int64_t n, float sca
 
 /* out float32 [N] = column sums of x [rows, N] (bias gradients). */
 int ull_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
+
+/* Backward of ull_mask_loss_sums_f32 (g float32 [n_masks, 4] -> dlogits float32 [n_masks, hw]), of ull_box_losses_f32 (gw float32[2] ->
+ * dpred float32 [n, 4]) and the adjoint of ull_bilinear_f32 (din float32, zeroed by the caller; atomics). */
+int ull_mask_loss_sums_bwd_f32(const void* logits, const void* target, const void* g, int64_t n_masks, int64_t hw, float scale, void* dlogits,
+                               void* stream);
+int ull_box_losses_bwd_f32(const void* pred, int pred_dtype, const void* gt, int64_t n, const void* gw, void* dpred, void* stream);
+int ull_bilinear_bwd_f32(const void* dout, void* din, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w, int64_t n,
+                         int64_t out_h, int64_t out_w, void* stream);
 
 /* ==== BEGIN fp16 twins (generated by tools/gen_header_f16.py) ==== */
 /* IEEE binary16 build of every dtype-dependent entry point: same arguments, layouts, flags and rounding points as the *_bf16
@@ -307,6 +331,11 @@ int ull_rope_bwd_inplace_f16(void* dx, int64_t row_stride, const void* positions
 int ull_attention_bwd_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
 int ull_shifted_cross_entropy_bwd_f16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, const void* stats, const void* gout, void* dlogits, void* stream);
 int ull_embed_splice_bwd_f16(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
+int ull_layernorm_bwd_f16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, void* db, int64_t rows, int64_t D, float eps, void* stream);
+int ull_layernorm2d_cl_bwd_f16(const void* x, const void* w, const void* b, const void* dy, void* dx, void* dw, void* db, int64_t rows, int64_t C, float eps, int gelu, void* stream);
+int ull_gelu_fwd_f16(const void* x, void* y, int64_t n, void* stream);
+int ull_gelu_bwd_f16(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+int ull_mask_matmul_bwd_f16(const void* hyper, const void* up, const void* dmasks, void* dhyper, void* dup, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
 int ull_sum_slabs_f16(const void* x, void* out, int64_t R, int64_t n, float scale, void* stream);
 int ull_colsum_f16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
 /* ==== END fp16 twins ==== */

@@ -491,6 +491,62 @@ def gen_core_grads(name, dtype, seed):
                     loss=r.loss.detach(), grads=ref_grads))
 
 
+# --------------------------------------------------------------------------- G13 gradients of the full RES / REC training loss
+def gen_full_grads(name, dtype, seed):
+    """UllavaForCausalLM.forward(inference=False)["loss"].backward() with the trainable set of train_ullava.py:207-261 (no LoRA: the
+    language model, lm_head, embed_tokens, projector; seg / det projectors, det_decoder, mask_decoder except its IoU head; CLIP and the
+    rest of SAM frozen).  Reference .grad of every parameter that received one; oracle autograd must agree bit for bit."""
+    print(f"[{name}]")
+    m, cfg, shapes, sd, ocfg, ids, mask, images, images_sam, size_list, resize_list = _full_setup(dtype, seed)
+    m.train()
+    for n_, p_ in m.named_parameters():
+        p_.requires_grad = False
+    for p_ in m.llm.model.parameters():
+        p_.requires_grad = True
+    for p_ in m.llm.lm_head.parameters():
+        p_.requires_grad = True
+    for p_ in m.llm.vision_projector.parameters():
+        p_.requires_grad = True
+    for n_, p_ in m.named_parameters():
+        if any(x in n_ for x in ["lm_head", "embed_tokens", "seg_projector", "mask_decoder", "det_projector", "det_decoder"]):
+            p_.requires_grad = "mask_decoder.iou_prediction_head" not in n_
+    g = torch.Generator().manual_seed(seed + 23)
+    n_seg, n_loc = [2, 1], [1, 2]
+    gt_masks = [(torch.rand(n_seg[i], *size_list[i], generator=g) > 0.7).float() for i in range(2)]
+    xy = [torch.rand(n_loc[i], 2, generator=g) * 0.5 for i in range(2)]
+    gt_boxes = [torch.cat([xy[i], xy[i] + 0.1 + torch.rand(n_loc[i], 2, generator=g) * 0.4], dim=1) for i in range(2)]
+    labels = ids.clone()
+    labels[:, :7] = -100
+    labels[mask == 0] = -100
+    r = m(images_sam=images_sam, images=images, input_ids=ids, labels=labels, attention_mask=mask, mask_list=gt_masks,
+          size_list=size_list, resize_list=resize_list, bbox_list=gt_boxes, inference=False)
+    r["loss"].backward()
+    ref_grads = {n_: p_.grad.detach().clone() for n_, p_ in m.named_parameters() if p_.grad is not None}
+    trainable = {n_ for n_, p_ in m.named_parameters() if p_.requires_grad}
+    leaves = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    o = O.ullava_forward(leaves, ocfg, images_sam, images, ids, mask, size_list, resize_list, labels=labels)
+    w = dict(ce_weight=cfg.ce_weight, bce_weight=cfg.bce_weight, dice_weight=cfg.dice_weight, l1_weight=cfg.l1_weight, iou_weight=cfg.iou_weight)
+    ol = O.ullava_losses(o["pred_masks"], o["pred_boxes"], gt_masks, gt_boxes, o["ce_loss"], w)
+    eq(ol["loss"].detach(), r["loss"].detach(), "loss")
+    ol["loss"].backward()
+    for k, gr in ref_grads.items():
+        assert leaves[k].grad is not None, k
+        eq(leaves[k].grad, gr, f"grad[{k}]")
+    print(f"   loss {float(r['loss']):.5f}; {len(ref_grads)} parameter gradients bit-exact between reference and oracle autograd")
+    # the decoder / projector gradients are what this fixture adds over G12: keep those whole, the language-model ones as norms
+    # (G12 already stores them whole); every gradient is kept as a strided sample of at most 8192 elements + its exact L2 norm
+    keep = {}
+    for k, v in ref_grads.items():
+        if k.startswith("llm.model.layers.") or "embed_tokens" in k or "lm_head" in k:
+            continue
+        st = max(1, -(-v.numel() // 8192))
+        keep[k] = dict(stride=st, sample=v.reshape(-1)[::st].contiguous())
+    norms = {k: float(v.float().norm()) for k, v in ref_grads.items()}
+    save(name, dict(cfg=ocfg, weights=w, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=ids, attention_mask=mask, labels=labels,
+                    images=images, images_sam_seed=seed + 19, gt_seed=seed + 23, size_list=size_list, resize_list=resize_list, gt_boxes=gt_boxes,
+                    loss=r["loss"].detach().float(), grads=keep, grad_norms=norms, trainable=sorted(trainable)))
+
+
 def gen_signatures(name):
     """inspect.signature of the reference's public model surface: parameter names, order and defaults."""
     import inspect
@@ -545,6 +601,9 @@ if __name__ == "__main__":
         gen_sam_blocks("g9_sam_blocks_bf16.pt", torch.bfloat16, 9)
     if want("evaluate"):
         gen_evaluate("g11_evaluate_bf16.pt", torch.bfloat16, 8)
+    if want("fullgrads"):
+        gen_full_grads("g13_full_grads_fp32.pt", torch.float32, 8)
+        gen_full_grads("g13_full_grads_bf16.pt", torch.bfloat16, 8)
     if want("grads"):
         gen_core_grads("g12_core_grads_fp32.pt", torch.float32, 12)
         gen_core_grads("g12_core_grads_bf16.pt", torch.bfloat16, 12)

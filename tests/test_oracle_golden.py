@@ -161,3 +161,27 @@ def test_core_gradients_g12(name):
     assert len(fx["grads"]) == 23
     for k, g in fx["grads"].items():
         _eq(leaves[k].grad, g)
+
+
+def test_full_training_gradients_g13():
+    """autograd through oracle forward + losses == the reference's forward(inference=False)['loss'].backward() on the trainable set of
+    train_ullava.py:207-261 (strided samples + exact norms of 151 gradients; fp32 fixture, the bf16 one is replayed on the GPU box)."""
+    fx = load_fixture("g13_full_grads_fp32.pt")
+    sd = fixture_state_dict(fx, torch.float32)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g)
+    g2 = torch.Generator().manual_seed(fx["gt_seed"])
+    gt_masks = [(torch.rand(n, *fx["size_list"][i], generator=g2) > 0.7).float() for i, n in enumerate([2, 1])]
+    trainable = set(fx["trainable"])
+    leaves = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    o = O.ullava_forward(leaves, fx["cfg"], images_sam, fx["images"], fx["input_ids"], fx["attention_mask"], fx["size_list"], fx["resize_list"],
+                         labels=fx["labels"])
+    ol = O.ullava_losses(o["pred_masks"], o["pred_boxes"], gt_masks, fx["gt_boxes"], o["ce_loss"], fx["weights"])
+    assert torch.equal(ol["loss"].detach().float(), fx["loss"])
+    ol["loss"].backward()
+    assert len(fx["grad_norms"]) == 151
+    for k, nrm in fx["grad_norms"].items():
+        assert float(leaves[k].grad.float().norm()) == nrm, k
+    for k, rec in fx["grads"].items():
+        _eq(leaves[k].grad.reshape(-1)[::rec["stride"]].contiguous(), rec["sample"])

@@ -28,6 +28,14 @@ SIGNATURES = {
     "ull_embed_splice_bwd_bf16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr],
     "ull_colsum_bf16": [_ptr, _i64, _i64, _i64, _ptr, _ptr],
     "ull_sum_slabs_bf16": [_ptr, _ptr, _i64, _i64, _f32, _ptr],
+    "ull_layernorm_bwd_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _f32, _ptr],
+    "ull_layernorm2d_cl_bwd_bf16": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _i32, _ptr],
+    "ull_gelu_fwd_bf16": [_ptr, _ptr, _i64, _ptr],
+    "ull_gelu_bwd_bf16": [_ptr, _ptr, _ptr, _i64, _ptr],
+    "ull_mask_matmul_bwd_bf16": [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
+    "ull_mask_loss_sums_bwd_f32": [_ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr, _ptr],
+    "ull_box_losses_bwd_f32": [_ptr, _i32, _ptr, _i64, _ptr, _ptr, _ptr],
+    "ull_bilinear_bwd_f32": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_gemv_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_gemv_rmsnorm_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],

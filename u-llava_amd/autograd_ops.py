@@ -15,7 +15,9 @@ from . import ops
 
 def _t(x: torch.Tensor) -> torch.Tensor:
     """[R, C] -> contiguous [C, R] (data movement for the transposed-operand GEMMs of Linear backward)."""
-    return x.t().contiguous()
+    out = torch.empty(x.shape[1], x.shape[0], device=x.device, dtype=x.dtype)      # fresh buffer: canonical strides also for size-1 dims
+    out.copy_(x.t())
+    return out
 
 
 class _Linear(torch.autograd.Function):
@@ -180,3 +182,176 @@ class _EmbedSplice(torch.autograd.Function):
 
 def embed_splice(table, img_feat, vid_feat, ids, spans, img_tokens=0, img_pitch=0, img_off=0):
     return _EmbedSplice.apply(table, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off)
+
+
+# ---- SAM mask decoder / postprocess / losses (training of `mask_decoder`, seg / det heads: train_ullava.py:248-261) ------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return ops.layernorm(x, w, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = ops.layernorm_bwd(x, w, dy.contiguous(), ctx.eps, need_wb=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, (dw.to(w.dtype) if dw is not None else None), (db.to(w.dtype) if db is not None else None), None
+
+
+def layernorm(x, w, b, eps):
+    return _LayerNorm.apply(x, w, b, eps)
+
+
+class _LayerNorm2dCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, gelu):
+        ctx.save_for_backward(x, w, b)
+        ctx.eps, ctx.gelu = eps, gelu
+        return ops.layernorm2d_cl(x, w, b, eps, gelu)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        dx, dw, db = ops.layernorm2d_cl_bwd(x, w, b, dy, ctx.eps, ctx.gelu)
+        return dx, dw.to(w.dtype), db.to(w.dtype), None, None
+
+
+def layernorm2d_cl(x, w, b, eps=1e-6, gelu=False):
+    return _LayerNorm2dCL.apply(x, w, b, eps, gelu)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(x, dy)
+
+
+def gelu(x):
+    return _Gelu.apply(x)
+
+
+class _Add(torch.autograd.Function):
+    """rnd(a + b[row % b_rows]) (ops.add_rows); gradients pass through (b's only when it is not broadcast)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.same = a.shape == b.shape
+        return ops.add_rows(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        if ctx.needs_input_grad[1] and not ctx.same:
+            raise NotImplementedError("gradient of a broadcast operand of add_rows")
+        return d, (d if ctx.needs_input_grad[1] else None)
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Attention(torch.autograd.Function):
+    """SAM decoder attention (transformer.py:220-242): separate projected q [n*Sq, Di], k / v [n*Sk, Di], softmax(q k^T / sqrt(hd)) v."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, n, H, Sq, Sk):
+        import math
+        Di = q.shape[-1]
+        hd = Di // H
+        vt = ops.transpose_v(v, Sk * Di, Di, n, Sk, H, hd)
+        att = torch.empty(n * Sq, Di, device=q.device, dtype=q.dtype)
+        ops.attention(q, k, vt, att, n, H, Sq, Sk, hd, (Sq * Di, hd, Di), (Sk * Di, hd, Di), (Sq * Di, hd, Di), None, causal=False, scale_mode=2,
+                      scale=math.sqrt(hd))
+        ctx.save_for_backward(q, k, v, att)
+        ctx.dims = (n, H, Sq, Sk, hd)
+        return att
+
+    @staticmethod
+    def backward(ctx, datt):
+        q, k, v, att = ctx.saved_tensors
+        n, H, Sq, Sk, hd = ctx.dims
+        Di = H * hd
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        sq, sk = (Sq * Di, hd, Di), (Sk * Di, hd, Di)
+        ops.attention_bwd(q, k, v, att, datt.contiguous(), dq, dk, dv, (sq, sk, sk, sq, sq, sq, sk, sk), None, n, H, Sq, Sk, hd, False, hd ** -0.5)
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, n, H, Sq, Sk):
+    return _Attention.apply(q, k, v, n, H, Sq, Sk)
+
+
+class _MaskMatmul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hyper, up, n, T, C, G):
+        ctx.save_for_backward(hyper, up)
+        ctx.dims = (n, T, C, G)
+        return ops.mask_matmul(hyper, up, n, T, C, G)
+
+    @staticmethod
+    def backward(ctx, dm):
+        hyper, up = ctx.saved_tensors
+        n, T, C, G = ctx.dims
+        dh, dup = ops.mask_matmul_bwd(hyper, up, dm, n, T, C, G)
+        return dh.to(hyper.dtype), dup, None, None, None, None
+
+
+def mask_matmul(hyper, up, n, T, C, G):
+    return _MaskMatmul.apply(hyper, up, n, T, C, G)
+
+
+class _Bilinear(torch.autograd.Function):
+    """ops.bilinear (fp32 output) with its adjoint; the gradient is returned in the input's dtype."""
+
+    @staticmethod
+    def forward(ctx, x, in_h, in_w, out_h, out_w):
+        ctx.meta = (tuple(x.shape[-2:]), in_h, in_w, x.dtype)
+        return ops.bilinear(x, in_h, in_w, out_h, out_w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        full, in_h, in_w, dt = ctx.meta
+        return ops.bilinear_bwd(dout.contiguous(), full, in_h, in_w).to(dt), None, None, None, None
+
+
+def bilinear(x, in_h, in_w, out_h, out_w):
+    return _Bilinear.apply(x, in_h, in_w, out_h, out_w)
+
+
+class _MaskLossSums(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, scale):
+        ctx.save_for_backward(logits, target)
+        ctx.scale = scale
+        return ops.mask_loss_sums(logits, target, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target = ctx.saved_tensors
+        return ops.mask_loss_sums_bwd(logits, target, g.float().contiguous(), ctx.scale), None, None
+
+
+def mask_loss_sums(logits, target, scale=1000.0):
+    return _MaskLossSums.apply(logits, target, scale)
+
+
+class _BoxLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt):
+        ctx.save_for_backward(pred, gt)
+        return ops.box_losses(pred, gt)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt = ctx.saved_tensors
+        return ops.box_losses_bwd(pred, gt, g.float().contiguous()).to(pred.dtype), None
+
+
+def box_losses(pred, gt):
+    return _BoxLosses.apply(pred, gt)

@@ -345,6 +345,152 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const elem_t* __restrict
     }
 }
 
+// ---- torch.nn.LayerNorm backward (SAM TwoWayAttentionBlock.norm1-4, norm_final_attn): y = ((x - mean) * rstd) * w + b ---------------
+// dx = rstd * (g - mean(g) - xh * mean(g * xh)), g = dy * w;  dw += dy * xh, db += dy (fp32 [D], zeroed by the caller).
+constexpr int LN_MAXC = 8;                               // columns per thread: D <= 2048
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const elem_t* __restrict__ x, long ldx, const elem_t* __restrict__ w,
+                                                            const elem_t* __restrict__ dy, long lddy, elem_t* __restrict__ dx, long lddx,
+                                                            float* __restrict__ dw, float* __restrict__ db, long rows, int D, float eps) {
+    __shared__ float red[4];
+    float dwp[LN_MAXC], dbp[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) dwp[i] = dbp[i] = 0.f;
+    const float invD = 1.0f / (float)D;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const elem_t* xr = x + row * ldx;
+        const elem_t* gr = dy + row * lddy;
+        float s1 = 0.f;
+        for (int c = threadIdx.x; c < D; c += 256) s1 += e2f(xr[c]);
+        const float mean = block_sum(s1, red) * invD;
+        float s2 = 0.f;
+        for (int c = threadIdx.x; c < D; c += 256) { const float d = e2f(xr[c]) - mean; s2 += d * d; }
+        const float rstd = 1.0f / sqrtf(block_sum(s2, red) * invD + eps);
+        float a = 0.f, bsum = 0.f;
+        for (int c = threadIdx.x; c < D; c += 256) {
+            const float g = e2f(gr[c]) * e2f(w[c]);
+            a += g;
+            bsum += g * (e2f(xr[c]) - mean) * rstd;
+        }
+        a = block_sum(a, red) * invD;
+        bsum = block_sum(bsum, red) * invD;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = threadIdx.x + i * 256;
+            if (c < D) {
+                const float xh = (e2f(xr[c]) - mean) * rstd, g0 = e2f(gr[c]);
+                dx[row * lddx + c] = f2e(rstd * (g0 * e2f(w[c]) - a - xh * bsum));
+                dwp[i] += g0 * xh;
+                dbp[i] += g0;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < D) {
+            if (dw != nullptr) atomicAdd(dw + c, dwp[i]);
+            if (db != nullptr) atomicAdd(db + c, dbp[i]);
+        }
+    }
+}
+
+ULL_DEV float gelu_grad(float x) {                       // d/dx [0.5 x (1 + erf(x / sqrt 2))]
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// ---- common.py:31-43 LayerNorm2d (+ the nn.GELU that follows it in output_upscaling) backward on channels-last rows [rows, C] --------
+// one wave per row, C <= 512; the forward's LN output is recomputed in fp32.
+__global__ __launch_bounds__(256) void layernorm2d_cl_bwd_kernel(const elem_t* __restrict__ x, const elem_t* __restrict__ w, const elem_t* __restrict__ b,
+                                                                 const elem_t* __restrict__ dy, elem_t* __restrict__ dx, float* __restrict__ dw,
+                                                                 float* __restrict__ db, long rows, int C, float eps, int gelu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dwp[8], dbp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dwp[i] = dbp[i] = 0.f;
+    const float invC = 1.0f / (float)C;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const elem_t* xr = x + row * C;
+        float s1 = 0.f;
+        for (int c = lane; c < C; c += 64) s1 += e2f(xr[c]);
+        const float mean = wave_sum(s1) * invC;
+        float s2 = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = e2f(xr[c]) - mean; s2 += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) * invC + eps);
+        float gv[8], xh[8], a = 0.f, bs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + i * 64;
+            gv[i] = xh[i] = 0.f;
+            if (c < C) {
+                xh[i] = (e2f(xr[c]) - mean) * rstd;
+                float g0 = e2f(dy[row * C + c]);
+                if (gelu) g0 *= gelu_grad(e2f(w[c]) * xh[i] + e2f(b[c]));
+                gv[i] = g0;
+                a += g0 * e2f(w[c]);
+                bs += g0 * e2f(w[c]) * xh[i];
+            }
+        }
+        a = wave_sum(a) * invC;
+        bs = wave_sum(bs) * invC;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + i * 64;
+            if (c < C) {
+                dx[row * C + c] = f2e(rstd * (gv[i] * e2f(w[c]) - a - xh[i] * bs));
+                dwp[i] += gv[i] * xh[i];
+                dbp[i] += gv[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + i * 64;
+        if (c < C) {
+            if (dw != nullptr) atomicAdd(dw + c, dwp[i]);
+            if (db != nullptr) atomicAdd(db + c, dbp[i]);
+        }
+    }
+}
+
+// ---- torch.nn.GELU (erf) as its own op on the training path (the inference path fuses it into the GEMM epilogue) ------------------------
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const elem_t* __restrict__ x, elem_t* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = f2e(act_gelu_erf(e2f(x[i])));
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const elem_t* __restrict__ x, const elem_t* __restrict__ dy, elem_t* __restrict__ dx, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dx[i] = f2e(e2f(dy[i]) * gelu_grad(e2f(x[i])));
+}
+
+// ---- mask_decoder.py:150-158 backward of masks = hyper_in @ upscaled (blocked `up` layout of mask_matmul_kernel) ------------------------
+// dup[i][c] = sum_t dm[n, t, Y, X] * hyper[n, t, c];  dhyper[n, t, c] += sum_pixels dm * up  (fp32, zeroed by the caller).
+__global__ __launch_bounds__(256) void mask_matmul_bwd_kernel(const elem_t* __restrict__ hyper, const elem_t* __restrict__ up, const elem_t* __restrict__ dm,
+                                                              float* __restrict__ dhyper, elem_t* __restrict__ dup, int T, int Cc, int G, long per_n) {
+    __shared__ float acc[8 * 32];                            // [T <= 8][Cc <= 32]
+    const long n = blockIdx.y;
+    for (int e = threadIdx.x; e < T * Cc; e += 256) acc[e] = 0.f;
+    __syncthreads();
+    const int HW = 4 * G;
+    for (long il = (long)blockIdx.x * 256 + threadIdx.x; il < per_n; il += (long)gridDim.x * 256) {
+        const long i = n * per_n + il;
+        const int d2 = (int)(il & 3), d1 = (int)((il >> 2) & 3);
+        const long cell = il >> 4;
+        const int xx = (int)(cell % G), y = (int)(cell / G);
+        const int Y = 4 * y + 2 * (d1 >> 1) + (d2 >> 1), X = 4 * xx + 2 * (d1 & 1) + (d2 & 1);
+        float g[8];
+        for (int t = 0; t < T; ++t) g[t] = e2f(dm[((n * T + t) * HW + Y) * (long)HW + X]);
+        for (int c = 0; c < Cc; ++c) {
+            const float u = e2f(up[i * Cc + c]);
+            float d = 0.f;
+            for (int t = 0; t < T; ++t) {
+                d += g[t] * e2f(hyper[(n * T + t) * Cc + c]);
+                if (g[t] != 0.f) atomicAdd(&acc[t * Cc + c], g[t] * u);
+            }
+            dup[i * Cc + c] = f2e(d);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * Cc; e += 256) atomicAdd(dhyper + n * T * Cc + e, acc[e]);
+}
+
 inline unsigned nblk(long total, long cap = 16384) {
     long b = (total + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -438,5 +584,48 @@ extern "C" int ULL_FN(ull_colsum_)(const void* x, int64_t ld, int64_t rows, int6
 extern "C" int ULL_FN(ull_sum_slabs_)(const void* x, void* out, int64_t R, int64_t n, float scale, void* stream) {
     if (!x || !out || R <= 0 || n <= 0) return ULL_ERR_ARG;
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (elem_t*)out, (int)R, (long)n, scale);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_layernorm_bwd_)(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw,
+                                      void* db, int64_t rows, int64_t D, float eps, void* stream) {
+    if (!x || !w || !dy || !dx || rows <= 0 || D <= 0) return ULL_ERR_ARG;
+    if (D > 256 * LN_MAXC) return ULL_ERR_SHAPE;
+    const unsigned blocks = (unsigned)(rows < 2048 ? rows : 2048);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, ldx, (const elem_t*)w,
+                       (const elem_t*)dy, lddy, (elem_t*)dx, lddx, (float*)dw, (float*)db, (long)rows, (int)D, eps);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_layernorm2d_cl_bwd_)(const void* x, const void* w, const void* b, const void* dy, void* dx, void* dw, void* db, int64_t rows,
+                                           int64_t C, float eps, int gelu, void* stream) {
+    if (!x || !w || !b || !dy || !dx || rows <= 0 || C <= 0) return ULL_ERR_ARG;
+    if (C > 512) return ULL_ERR_SHAPE;
+    const long want = (rows + 3) / 4;
+    hipLaunchKernelGGL(layernorm2d_cl_bwd_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x,
+                       (const elem_t*)w, (const elem_t*)b, (const elem_t*)dy, (elem_t*)dx, (float*)dw, (float*)db, (long)rows, (int)C, eps, gelu);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_gelu_fwd_)(const void* x, void* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (elem_t*)y, (long)n);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_gelu_bwd_)(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+    if (!x || !dy || !dx || n <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (const elem_t*)dy, (elem_t*)dx, (long)n);
+    return ull_check_launch();
+}
+
+extern "C" int ULL_FN(ull_mask_matmul_bwd_)(const void* hyper, const void* up, const void* dmasks, void* dhyper, void* dup, int64_t n, int64_t T,
+                                        int64_t C, int64_t G, void* stream) {
+    if (!hyper || !up || !dmasks || !dhyper || !dup || n <= 0 || G <= 0) return ULL_ERR_ARG;
+    if (T > 8 || C > 32 || T <= 0 || C <= 0) return ULL_ERR_SHAPE;
+    const long per_n = G * G * 16;
+    hipLaunchKernelGGL(mask_matmul_bwd_kernel, dim3((unsigned)((per_n + 255) / 256 < 256 ? (per_n + 255) / 256 : 256), (unsigned)n), dim3(256), 0,
+                       (hipStream_t)stream, (const elem_t*)hyper, (const elem_t*)up, (const elem_t*)dmasks, (float*)dhyper, (elem_t*)dup, (int)T, (int)C,
+                       (int)G, per_n);
     return ull_check_launch();
 }

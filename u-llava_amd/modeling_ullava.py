@@ -12,6 +12,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from . import autograd_ops as A
 from . import ops
 from .configuration import UllavaConfig
 from .modeling_core import BF16, Linear, UllavaCoreForCausalLM, _Holder
@@ -45,6 +46,15 @@ class UllavaForCausalLM(nn.Module):
         self.det_projector = _mlp_seq([D, D, O], device, dtype, dropout_tail=True)            # ullava.py:86-91
         self.det_decoder = _mlp_seq([O, O, O // 2, 4], device, dtype)                         # ullava.py:96-102
         self._sam = SamEngine(self.visual_model, config.sam_config)
+        # trainability defaults of the reference's constructor (ullava.py:84-130): the projectors and the box decoder are trainable,
+        # SAM is frozen except -- with config.train_mask_decoder -- its mask decoder.  (The language model's parameters default to
+        # frozen here; train_ullava.py:239-261 switches on what it trains by name, exactly as it does for the reference.)
+        for mod in (self.seg_projector, self.det_projector, self.det_decoder):
+            for p_ in mod.parameters():
+                p_.requires_grad = True
+        if getattr(config, "train_mask_decoder", True):
+            for p_ in self.visual_model.mask_decoder.parameters():
+                p_.requires_grad = True
         self.overlap_sam_encoder = True     # SAM image encoder on a second HIP stream beside CLIP + LLaMA (False: same stream)
 
     @classmethod
@@ -105,26 +115,40 @@ class UllavaForCausalLM(nn.Module):
         return tm.view(B, g, g, C).permute(0, 3, 1, 2).contiguous()
 
     # -- shared tail of forward / evaluate -----------------------------------------------------------------------------
-    def _run_mlp(self, seq, x):
+    def _heads_training_graph(self) -> bool:
+        """gradients enabled and one of the heads on top of the language model is trainable (train_ullava.py:248-261: seg / det
+        projectors, det_decoder, mask_decoder)."""
+        if not torch.is_grad_enabled():
+            return False
+        mods = (self.seg_projector, self.det_projector, self.det_decoder, self.visual_model.mask_decoder)
+        return any(p.requires_grad for m in mods for p in m.parameters())
+
+    def _run_mlp(self, seq, x, train: bool = False):
         lin = [m for m in seq if isinstance(m, Linear)]
         for i, l in enumerate(lin):
-            x = ops.linear(x, l.weight, l.bias, act="relu" if i < len(lin) - 1 else None)
+            if train:
+                x = A.linear(x, l.weight, l.bias, relu=i < len(lin) - 1)
+            else:
+                x = ops.linear(x, l.weight, l.bias, act="relu" if i < len(lin) - 1 else None)
         return x
 
-    def _select(self, last_hidden: torch.Tensor, token_mask: torch.Tensor, projector) -> List[torch.Tensor]:
+    def _select(self, last_hidden: torch.Tensor, token_mask: torch.Tensor, projector, train: bool = False) -> List[torch.Tensor]:
         """rows of last_hidden [B, L, D] where token_mask [B, L] is set -> per-sample [n_i, out_dim] after the projector."""
         B, L, D = last_hidden.shape
         counts = token_mask.sum(-1).tolist()                       # host sync (the reference indexes device offsets too)
         idx = token_mask.reshape(-1).nonzero().squeeze(-1)
-        rows = ops.gather_rows(last_hidden.reshape(B * L, D), idx)
-        emb = self._run_mlp(projector, rows) if rows.shape[0] else rows.new_empty(0, self.config.out_dim)
+        if train:
+            rows = last_hidden.reshape(B * L, D)[idx]               # gather (data movement) recorded by autograd
+        else:
+            rows = ops.gather_rows(last_hidden.reshape(B * L, D), idx)
+        emb = self._run_mlp(projector, rows, train) if rows.shape[0] else rows.new_empty(0, self.config.out_dim)
         out, o = [], 0
         for c in counts:
             out.append(emb[o:o + c])
             o += c
         return out
 
-    def _decode(self, image_embeddings_tm, pred_embeddings, resize_list, size_list):
+    def _decode(self, image_embeddings_tm, pred_embeddings, resize_list, size_list, train: bool = False):
         """prompt encoder + mask decoder + postprocess.  The reference decodes one image at a time (ullava.py:228-252); every op of
         the decoder is independent per prompt, so all prompts of the batch go through one chain of launches here (the per-image
         chains were host-launch-bound: ~70 small kernels each) and only the two resizes of postprocess_masks stay per image."""
@@ -133,7 +157,11 @@ class UllavaForCausalLM(nn.Module):
         low_all = None
         if sum(counts):
             idx = torch.tensor([i for i, c in enumerate(counts) for _ in range(c)], dtype=torch.int64, device=dev)
-            masks, _iou = self._sam.decode(image_embeddings_tm, torch.cat([e for e in pred_embeddings if e.shape[0]], dim=0).contiguous(), idx)
+            text = torch.cat([e for e in pred_embeddings if e.shape[0]], dim=0).contiguous()
+            if train:
+                masks = self._sam.decode_train(image_embeddings_tm, text, idx)
+            else:
+                masks, _iou = self._sam.decode(image_embeddings_tm, text, idx)
             low_all = masks[:, 0].contiguous()                      # multimask_output=False -> mask 0
         pred_masks, o = [], 0
         for i, c in enumerate(counts):
@@ -141,15 +169,16 @@ class UllavaForCausalLM(nn.Module):
             if c == 0:
                 pred_masks.append(torch.empty(0, H, W, device=dev, dtype=torch.float32))
                 continue
-            pred_masks.append(self._sam.postprocess(low_all[o:o + c], resize_list[i], (H, W)))
+            post = self._sam.postprocess_train if train else self._sam.postprocess
+            pred_masks.append(post(low_all[o:o + c].contiguous(), resize_list[i], (H, W)))
             o += c
         return pred_masks
 
     def forward(self, images_sam: torch.FloatTensor, images: torch.FloatTensor, input_ids: torch.LongTensor, labels: torch.LongTensor,
                 attention_mask: torch.LongTensor, mask_list: List[torch.FloatTensor], size_list: List[torch.Tensor],
                 resize_list: List[tuple], bbox_list: List[torch.FloatTensor], inference: bool = False):
-        """reference ullava.py:152-333.  inference=False returns the training-loss dict (forward values only: there is no backward
-        on this path yet)."""
+        """reference ullava.py:152-333.  inference=False returns the training-loss dict; with gradients enabled and trainable
+        parameters (train_ullava.py:207-261) the losses carry an autograd graph whose backward runs HIP kernels (autograd_ops.py)."""
         B = input_ids.shape[0]
         # the SAM image encoder does not depend on the LLM: it runs on a second HIP stream and fills the gaps (tile-quantisation
         # tails, small kernels, launch latency) of the CLIP + LLaMA stream; joined before the mask decoder.  Each stream has its own
@@ -159,7 +188,7 @@ class UllavaForCausalLM(nn.Module):
         side = self._side_stream()
         side.wait_stream(main)
         with ops.streamk_policy(8192 if side is not main else 2048):
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), torch.no_grad():          # SAM image encoder: frozen (reference get_visual_embs: no_grad)
                 image_embeddings = self._visual_embs_tm(images_sam)
             pad = torch.zeros((B, 1), dtype=torch.bool, device=input_ids.device)
             seg_token_mask = torch.cat([input_ids[:, 1:] == self.config.seg_token_idx, pad], dim=1)    # row t selected iff ids[t+1]==[SEG]
@@ -169,15 +198,16 @@ class UllavaForCausalLM(nn.Module):
         last = output.hidden_states[-1]
         main.wait_stream(side)
         image_embeddings.record_stream(main)
-        pred_embeddings = self._select(last, seg_token_mask, self.seg_projector)
-        pred_loc_embeddings = self._select(last, loc_token_mask, self.det_projector)
-        pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, size_list)
-        pred_boxes = [self._run_mlp(self.det_decoder, e) if e.shape[0] else e.new_empty(0, 4) for e in pred_loc_embeddings]
+        train = self._heads_training_graph() and not inference
+        pred_embeddings = self._select(last, seg_token_mask, self.seg_projector, train)
+        pred_loc_embeddings = self._select(last, loc_token_mask, self.det_projector, train)
+        pred_masks = self._decode(image_embeddings, pred_embeddings, resize_list, size_list, train)
+        pred_boxes = [self._run_mlp(self.det_decoder, e, train) if e.shape[0] else e.new_empty(0, 4) for e in pred_loc_embeddings]
         if inference:
             return {"pred_masks": pred_masks, "pred_boxes": pred_boxes, "gt_masks": mask_list, "gt_boxes": bbox_list, "logits": output.logits}
-        return self._losses(output.loss, pred_masks, pred_boxes, mask_list, bbox_list)
+        return self._losses(output.loss, pred_masks, pred_boxes, mask_list, bbox_list, train)
 
-    def _losses(self, ce, pred_masks, pred_boxes, gt_masks, gt_boxes):
+    def _losses(self, ce, pred_masks, pred_boxes, gt_masks, gt_boxes, train: bool = False):
         """reference ullava.py:268-333 + models/loss.py.  The per-pixel / per-box sums are HIP kernels; the handful of scalar
         combinations below run as 0-dim device ops.  Like the reference, the total is accumulated IN PLACE into the tensor that
         `ce_loss` names, so the returned "ce_loss" equals "loss" (reproduced, not corrected)."""
@@ -198,7 +228,7 @@ class UllavaForCausalLM(nn.Module):
                 raise AssertionError(f"gt_mask.shape: {tuple(gm.shape)}, pred_mask.shape: {tuple(pm.shape)}")
             n = gm.shape[0]
             if n:
-                sums = ops.mask_loss_sums(pm.contiguous(), gm.to(device=dev, dtype=torch.float32).contiguous())     # [n, 4]
+                sums = (A.mask_loss_sums if train else ops.mask_loss_sums)(pm.contiguous(), gm.to(device=dev, dtype=torch.float32).contiguous())   # [n, 4]
                 hw = pm[0].numel()
                 mask_bce = mask_bce + (sums[:, 0] / hw).sum() / (n + 1e-8) * n
                 dice = 1 - (2 * sums[:, 1] + 1e-6) / (sums[:, 2] + sums[:, 3] + 1e-6)
@@ -209,7 +239,7 @@ class UllavaForCausalLM(nn.Module):
                 raise AssertionError(f"gt_box.shape: {tuple(gb.shape)}, pred_box.shape: {tuple(pb.shape)}")
             nb = gb.shape[0]
             if nb:
-                bl = ops.box_losses(pb, gb.to(device=dev, dtype=torch.float32))
+                bl = (A.box_losses if train else ops.box_losses)(pb, gb.to(device=dev, dtype=torch.float32))
                 box_l1 = box_l1 + bl[0] / (nb + 1e-8)
                 box_giou = box_giou + bl[1] / (nb + 1e-8)
             num_boxes += nb

@@ -615,3 +615,77 @@ def sum_slabs(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     out = torch.empty(x.shape[1], device=x.device, dtype=x.dtype)
     _lib.call("ull_sum_slabs_" + _SFX[x.dtype], _p(x), _p(out), x.shape[0], x.shape[1], float(scale), _stream())
     return out
+
+
+def layernorm_bwd(x, w, dy, eps: float, need_wb: bool = True):
+    """-> (dx, dw float32 [D] or None, db float32 [D] or None)."""
+    _chk(x, "x"); _chk(w, "w", x.dtype); _chk(dy, "dy", x.dtype)
+    rows, ldx = _rows(x)
+    D = x.shape[-1]
+    dx = torch.empty_like(x)
+    dw = torch.zeros(D, device=x.device, dtype=torch.float32) if need_wb else None
+    db = torch.zeros(D, device=x.device, dtype=torch.float32) if need_wb else None
+    _lib.call("ull_layernorm_bwd_" + _SFX[x.dtype], _p(x), ldx, _p(w), _p(dy), _rows(dy)[1], _p(dx), _rows(dx)[1], _p(dw), _p(db), rows, D, float(eps),
+              _stream())
+    return dx, dw, db
+
+
+def layernorm2d_cl_bwd(x, w, b, dy, eps: float, gelu: bool, need_wb: bool = True):
+    _chk(x, "x"); _chk(w, "w", x.dtype); _chk(b, "b", x.dtype); _chk(dy, "dy", x.dtype)
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    dw = torch.zeros(C, device=x.device, dtype=torch.float32) if need_wb else None
+    db = torch.zeros(C, device=x.device, dtype=torch.float32) if need_wb else None
+    _lib.call("ull_layernorm2d_cl_bwd_" + _SFX[x.dtype], _p(x.contiguous()), _p(w), _p(b), _p(dy.contiguous()), _p(dx), _p(dw), _p(db), x.numel() // C, C,
+              float(eps), int(gelu), _stream())
+    return dx, dw, db
+
+
+def gelu_fwd(x):
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    _lib.call("ull_gelu_fwd_" + _SFX[x.dtype], _p(x.contiguous()), _p(y), x.numel(), _stream())
+    return y
+
+
+def gelu_bwd(x, dy):
+    _chk(x, "x"); _chk(dy, "dy", x.dtype)
+    dx = torch.empty_like(x)
+    _lib.call("ull_gelu_bwd_" + _SFX[x.dtype], _p(x.contiguous()), _p(dy.contiguous()), _p(dx), x.numel(), _stream())
+    return dx
+
+
+def mask_matmul_bwd(hyper, up, dmasks, n: int, T: int, C: int, G: int):
+    """-> (dhyper float32 [n, T, C], dup like up)."""
+    _chk(hyper, "hyper"); _chk(up, "up", hyper.dtype); _chk(dmasks, "dmasks", hyper.dtype)
+    dh = torch.zeros(n, T, C, device=up.device, dtype=torch.float32)
+    dup = torch.empty_like(up)
+    _lib.call("ull_mask_matmul_bwd_" + _SFX[hyper.dtype], _p(hyper.contiguous()), _p(up), _p(dmasks.contiguous()), _p(dh), _p(dup), n, T, C, G, _stream())
+    return dh, dup
+
+
+def mask_loss_sums_bwd(logits, target, g, scale: float = 1000.0):
+    _chk(logits, "mask logits", torch.float32); _chk(target, "mask target", torch.float32); _chk(g, "g", torch.float32)
+    n = logits.shape[0]
+    dl = torch.empty_like(logits)
+    _lib.call("ull_mask_loss_sums_bwd_f32", _p(logits.contiguous()), _p(target.contiguous()), _p(g.contiguous()), n, logits[0].numel(), float(scale),
+              _p(dl), _stream())
+    return dl
+
+
+def box_losses_bwd(pred, gt, gw):
+    _chk(pred, "pred boxes", pred.dtype if pred.dtype in DT_CODE else None); _chk(gt, "gt boxes", torch.float32); _chk(gw, "gw", torch.float32)
+    dp = torch.empty(pred.shape[0], 4, device=pred.device, dtype=torch.float32)
+    _lib.call("ull_box_losses_bwd_f32", _p(pred.contiguous()), DT_CODE[pred.dtype], _p(gt.contiguous()), pred.shape[0], _p(gw.contiguous()), _p(dp),
+              _stream())
+    return dp
+
+
+def bilinear_bwd(dout, full_hw, in_h: int, in_w: int):
+    """adjoint of bilinear(): dout fp32 [n, out_h, out_w] -> din fp32 [n, Hfull, Wfull] (zero outside the in_h x in_w crop)."""
+    _chk(dout, "dout", torch.float32)
+    n, oh, ow = dout.shape
+    Hf, Wf = full_hw
+    din = torch.zeros(n, Hf, Wf, device=dout.device, dtype=torch.float32)
+    _lib.call("ull_bilinear_bwd_f32", _p(dout.contiguous()), _p(din), Hf * Wf, Wf, in_h, in_w, n, oh, ow, _stream())
+    return din

@@ -13,6 +13,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from . import autograd_ops as A
 from . import ops
 from .configuration import SamConfig
 from .modeling_core import BF16, Conv2dHolder, Embedding, Linear, Norm, _Holder, _param
@@ -310,6 +311,77 @@ class SamEngine:
         masks = ops.mask_matmul(hyper, y2, n, nm, D // 8, g)
         iou = self._mlp3(md.iou_prediction_head, hs[:, 0, :])
         return masks, iou
+
+    # -- training path of the mask decoder (train_ullava.py:248-261 makes `mask_decoder` trainable) -----------------------------------
+    def decode_train(self, image_embedding_tm: torch.Tensor, text_embeds: torch.Tensor, image_index: Optional[torch.Tensor] = None):
+        """decode() with an autograd graph: same HIP forward kernels (GELU un-fused from the second up-scaling GEMM so that its input is
+        kept, ConvTranspose2d weights re-packed under autograd), HIP backward kernels (autograd_ops.py).  The image embedding, the
+        dense (no-mask) embedding and the positional encoding are constants (SAM encoder and prompt encoder are frozen)."""
+        md, tr = self.sam.mask_decoder, self.sam.mask_decoder.transformer
+        n, D = text_embeds.shape
+        P = image_embedding_tm.shape[-2]
+        g = int(math.isqrt(P))
+        nm = md.mask_tokens.weight.shape[0]
+        H = self.cfg.decoder_heads
+        u0, u3 = md.output_upscaling[0], md.output_upscaling[3]
+        up0_w = u0.weight.permute(2, 3, 1, 0).reshape(-1, u0.weight.shape[0])
+        up3_w = u3.weight.permute(2, 3, 1, 0).reshape(-1, u3.weight.shape[0])
+        up0_b, up3_b = u0.bias.repeat(4), u3.bias.repeat(4)
+        out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], dim=0)
+        tokens = torch.cat([out_tok.unsqueeze(0).expand(n, -1, -1), text_embeds.unsqueeze(1)], dim=1).contiguous()
+        T = tokens.shape[1]
+        with torch.no_grad():
+            src = ops.add_rows(image_embedding_tm.reshape(-1, D), self.sam.prompt_encoder.no_mask_embed.weight)
+            if image_index is None:
+                keys = src.unsqueeze(0).expand(n, -1, -1).contiguous().view(n * P, D)
+            else:
+                keys = ops.gather_rows(src.view(-1, P * D), image_index).view(n * P, D)
+            pos = self.dense_pe()
+
+        def attn(a, q_in, k_in, v_in, Sq, Sk, residual=None, unfused=()):
+            q = A.linear(q_in, a.q_proj.weight, a.q_proj.bias, bias_after_rounding="q" in unfused)
+            k = A.linear(k_in, a.k_proj.weight, a.k_proj.bias, bias_after_rounding="k" in unfused)
+            v = A.linear(v_in, a.v_proj.weight, a.v_proj.bias, bias_after_rounding="v" in unfused)
+            return A.linear(A.attention(q, k, v, n, H, Sq, Sk), a.out_proj.weight, a.out_proj.bias, residual=residual)
+
+        def ln(x, m):
+            return A.layernorm(x, m.weight, m.bias, 1e-5)
+        qpe = tokens.view(n * T, D)
+        queries = qpe
+        for i, l in enumerate(tr.layers):
+            if i == 0:
+                queries = attn(l.self_attn, queries, queries, queries, T, T)
+            else:
+                q = A.add(queries, qpe)
+                queries = attn(l.self_attn, q, q, queries, T, T, residual=queries)
+            queries = ln(queries, l.norm1)
+            q = A.add(queries, qpe)
+            k = A.add(keys, pos)
+            queries = ln(attn(l.cross_attn_token_to_image, q, k, keys, T, P, residual=queries, unfused=("k", "v") if i == 0 else ()), l.norm2)
+            m = A.linear(queries, l.mlp.lin1.weight, l.mlp.lin1.bias, relu=True)
+            queries = ln(A.linear(m, l.mlp.lin2.weight, l.mlp.lin2.bias, residual=queries), l.norm3)
+            q = A.add(queries, qpe)
+            keys = ln(attn(l.cross_attn_image_to_token, k, q, queries, P, T, residual=keys, unfused=("q",) if i == 0 else ()), l.norm4)
+        q = A.add(queries, qpe)
+        k = A.add(keys, pos)
+        hs = ln(attn(tr.final_attn_token_to_image, q, k, keys, T, P, residual=queries), tr.norm_final_attn).view(n, T, D)
+        lnu = md.output_upscaling[1]
+        y1 = A.linear(keys, up0_w, up0_b)
+        y1 = A.layernorm2d_cl(y1.view(-1, D // 4), lnu.weight, lnu.bias, 1e-6, True)
+        y2 = A.gelu(A.linear(y1, up3_w, up3_b))
+
+        def mlp3(mm, x):
+            nl = len(mm.layers)
+            for j, lyr in enumerate(mm.layers):
+                x = A.linear(x, lyr.weight, lyr.bias, relu=j < nl - 1)
+            return x
+        hyper = torch.stack([mlp3(md.output_hypernetworks_mlps[t], hs[:, 1 + t, :].contiguous()) for t in range(nm)], dim=1).contiguous()
+        return A.mask_matmul(hyper, y2, n, nm, D // 8, g)
+
+    def postprocess_train(self, masks: torch.Tensor, input_size, original_size) -> torch.Tensor:
+        s_ = self.cfg.img_size
+        up = A.bilinear(masks, masks.shape[-2], masks.shape[-1], s_, s_)
+        return A.bilinear(up, int(input_size[0]), int(input_size[1]), int(original_size[0]), int(original_size[1]))
 
     # -- Sam.postprocess_masks (sam.py:137-172) --------------------------------------------------------------------
     def postprocess(self, masks: torch.Tensor, input_size, original_size) -> torch.Tensor:
