@@ -228,6 +228,40 @@ int ull_mask_loss_sums_f32(const void* logits, const void* target, int64_t n_mas
  * predictions with x1 >= x0 and y1 >= y0}.  pred [n,4] of dtype pred_dtype (ULL_DT_*), gt [n,4] fp32, xyxy. */
 int ull_box_losses_f32(const void* pred, int pred_dtype, const void* gt, int64_t n, void* out, void* stream);
 
+/* ---- fused two-way mask decoder (north_star: "SAM's MaskDecoder cross-attention fused into one LDS-resident kernel") ----------------
+ * models/segment_anything/modeling/transformer.py:62-106,151-182,220-242; mask_decoder.py:137-164.  Fixed dims: width 256, cross-attention
+ * internal width 128, 8 heads, T <= 8 tokens per prompt.  All weights in nn.Linear layout, every 16-bit rounding point of the
+ * reference graph kept.  queries / qpe / out [n, T, 256]; keys [n, P, 256]; pos [P, 256]. */
+
+/* TwoWayAttentionBlock self attention + norm1 (:151-160) in one launch.  first != 0: layer 0 (no positional add, no residual). */
+int ull_sam_token_self_attn_ln_bf16(const void* queries, const void* qpe, int64_t n, int64_t T, int first, const void* wq, const void* bq,
+                                    const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo,
+                                    const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+
+/* MLP block + norm3 (:168-171): out = LN(queries + lin2(relu(lin1(queries)))), hidden <= 2048, in one launch. */
+int ull_sam_token_mlp_ln_bf16(const void* queries, int64_t n, int64_t T, int64_t hidden, const void* w1, const void* b1, const void* w2,
+                              const void* b2, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+
+/* The four hyper-network MLPs + the IoU head (mask_decoder.py:137-164) in one launch.  ptrs: HOST array of 30 device pointers =
+ * 5 MLPs x {w1, b1, w2, b2, w3, b3} (hyper 0..3 on token rows 1..4, then the IoU head on row 0); hyper [n, 4, hyper_out], iou [n, n_iou]. */
+int ull_sam_small_mlps_bf16(const void* hs, int64_t n, int64_t T, const void* const* ptrs, int64_t n_mask_tokens, int64_t hyper_out,
+                            int64_t n_iou, void* hyper, void* iou, void* stream);
+
+/* token -> image cross attention + LayerNorm (:162-166 and the final attention :100-105), two launches: (1) per 64-key tile the k / v
+ * projections on the MFMA with the tile LDS-resident, the q projection and the scaled scores; (2) exact fp32 softmax over all P keys,
+ * P V, out-projection, residual, LayerNorm.  late_bias_kv != 0: bias added after the rounding of the k / v products (layer 0, see
+ * ULL_EPI_BIAS_ROUNDED).  Caller-owned scratch: scores_ws [n * 8 * 8 * P] and vproj_ws [n * P * 128] elements.  P % 512 == 0. */
+int ull_sam_t2i_attention_ln_bf16(const void* queries, const void* qpe, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P,
+                                  const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo,
+                                  const void* bo, int late_bias_kv, const void* ln_w, const void* ln_b, float eps, void* scores_ws, void* vproj_ws,
+                                  void* out, void* stream);
+
+/* image -> token cross attention + norm4 (:173-180) in ONE launch per 64 image rows: q projection on the MFMA (tile LDS-resident), k / v of
+ * the T tokens, softmax over T, P V, out-projection on the MFMA, residual, LayerNorm; out [n, P, 256] (must not alias keys). */
+int ull_sam_i2t_attention_ln_bf16(const void* keys, const void* pos, const void* queries, const void* qpe, int64_t n, int64_t T, int64_t P,
+                                  const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo,
+                                  const void* bo, int late_bias_q, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+
 /* ---- backward kernels (train_ullava.py / train_ullava_core.py; torch autograd of the cited forward ops) --------
  * Gradients are evaluated in fp32 from the stored 16-bit tensors and rounded once on output.  Linear layers need no entry point of
  * their own: dX = dY W and dW = dY^T X are ull_gemm_bf16 on transposed operands. */
@@ -324,6 +358,11 @@ int ull_layernorm2d_cl_f16(const void* x, const void* w, const void* b, void* y,
 int ull_im2col3x3_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 int ull_mask_matmul_f16(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
 int ull_patchify_f16(const void* img, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, const void* Wp, int64_t Kp, const void* bias, void* out, int64_t ldc, int64_t N, const void* zeros, void* stream);
+int ull_sam_token_self_attn_ln_f16(const void* queries, const void* qpe, int64_t n, int64_t T, int first, const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+int ull_sam_token_mlp_ln_f16(const void* queries, int64_t n, int64_t T, int64_t hidden, const void* w1, const void* b1, const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+int ull_sam_small_mlps_f16(const void* hs, int64_t n, int64_t T, const void* const* ptrs, int64_t n_mask_tokens, int64_t hyper_out, int64_t n_iou, void* hyper, void* iou, void* stream);
+int ull_sam_t2i_attention_ln_f16(const void* queries, const void* qpe, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P, const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo, int late_bias_kv, const void* ln_w, const void* ln_b, float eps, void* scores_ws, void* vproj_ws, void* out, void* stream);
+int ull_sam_i2t_attention_ln_f16(const void* keys, const void* pos, const void* queries, const void* qpe, int64_t n, int64_t T, int64_t P, const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo, int late_bias_q, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
 int ull_rmsnorm_bwd_f16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, int64_t rows, int64_t D, float eps, void* stream);
 int ull_swiglu_fwd_f16(const void* gu, void* a, int64_t M, int64_t I, void* stream);
 int ull_swiglu_bwd_f16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream);

@@ -438,3 +438,63 @@ def test_mask_decoder_stage_trace_bf16_layer0_bit_exact():
         if k.startswith("l0."):
             assert flips <= (3e-3 if k == "l0.norm4" else 1e-3) and dmax <= 2.0 ** -7, (k, flips, dmax)
     assert len(rows) >= 8
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_fused_decoder_kernels_match_the_op_by_op_chain(dt):
+    """csrc/sam_decoder.hip (one or two launches per attention / MLP block, LDS-resident key tiles) against the op-by-op decode that
+    the stage-trace test pins to the reference: same rounding points, so the two differ only by fp32 summation order -- the queries
+    after the first block must agree up to isolated one-ulp flips, the final mask logits within the decoder's flip-amplification
+    envelope (the same bound as HIP vs reference fixture), IoU predictions likewise.  n = 1 and a batched n = 5 over 2 images."""
+    C, S = pkg("configuration"), pkg("sam")
+    fx = load_fixture("g7_sam_decoder_bf16.pt")
+    cfg = C.SamConfig(depth=0)
+    holder = S.build_sam_holder(cfg, device=DEV, dtype=dt)
+    sd = {k[len("visual_model."):]: v for k, v in fixture_sd(fx, dt).items()}
+    holder.load_state_dict(sd, strict=False)
+    eng = S.SamEngine(holder, cfg)
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(2, 4096, 256, generator=g).to(dt).to(DEV)
+    text = torch.randn(5, 256, generator=g).to(dt).to(DEV)
+    idx = torch.tensor([0, 1, 1, 0, 1], device=DEV)
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    for e_, t_, i_ in ((emb[0], text[:1], None), (emb, text, idx)):
+        eng.fused_decoder = True
+        mf, iouf = eng.decode(e_, t_, i_)
+        eng.fused_decoder = False
+        mu, iouu = eng.decode(e_, t_, i_)
+        d = (mf.float() - mu.float()).abs()
+        mx = float(mu.float().abs().max())
+        frac = float((d > 0).float().mean())
+        print(f"{dt} n={t_.shape[0]}: fused vs op-by-op mask logits: max {float(d.max()) / mx:.2e} of max|logit|, differing {frac:.3f}; "
+              f"iou {rel_err(iouf, iouu):.2e}")
+        assert float(d.max()) <= 4 * ulp * mx
+        assert rel_err(iouf, iouu) <= 4 * ulp
+    # first block in isolation: queries after self-attention + LN, token->image attention + LN, MLP + LN; keys after image->token + LN
+    ops = pkg("ops")
+    tr = holder.mask_decoder.transformer
+    l0 = tr.layers[0]
+    md = holder.mask_decoder
+    tokens = torch.cat([torch.cat([md.iou_token.weight, md.mask_tokens.weight], 0).unsqueeze(0), text[:1].unsqueeze(1)], dim=1).contiguous()
+    keys = ops.add_rows(emb[0], holder.prompt_encoder.no_mask_embed.weight).view(1, 4096, 256)
+    pos = eng.dense_pe()
+    q1 = ops.sam_token_self_attn_ln(tokens, tokens, l0.self_attn, l0.norm1, first=True)
+    ref1 = ops.layernorm(eng._attn(l0.self_attn, tokens.view(6, 256), tokens.view(6, 256), tokens.view(6, 256), 1, 6, 6), l0.norm1.weight, l0.norm1.bias, 1e-5)
+    flip = 1.0 if dt == torch.bfloat16 else 8.0         # fp16's rounding grid is 8x finer: fp32 summation-order noise flips 8x more roundings
+    assert float((q1.view(6, 256) != ref1).float().mean()) <= 0.01 * flip
+    q2 = ops.sam_t2i_attention_ln(q1, tokens, keys, pos, l0.cross_attn_token_to_image, l0.norm2, late_bias_kv=True)
+    qq, kk = ops.add_rows(q1.view(6, 256), tokens.view(6, 256)), ops.add_rows(keys.view(4096, 256), pos)
+    ref2 = ops.layernorm(eng._attn(l0.cross_attn_token_to_image, qq, kk, keys.view(4096, 256), 1, 6, 4096, residual=q1.view(6, 256), unfused_bias=("k", "v")),
+                         l0.norm2.weight, l0.norm2.bias, 1e-5)
+    f2 = float((q2.view(6, 256) != ref2).float().mean())
+    q3 = ops.sam_token_mlp_ln(q2, l0.mlp.lin1, l0.mlp.lin2, l0.norm3)
+    m_ = ops.linear(q2.view(6, 256), l0.mlp.lin1.weight, l0.mlp.lin1.bias, act="relu")
+    ref3 = ops.layernorm(ops.linear(m_, l0.mlp.lin2.weight, l0.mlp.lin2.bias, residual=q2.view(6, 256)), l0.norm3.weight, l0.norm3.bias, 1e-5)
+    f3 = float((q3.view(6, 256) != ref3).float().mean())
+    k1 = ops.sam_i2t_attention_ln(keys, pos, q3, tokens, l0.cross_attn_image_to_token, l0.norm4, late_bias_q=True)
+    qq3 = ops.add_rows(q3.view(6, 256), tokens.view(6, 256))
+    ref4 = ops.layernorm(eng._attn(l0.cross_attn_image_to_token, kk, qq3, q3.view(6, 256), 1, 4096, 6, residual=keys.view(4096, 256), unfused_bias=("q",)),
+                         l0.norm4.weight, l0.norm4.bias, 1e-5)
+    f4 = float((k1.view(4096, 256) != ref4).float().mean())
+    print(f"{dt} block 0, fraction of elements differing from the op-by-op chain: t2i {f2:.4f}, mlp {f3:.4f}, i2t {f4:.5f}")
+    assert f2 <= 0.02 * flip and f3 <= 0.02 * flip and f4 <= 0.002 * flip

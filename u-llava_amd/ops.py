@@ -689,3 +689,71 @@ def bilinear_bwd(dout, full_hw, in_h: int, in_w: int):
     din = torch.zeros(n, Hf, Wf, device=dout.device, dtype=torch.float32)
     _lib.call("ull_bilinear_bwd_f32", _p(dout.contiguous()), _p(din), Hf * Wf, Wf, in_h, in_w, n, oh, ow, _stream())
     return din
+
+
+# ---- fused two-way mask decoder (csrc/sam_decoder.hip) ------------------------------------------------------------------------------
+def _lin_ptrs(*lins):
+    out = []
+    for l in lins:
+        out += [_p(l.weight), _p(l.bias)]
+    return out
+
+
+def sam_token_self_attn_ln(queries, qpe, a, ln, first: bool, eps: float = 1e-5):
+    """queries / qpe [n, T, 256]; `a`: holder with q_proj / k_proj / v_proj / out_proj; ln: LayerNorm holder -> new queries."""
+    _chk(queries, "queries"); _chk(qpe, "qpe", queries.dtype)
+    n, T, _ = queries.shape
+    out = torch.empty_like(queries)
+    _lib.call("ull_sam_token_self_attn_ln_" + _SFX[queries.dtype], _p(queries), _p(qpe), n, T, int(first), *_lin_ptrs(a.q_proj, a.k_proj, a.v_proj, a.out_proj),
+              _p(ln.weight), _p(ln.bias), float(eps), _p(out), _stream())
+    return out
+
+
+def sam_token_mlp_ln(queries, lin1, lin2, ln, eps: float = 1e-5):
+    _chk(queries, "queries")
+    n, T, _ = queries.shape
+    out = torch.empty_like(queries)
+    _lib.call("ull_sam_token_mlp_ln_" + _SFX[queries.dtype], _p(queries), n, T, lin1.weight.shape[0], *_lin_ptrs(lin1, lin2), _p(ln.weight), _p(ln.bias),
+              float(eps), _p(out), _stream())
+    return out
+
+
+def sam_small_mlps(hs, hyper_mlps, iou_head):
+    """hs [n, T, 256] -> (hyper [n, 4, C], iou [n, n_iou]): the 4 hyper-network MLPs on rows 1..4 and the IoU head on row 0."""
+    import ctypes
+    _chk(hs, "hs")
+    n, T, _ = hs.shape
+    ptrs = []
+    for m in list(hyper_mlps) + [iou_head]:
+        ptrs += _lin_ptrs(*m.layers)
+    arr = (ctypes.c_void_p * 30)(*ptrs)
+    C, n_iou = hyper_mlps[0].layers[2].weight.shape[0], iou_head.layers[2].weight.shape[0]
+    hyper = torch.empty(n, 4, C, device=hs.device, dtype=hs.dtype)
+    iou = torch.empty(n, n_iou, device=hs.device, dtype=hs.dtype)
+    _lib.call("ull_sam_small_mlps_" + _SFX[hs.dtype], _p(hs), n, T, arr, 4, C, n_iou, _p(hyper), _p(iou), _stream())
+    return hyper, iou
+
+
+def sam_t2i_attention_ln(queries, qpe, keys, pos, a, ln, late_bias_kv: bool, eps: float = 1e-5):
+    """token -> image attention + residual + LayerNorm: queries / qpe [n, T, 256], keys [n, P, 256], pos [P, 256] -> new queries."""
+    _chk(queries, "queries"); _chk(qpe, "qpe", queries.dtype); _chk(keys, "keys", queries.dtype); _chk(pos, "pos", queries.dtype)
+    n, T, _ = queries.shape
+    P = keys.shape[1]
+    ws_s = torch.empty(n * 8 * 8 * P, device=keys.device, dtype=keys.dtype)
+    ws_v = torch.empty(n * P * 128, device=keys.device, dtype=keys.dtype)
+    out = torch.empty_like(queries)
+    _lib.call("ull_sam_t2i_attention_ln_" + _SFX[queries.dtype], _p(queries), _p(qpe), _p(keys), _p(pos), n, T, P,
+              *_lin_ptrs(a.q_proj, a.k_proj, a.v_proj, a.out_proj), int(late_bias_kv), _p(ln.weight), _p(ln.bias), float(eps), _p(ws_s), _p(ws_v), _p(out),
+              _stream())
+    return out
+
+
+def sam_i2t_attention_ln(keys, pos, queries, qpe, a, ln, late_bias_q: bool, eps: float = 1e-5):
+    """image -> token attention + residual + LayerNorm in one launch -> new keys [n, P, 256]."""
+    _chk(keys, "keys"); _chk(pos, "pos", keys.dtype); _chk(queries, "queries", keys.dtype); _chk(qpe, "qpe", keys.dtype)
+    n, T, _ = queries.shape
+    P = keys.shape[1]
+    out = torch.empty_like(keys)
+    _lib.call("ull_sam_i2t_attention_ln_" + _SFX[keys.dtype], _p(keys), _p(pos), _p(queries), _p(qpe), n, T, P,
+              *_lin_ptrs(a.q_proj, a.k_proj, a.v_proj, a.out_proj), int(late_bias_q), _p(ln.weight), _p(ln.bias), float(eps), _p(out), _stream())
+    return out

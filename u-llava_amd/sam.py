@@ -242,6 +242,39 @@ class SamEngine:
             trace.update({tag + ".q": q, tag + ".k": k, tag + ".v": v, tag + ".att": att})
         return ops.linear(att, a.out_proj.weight, a.out_proj.bias, residual=residual)
 
+    # -- fused two-way transformer (csrc/sam_decoder.hip) ------------------------------------------------------------------------
+    fused_decoder = True        # False: the op-by-op chain below (what `trace=` and the training path use)
+
+    def _fusable(self, D, P, T, nm) -> bool:
+        c = self.cfg
+        return D == 256 and c.decoder_heads == 8 and c.decoder_mlp_dim <= 2048 and c.decoder_mlp_dim % 32 == 0 and P % 512 == 0 and T <= 8 and nm == 4 \
+            and self.sam.mask_decoder.transformer.layers[0].cross_attn_token_to_image.q_proj.weight.shape[0] == 128
+
+    def _decode_fused(self, image_embedding_tm, tokens, image_index, n, D, P, g, nm, T):
+        """decode() with every attention / MLP block of the TwoWayTransformer as one or two launches (17 launches per decode instead
+        of ~70; LDS-resident key tiles, nothing but the block outputs written to HBM).  Same rounding points as the op-by-op chain."""
+        md, tr, pk = self.sam.mask_decoder, self.sam.mask_decoder.transformer, self.pk()
+        src = ops.add_rows(image_embedding_tm.reshape(-1, D), self.sam.prompt_encoder.no_mask_embed.weight)
+        if image_index is None:
+            keys = src.view(1, P, D).expand(n, -1, -1).contiguous()
+        else:
+            keys = ops.gather_rows(src.view(-1, P * D), image_index).view(n, P, D)
+        pos = self.dense_pe()
+        queries = tokens
+        for i, l in enumerate(tr.layers):
+            queries = ops.sam_token_self_attn_ln(queries, tokens, l.self_attn, l.norm1, first=(i == 0))
+            # layer 0: the image keys are still non-contiguous views in the reference -> at::linear's unfused-bias path (see _attn)
+            queries = ops.sam_t2i_attention_ln(queries, tokens, keys, pos, l.cross_attn_token_to_image, l.norm2, late_bias_kv=(i == 0))
+            queries = ops.sam_token_mlp_ln(queries, l.mlp.lin1, l.mlp.lin2, l.norm3)
+            keys = ops.sam_i2t_attention_ln(keys, pos, queries, tokens, l.cross_attn_image_to_token, l.norm4, late_bias_q=(i == 0))
+        hs = ops.sam_t2i_attention_ln(queries, tokens, keys, pos, tr.final_attn_token_to_image, tr.norm_final_attn, late_bias_kv=False)
+        ln = md.output_upscaling[1]
+        y1 = ops.linear(keys.view(n * P, D), pk["up0_w"], pk["up0_b"])
+        y1 = ops.layernorm2d_cl(y1.view(-1, D // 4), ln.weight, ln.bias, 1e-6, gelu=True)
+        y2 = ops.linear(y1, pk["up3_w"], pk["up3_b"], act="gelu")
+        hyper, iou = ops.sam_small_mlps(hs, md.output_hypernetworks_mlps, md.iou_prediction_head)
+        return ops.mask_matmul(hyper, y2, n, nm, D // 8, g), iou
+
     def _mlp3(self, m, x):
         nl = len(m.layers)
         for i, l in enumerate(m.layers):
@@ -267,6 +300,8 @@ class SamEngine:
         out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], dim=0)                  # [1+nm, D]
         tokens = torch.cat([out_tok.unsqueeze(0).expand(n, -1, -1), text_embeds.unsqueeze(1)], dim=1).contiguous()   # [n, T, D]
         T = tokens.shape[1]
+        if trace is None and self.fused_decoder and self._fusable(D, P, T, nm):
+            return self._decode_fused(image_embedding_tm, tokens, image_index, n, D, P, g, nm, T)
         src = ops.add_rows(image_embedding_tm.reshape(-1, D), self.sam.prompt_encoder.no_mask_embed.weight)   # + dense (no-mask) embedding
         if image_index is None:
             keys = src.unsqueeze(0).expand(n, -1, -1).contiguous().view(n * P, D)                # repeat_interleave over prompts
