@@ -233,34 +233,42 @@ int ull_box_losses_f32(const void* pred, int pred_dtype, const void* gt, int64_t
  * internal width 128, 8 heads, T <= 8 tokens per prompt.  All weights in nn.Linear layout, every 16-bit rounding point of the
  * reference graph kept.  queries / qpe / out [n, T, 256]; keys [n, P, 256]; pos [P, 256]. */
 
-/* TwoWayAttentionBlock self attention + norm1 (:151-160) in one launch.  first != 0: layer 0 (no positional add, no residual). */
-int ull_sam_token_self_attn_ln_bf16(const void* queries, const void* qpe, int64_t n, int64_t T, int first, const void* wq, const void* bq,
-                                    const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo,
-                                    const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+/* Token self attention (:151-160, :220-242), one (prompt, head) per block: q/k/v projections of the head + attention over the T tokens;
+ * att [n, T, 256] = concatenated heads.  first != 0: layer 0 (no positional add). */
+int ull_sam_self_attn_heads_bf16(const void* queries, const void* qpe, int64_t n, int64_t T, int first, const void* wq, const void* bq,
+                                 const void* wk, const void* bk, const void* wv, const void* bv, void* att, void* stream);
 
-/* MLP block + norm3 (:168-171): out = LN(queries + lin2(relu(lin1(queries)))), hidden <= 2048, in one launch. */
-int ull_sam_token_mlp_ln_bf16(const void* queries, int64_t n, int64_t T, int64_t hidden, const void* w1, const void* b1, const void* w2,
-                              const void* b2, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+/* out [n, T, 256] = LayerNorm(res + att Wo^T + bo) (res NULL: no residual), att [n, T, din], din = 256 or 128; then up to three token-side
+ * projections for the attention that follows: projs = HOST array of 3 x {w [128, 256], b [128], out [n, T, 128]} device pointers (w NULL =
+ * unused; projs NULL = none), add_pe[i] != 0: the projection's input is out + qpe. */
+int ull_sam_out_ln_bf16(const void* att, int64_t din, const void* res, const void* qpe, int64_t n, int64_t T, const void* wo, const void* bo,
+                        const void* ln_w, const void* ln_b, float eps, void* out, const void* const* projs, const int* add_pe, void* stream);
+
+/* MLP block + norm3 (:168-171) in two launches (hidden split over hidden / 256 blocks per prompt, then sum + residual + LayerNorm and the
+ * projections as in ull_sam_out_ln_bf16).  part_ws: float32 [n * (hidden / 256) * 8 * 256] caller-owned scratch. */
+int ull_sam_token_mlp_ln_bf16(const void* queries, const void* qpe, int64_t n, int64_t T, int64_t hidden, const void* w1, const void* b1,
+                              const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* part_ws, void* out,
+                              const void* const* projs, const int* add_pe, void* stream);
 
 /* The four hyper-network MLPs + the IoU head (mask_decoder.py:137-164) in one launch.  ptrs: HOST array of 30 device pointers =
  * 5 MLPs x {w1, b1, w2, b2, w3, b3} (hyper 0..3 on token rows 1..4, then the IoU head on row 0); hyper [n, 4, hyper_out], iou [n, n_iou]. */
 int ull_sam_small_mlps_bf16(const void* hs, int64_t n, int64_t T, const void* const* ptrs, int64_t n_mask_tokens, int64_t hyper_out,
                             int64_t n_iou, void* hyper, void* iou, void* stream);
 
-/* token -> image cross attention + LayerNorm (:162-166 and the final attention :100-105), two launches: (1) per 64-key tile the k / v
- * projections on the MFMA with the tile LDS-resident, the q projection and the scaled scores; (2) exact fp32 softmax over all P keys,
- * P V, out-projection, residual, LayerNorm.  late_bias_kv != 0: bias added after the rounding of the k / v products (layer 0, see
- * ULL_EPI_BIAS_ROUNDED).  Caller-owned scratch: scores_ws [n * 8 * 8 * P] and vproj_ws [n * P * 128] elements.  P % 512 == 0. */
-int ull_sam_t2i_attention_ln_bf16(const void* queries, const void* qpe, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P,
-                                  const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo,
-                                  const void* bo, int late_bias_kv, const void* ln_w, const void* ln_b, float eps, void* scores_ws, void* vproj_ws,
-                                  void* out, void* stream);
+/* token -> image cross attention core (:162-166 and the final attention :100-105), two launches: (1) per 128-key tile the v and k
+ * projections on the MFMA from ONE LDS-resident tile (weights streamed through LDS in K-slices) and the scaled scores against
+ * qproj [n, T, 128]; (2) one (prompt, head) per block: exact fp32 softmax over all P keys and P V -> att [n, T, 128].  late_bias_kv != 0:
+ * bias added after the rounding of the k / v products (layer 0, see ULL_EPI_BIAS_ROUNDED).  Caller-owned scratch: scores_ws [n*8*8*P]
+ * and vproj_ws [n*P*128] elements.  P = 4096 or 1024. */
+int ull_sam_t2i_attention_bf16(const void* qproj, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P, const void* wk,
+                               const void* bk, const void* wv, const void* bv, int late_bias_kv, void* scores_ws, void* vproj_ws, void* att,
+                               void* stream);
 
-/* image -> token cross attention + norm4 (:173-180) in ONE launch per 64 image rows: q projection on the MFMA (tile LDS-resident), k / v of
- * the T tokens, softmax over T, P V, out-projection on the MFMA, residual, LayerNorm; out [n, P, 256] (must not alias keys). */
-int ull_sam_i2t_attention_ln_bf16(const void* keys, const void* pos, const void* queries, const void* qpe, int64_t n, int64_t T, int64_t P,
-                                  const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo,
-                                  const void* bo, int late_bias_q, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+/* image -> token cross attention + norm4 (:173-180) in ONE launch per 128 image rows: q projection on the MFMA (tile LDS-resident), softmax
+ * over the T tokens against kproj / vproj [n, T, 128], P V, out-projection on the MFMA, residual, LayerNorm; out [n, P, 256] != keys. */
+int ull_sam_i2t_attention_ln_bf16(const void* keys, const void* pos, const void* kproj, const void* vproj, int64_t n, int64_t T, int64_t P,
+                                  const void* wq, const void* bq, const void* wo, const void* bo, int late_bias_q, const void* ln_w,
+                                  const void* ln_b, float eps, void* out, void* stream);
 
 /* ---- backward kernels (train_ullava.py / train_ullava_core.py; torch autograd of the cited forward ops) --------
  * Gradients are evaluated in fp32 from the stored 16-bit tensors and rounded once on output.  Linear layers need no entry point of
@@ -358,11 +366,12 @@ int ull_layernorm2d_cl_f16(const void* x, const void* w, const void* b, void* y,
 int ull_im2col3x3_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 int ull_mask_matmul_f16(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
 int ull_patchify_f16(const void* img, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, const void* Wp, int64_t Kp, const void* bias, void* out, int64_t ldc, int64_t N, const void* zeros, void* stream);
-int ull_sam_token_self_attn_ln_f16(const void* queries, const void* qpe, int64_t n, int64_t T, int first, const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
-int ull_sam_token_mlp_ln_f16(const void* queries, int64_t n, int64_t T, int64_t hidden, const void* w1, const void* b1, const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+int ull_sam_self_attn_heads_f16(const void* queries, const void* qpe, int64_t n, int64_t T, int first, const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, void* att, void* stream);
+int ull_sam_out_ln_f16(const void* att, int64_t din, const void* res, const void* qpe, int64_t n, int64_t T, const void* wo, const void* bo, const void* ln_w, const void* ln_b, float eps, void* out, const void* const* projs, const int* add_pe, void* stream);
+int ull_sam_token_mlp_ln_f16(const void* queries, const void* qpe, int64_t n, int64_t T, int64_t hidden, const void* w1, const void* b1, const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* part_ws, void* out, const void* const* projs, const int* add_pe, void* stream);
 int ull_sam_small_mlps_f16(const void* hs, int64_t n, int64_t T, const void* const* ptrs, int64_t n_mask_tokens, int64_t hyper_out, int64_t n_iou, void* hyper, void* iou, void* stream);
-int ull_sam_t2i_attention_ln_f16(const void* queries, const void* qpe, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P, const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo, int late_bias_kv, const void* ln_w, const void* ln_b, float eps, void* scores_ws, void* vproj_ws, void* out, void* stream);
-int ull_sam_i2t_attention_ln_f16(const void* keys, const void* pos, const void* queries, const void* qpe, int64_t n, int64_t T, int64_t P, const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo, int late_bias_q, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
+int ull_sam_t2i_attention_f16(const void* qproj, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P, const void* wk, const void* bk, const void* wv, const void* bv, int late_bias_kv, void* scores_ws, void* vproj_ws, void* att, void* stream);
+int ull_sam_i2t_attention_ln_f16(const void* keys, const void* pos, const void* kproj, const void* vproj, int64_t n, int64_t T, int64_t P, const void* wq, const void* bq, const void* wo, const void* bo, int late_bias_q, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
 int ull_rmsnorm_bwd_f16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, int64_t rows, int64_t D, float eps, void* stream);
 int ull_swiglu_fwd_f16(const void* gu, void* a, int64_t M, int64_t I, void* stream);
 int ull_swiglu_bwd_f16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream);

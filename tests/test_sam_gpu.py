@@ -478,20 +478,23 @@ def test_fused_decoder_kernels_match_the_op_by_op_chain(dt):
     tokens = torch.cat([torch.cat([md.iou_token.weight, md.mask_tokens.weight], 0).unsqueeze(0), text[:1].unsqueeze(1)], dim=1).contiguous()
     keys = ops.add_rows(emb[0], holder.prompt_encoder.no_mask_embed.weight).view(1, 4096, 256)
     pos = eng.dense_pe()
-    q1 = ops.sam_token_self_attn_ln(tokens, tokens, l0.self_attn, l0.norm1, first=True)
+    att0 = ops.sam_self_attn_heads(tokens, tokens, l0.self_attn, first=True)
+    q1, (qp,) = ops.sam_out_ln(att0, None, tokens, l0.self_attn.out_proj, l0.norm1, projs=[(l0.cross_attn_token_to_image.q_proj, True)])
     ref1 = ops.layernorm(eng._attn(l0.self_attn, tokens.view(6, 256), tokens.view(6, 256), tokens.view(6, 256), 1, 6, 6), l0.norm1.weight, l0.norm1.bias, 1e-5)
     flip = 1.0 if dt == torch.bfloat16 else 8.0         # fp16's rounding grid is 8x finer: fp32 summation-order noise flips 8x more roundings
     assert float((q1.view(6, 256) != ref1).float().mean()) <= 0.01 * flip
-    q2 = ops.sam_t2i_attention_ln(q1, tokens, keys, pos, l0.cross_attn_token_to_image, l0.norm2, late_bias_kv=True)
+    att1 = ops.sam_t2i_attention(qp, keys, pos, l0.cross_attn_token_to_image, late_bias_kv=True)
+    q2, _ = ops.sam_out_ln(att1, q1, tokens, l0.cross_attn_token_to_image.out_proj, l0.norm2)
     qq, kk = ops.add_rows(q1.view(6, 256), tokens.view(6, 256)), ops.add_rows(keys.view(4096, 256), pos)
     ref2 = ops.layernorm(eng._attn(l0.cross_attn_token_to_image, qq, kk, keys.view(4096, 256), 1, 6, 4096, residual=q1.view(6, 256), unfused_bias=("k", "v")),
                          l0.norm2.weight, l0.norm2.bias, 1e-5)
     f2 = float((q2.view(6, 256) != ref2).float().mean())
-    q3 = ops.sam_token_mlp_ln(q2, l0.mlp.lin1, l0.mlp.lin2, l0.norm3)
+    q3, (kp, vp) = ops.sam_token_mlp_ln(q2, tokens, l0.mlp.lin1, l0.mlp.lin2, l0.norm3,
+                                        projs=[(l0.cross_attn_image_to_token.k_proj, True), (l0.cross_attn_image_to_token.v_proj, False)])
     m_ = ops.linear(q2.view(6, 256), l0.mlp.lin1.weight, l0.mlp.lin1.bias, act="relu")
     ref3 = ops.layernorm(ops.linear(m_, l0.mlp.lin2.weight, l0.mlp.lin2.bias, residual=q2.view(6, 256)), l0.norm3.weight, l0.norm3.bias, 1e-5)
     f3 = float((q3.view(6, 256) != ref3).float().mean())
-    k1 = ops.sam_i2t_attention_ln(keys, pos, q3, tokens, l0.cross_attn_image_to_token, l0.norm4, late_bias_q=True)
+    k1 = ops.sam_i2t_attention_ln(keys, pos, kp, vp, l0.cross_attn_image_to_token, l0.norm4, late_bias_q=True)
     qq3 = ops.add_rows(q3.view(6, 256), tokens.view(6, 256))
     ref4 = ops.layernorm(eng._attn(l0.cross_attn_image_to_token, kk, qq3, q3.view(6, 256), 1, 4096, 6, residual=keys.view(4096, 256), unfused_bias=("q",)),
                          l0.norm4.weight, l0.norm4.bias, 1e-5)

@@ -18,11 +18,12 @@ SIGNATURES = {
     "ull_gemm_streamk_ws_bytes": [],
     "ull_gemm_qkv_rope_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i32, _ptr, _i64, _ptr],
     "ull_rope_table_bf16": [_ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr],
-    "ull_sam_token_self_attn_ln_bf16": [_ptr, _ptr, _i64, _i64, _i32] + [_ptr] * 10 + [_f32, _ptr, _ptr],
-    "ull_sam_token_mlp_ln_bf16": [_ptr, _i64, _i64, _i64] + [_ptr] * 6 + [_f32, _ptr, _ptr],
+    "ull_sam_self_attn_heads_bf16": [_ptr, _ptr, _i64, _i64, _i32] + [_ptr] * 7 + [_ptr],
+    "ull_sam_out_ln_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, ctypes.POINTER(_ptr), ctypes.POINTER(_i32), _ptr],
+    "ull_sam_token_mlp_ln_bf16": [_ptr, _ptr, _i64, _i64, _i64] + [_ptr] * 6 + [_f32, _ptr, _ptr, ctypes.POINTER(_ptr), ctypes.POINTER(_i32), _ptr],
     "ull_sam_small_mlps_bf16": [_ptr, _i64, _i64, ctypes.POINTER(_ptr), _i64, _i64, _i64, _ptr, _ptr, _ptr],
-    "ull_sam_t2i_attention_ln_bf16": [_ptr] * 4 + [_i64] * 3 + [_ptr] * 8 + [_i32, _ptr, _ptr, _f32, _ptr, _ptr, _ptr, _ptr],
-    "ull_sam_i2t_attention_ln_bf16": [_ptr] * 4 + [_i64] * 3 + [_ptr] * 8 + [_i32, _ptr, _ptr, _f32, _ptr, _ptr],
+    "ull_sam_t2i_attention_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr],
+    "ull_sam_i2t_attention_ln_bf16": [_ptr] * 4 + [_i64] * 3 + [_ptr] * 4 + [_i32, _ptr, _ptr, _f32, _ptr, _ptr],
     "ull_rmsnorm_bwd_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _f32, _ptr],
     "ull_swiglu_fwd_bf16": [_ptr, _ptr, _i64, _i64, _ptr],
     "ull_swiglu_bwd_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _ptr],

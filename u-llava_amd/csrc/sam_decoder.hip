@@ -3,14 +3,17 @@
 // reference: models/segment_anything/modeling/transformer.py:62-106 (TwoWayTransformer), :151-182 (TwoWayAttentionBlock),
 // :220-242 (Attention), mask_decoder.py:137-164 (hyper-network MLPs, IoU head).  One decode used to be ~70 launches of generic
 // kernels (3 Linears + add + transpose + attention + Linear + LayerNorm per attention); here every attention of the block is one or
-// two launches that keep the projected tiles in LDS:
-//   sam_token_self_attn_ln : q/k/v projections, 8-head attention over the T tokens, out-projection, (+residual), LayerNorm
-//   sam_t2i_kv_scores      : k = (keys + pe) Wk^T, v = keys Wv^T on the MFMA for a 64-key tile kept in LDS, q projection, scores
-//   sam_t2i_softmax_out_ln : exact fp32 softmax over all 4096 keys, P V, out-projection, residual, LayerNorm
-//   sam_token_mlp_ln       : 256 -> 2048 -> 256 MLP (ReLU), residual, LayerNorm
-//   sam_i2t_fused          : q = (keys + pe) Wq^T on the MFMA, k / v of the T tokens, softmax over T, P V, out-projection on the MFMA,
-//                            residual, LayerNorm -- the image->token attention in ONE launch, nothing but the new keys written
-//   sam_small_mlps         : the four hyper-network MLPs and the IoU head (3-layer MLPs on single token rows)
+// a few launches that keep the projected tiles in LDS and spread the weight streams over many CUs:
+//   sam_self_attn_heads  : (prompt, head) blocks: q/k/v projections of the head, attention over the T tokens
+//   sam_out_ln           : out-projection (+ residual) + LayerNorm of the T token rows (+ the next attention's token-side projection)
+//   sam_t2i_kv_scores    : 128-key tiles: v = keys Wv^T and k = (keys + pe) Wk^T on the MFMA from ONE LDS-resident tile (weights
+//                          streamed through LDS in K-slices), scaled scores of the T tokens against the tile
+//   sam_t2i_softmax_pv   : (prompt, head) blocks of 16 waves: exact fp32 softmax over all 4096 keys, P V
+//   sam_mlp_partial / sam_mlp_reduce_ln : the 256 -> 2048 -> 256 MLP split over 8 hidden chunks per prompt, then sum + residual +
+//                          LayerNorm (+ the token-side k / v projections of the image->token attention that follows)
+//   sam_i2t_fused        : 128 image rows per block: q = (keys + pe) Wq^T on the MFMA, softmax over the T tokens, P V, out-projection on
+//                          the MFMA, residual, LayerNorm -- the image->token attention in ONE launch, only the new keys are written
+//   sam_small_mlps       : the four hyper-network MLPs and the IoU head (3-layer MLPs on single token rows)
 // Every 16-bit rounding point of the reference's graph is kept (rnd()): Linear output (bias fused in fp32, or added after the rounding
 // where at::linear sees a non-contiguous input -- `late_bias`), tensor adds, scores / sqrt(hd), softmax output, P V, residual adds,
 // LayerNorm output.  Fixed dims: embedding 256, internal dim 128 (cross) / 256 (self), 8 heads, T <= 8 tokens per prompt.
@@ -42,6 +45,31 @@ ULL_DEV float dot_row(const float* __restrict__ x, const elem_t* __restrict__ w,
     return acc;
 }
 
+// Cooperative version for the token-side kernels (a few rows, weight-latency bound): LPO consecutive lanes share one output feature, lane
+// `sub` sums its K / LPO slice for every token row (x rows XS floats apart), xor-shuffles add the slices -- a 256-long dot becomes 8
+// dependent 16-byte weight loads per lane instead of 32.  acc[t] holds the full sum in all LPO lanes.
+constexpr int LPO = 4;
+ULL_DEV void dot_rows_coop(const float* __restrict__ x, int XS, const elem_t* __restrict__ w, int K, int T, int sub, float (&acc)[TMAX]) {
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
+    const int kc = K / LPO;
+    for (int c = sub * kc; c < (sub + 1) * kc; c += 8) {
+        float a[8];
+        unpack8(*(const uint4*)(w + c), a);
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[t] += x[t * XS + c + j] * a[j];
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        acc[t] += __shfl_xor(acc[t], 1, 64);
+        acc[t] += __shfl_xor(acc[t], 2, 64);
+    }
+}
+
 // LayerNorm of T rows of 256 floats in LDS (already rounded values), one wave per row (rows t = wave, wave + nwaves, ...), output 16-bit
 ULL_DEV void layernorm_rows(const float* __restrict__ xs, int T, LnW ln, float eps, elem_t* __restrict__ out, int wave, int nwaves, int lane) {
     for (int t = wave; t < T; t += nwaves) {
@@ -61,61 +89,90 @@ ULL_DEV void layernorm_rows(const float* __restrict__ xs, int T, LnW ln, float e
     }
 }
 
-// ---- token self attention + LayerNorm (transformer.py:151-160) ---------------------------------------------------------------------
-// first layer: q = k = v = queries, queries <- attn (no residual); else q = k = queries + query_pe, v = queries, queries <- queries + attn.
-__global__ __launch_bounds__(256) void sam_token_self_attn_ln_kernel(const elem_t* __restrict__ queries, const elem_t* __restrict__ qpe, int T, int first,
-                                                                     LinW wq, LinW wk, LinW wv, LinW wo, LnW ln, float eps, elem_t* __restrict__ out) {
-    __shared__ float xq[TMAX * D], xv[TMAX * D], qs[TMAX * D], ks[TMAX * D], vs[TMAX * D], pr[NH * TMAX * TMAX];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const elem_t* qr = queries + (long)n * T * D;
-    const elem_t* pe = qpe + (long)n * T * D;
-    for (int e = tid; e < T * D; e += 256) {
-        const float a = e2f(qr[e]);
+// LayerNorm of T rows of 256 floats in LDS (already rounded values), one wave per row; writes the 16-bit output AND leaves the rounded
+// output in LDS (for projections that follow)
+ULL_DEV void layernorm_rows_keep(float* __restrict__ xs, int T, LnW ln, float eps, elem_t* __restrict__ out, int wave, int nwaves, int lane) {
+    for (int t = wave; t < T; t += nwaves) {
+        float v[4], s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = xs[t * D + lane + 64 * i]; s1 += v[i]; }
+        const float mean = wave_sum(s1) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            const float y = rnd(((v[i] - mean) * rstd) * e2f(ln.w[c]) + e2f(ln.b[c]));
+            out[(long)t * D + c] = f2e(y);
+            xs[t * D + c] = y;
+        }
+    }
+}
+
+// token-side projections emitted by the kernels that produce new queries: p[t][o] = rnd(dot(x_t (+ qpe_t), W[o]) + b[o]), o < 128
+struct Proj { LinW w; int add_pe; elem_t* out; };          // out [n, T, 128]; w.w == nullptr: unused
+struct ProjSet { Proj p[3]; };
+ULL_DEV void token_projections(const float* __restrict__ xs /* LDS [T][256], rounded */, float* __restrict__ tmp /* LDS [T][256] */,
+                               const elem_t* __restrict__ qpe, int T, const ProjSet& ps, long n, int tid, int nthr) {
+    for (int k = 0; k < 3; ++k) {
+        const Proj& pr = ps.p[k];
+        if (pr.w.w == nullptr) continue;                      // (uniform across the block)
+        __syncthreads();
+        for (int e = tid; e < T * D; e += nthr) tmp[e] = pr.add_pe ? rnd(xs[e] + e2f(qpe[n * T * D + e])) : xs[e];
+        __syncthreads();
+        for (int e = tid; e < DI * LPO; e += nthr) {          // (nthr is a multiple of LPO; DI * LPO = 512 work items)
+            const int o = e / LPO, sub = e % LPO;
+            float acc[TMAX];
+            dot_rows_coop(tmp, D, pr.w.w + (long)o * D, D, T, sub, acc);
+            const float b = e2f(pr.w.b[o]);
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < T && sub == (t & (LPO - 1))) pr.out[(n * T + t) * DI + o] = f2e(acc[t] + b);
+        }
+    }
+}
+
+// ---- token self attention, one (prompt, head) per block (transformer.py:151-160, 220-242; head dim 32) ---------------------------------
+// first layer: q = k = v = queries; else q = k = queries + query_pe, v = queries.  o [n, T, 256] = concatenated heads (rounded).
+__global__ __launch_bounds__(384) void sam_self_attn_heads_kernel(const elem_t* __restrict__ queries, const elem_t* __restrict__ qpe, int T, int first,
+                                                                  LinW wq, LinW wk, LinW wv, elem_t* __restrict__ o) {
+    constexpr int HD = D / NH;                                // 32
+    __shared__ float xq[TMAX * D], xv[TMAX * D], q[TMAX * HD], k[TMAX * HD], v[TMAX * HD], pr[TMAX * TMAX];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const long n = blockIdx.y;
+    for (int e = tid; e < T * D; e += 384) {
+        const float a = e2f(queries[n * T * D + e]);
         xv[e] = a;
-        xq[e] = first ? a : rnd(a + e2f(pe[e]));
+        xq[e] = first ? a : rnd(a + e2f(qpe[n * T * D + e]));
     }
     __syncthreads();
-    {   // projections: thread o owns output feature o of q, k, v for every token
-        const int o = tid;
-        float aq[TMAX], ak[TMAX], av[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) aq[t] = ak[t] = av[t] = 0.f;
-        for (int c = 0; c < D; c += 8) {
-            float a[8], b[8], cc[8];
-            unpack8(*(const uint4*)(wq.w + (long)o * D + c), a);
-            unpack8(*(const uint4*)(wk.w + (long)o * D + c), b);
-            unpack8(*(const uint4*)(wv.w + (long)o * D + c), cc);
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t) {
-                if (t < T) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        aq[t] += xq[t * D + c + j] * a[j];
-                        ak[t] += xq[t * D + c + j] * b[j];
-                        av[t] += xv[t * D + c + j] * cc[j];
-                    }
-                }
-            }
-        }
-        const float bq = e2f(wq.b[o]), bk = e2f(wk.b[o]), bv = e2f(wv.b[o]);
+    {   // 3 x 32 output features, LPO lanes each
+        const int oi = tid / LPO, sub = tid % LPO;
+        const int which = oi / HD, f = h * HD + oi % HD;
+        const LinW& w = which == 0 ? wq : (which == 1 ? wk : wv);
+        const float* x = which == 2 ? xv : xq;
+        float acc[TMAX];
+        dot_rows_coop(x, D, w.w + (long)f * D, D, T, sub, acc);
+        float* dst = which == 0 ? q : (which == 1 ? k : v);
+        const float b = e2f(w.b[f]);
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
-            if (t < T) { qs[t * D + o] = rnd(aq[t] + bq); ks[t * D + o] = rnd(ak[t] + bk); vs[t * D + o] = rnd(av[t] + bv); }
+            if (t < T && sub == (t & (LPO - 1))) dst[t * HD + oi % HD] = rnd(acc[t] + b);
     }
     __syncthreads();
-    constexpr int HD = D / NH;                                // 32
     const float sq = sqrtf((float)HD);
-    for (int e = tid; e < NH * T * T; e += 256) {             // scores: rnd(rnd(q k) / sqrt(hd))
-        const int u = e % T, t = (e / T) % T, h = e / (T * T);
+    if (tid < T * T) {                                        // scores: rnd(rnd(q k) / sqrt(hd))
+        const int u = tid % T, t = tid / T;
         float acc = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) acc += qs[t * D + h * HD + d] * ks[u * D + h * HD + d];
-        pr[(h * TMAX + t) * TMAX + u] = rnd(rnd(acc) / sq);
+        for (int d = 0; d < HD; ++d) acc += q[t * HD + d] * k[u * HD + d];
+        pr[t * TMAX + u] = rnd(rnd(acc) / sq);
     }
     __syncthreads();
-    if (tid < NH * T) {                                       // softmax over the T keys of one (head, query)
-        const int t = tid % T, h = tid / T;
-        float* row = pr + (h * TMAX + t) * TMAX;
+    if (tid < T) {
+        float* row = pr + tid * TMAX;
         float m = -INFINITY, l = 0.f;
         for (int u = 0; u < T; ++u) m = fmaxf(m, row[u]);
         for (int u = 0; u < T; ++u) l += __expf(row[u] - m);
@@ -123,117 +180,107 @@ __global__ __launch_bounds__(256) void sam_token_self_attn_ln_kernel(const elem_
         for (int u = 0; u < T; ++u) row[u] = rnd(__expf(row[u] - m) * inv);
     }
     __syncthreads();
-    for (int e = tid; e < T * D; e += 256) {                  // o = P V -> xq (reused as the attention output)
-        const int c = e % D, t = e / D, h = c / HD;
+    for (int e = tid; e < T * HD; e += 384) {
+        const int d = e % HD, t = e / HD;
         float acc = 0.f;
-        for (int u = 0; u < T; ++u) acc += pr[(h * TMAX + t) * TMAX + u] * vs[u * D + c];
-        xq[e] = rnd(acc);
+        for (int u = 0; u < T; ++u) acc += pr[t * TMAX + u] * v[u * HD + d];
+        o[(n * T + t) * D + h * HD + d] = f2e(acc);
     }
+}
+
+// ---- out-projection (+ residual) + LayerNorm of the T token rows (+ projections for the next attention) --------------------------------
+// att [n, T, DIN] -> out = LN(res + (att Wo^T + bo)) (res == nullptr: no residual: layer 0's self attention replaces the queries)
+template <int DIN>
+__global__ __launch_bounds__(1024) void sam_out_ln_kernel(const elem_t* __restrict__ att, const elem_t* __restrict__ res, const elem_t* __restrict__ qpe, int T,
+                                                         LinW wo, LnW ln, float eps, elem_t* __restrict__ out, ProjSet ps) {
+    __shared__ float as[TMAX * DIN], xs[TMAX * D], tmp[TMAX * D];
+    const long n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < T * DIN; e += 1024) as[e] = e2f(att[n * T * DIN + e]);
     __syncthreads();
-    {   // out projection (+ residual) -> qs (reused)
-        const int o = tid;
+    {
+        const int o = tid / LPO, sub = tid % LPO;             // 256 output features x LPO lanes
         float acc[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
-        for (int c = 0; c < D; c += 8) {
-            float a[8];
-            unpack8(*(const uint4*)(wo.w + (long)o * D + c), a);
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[t] += xq[t * D + c + j] * a[j];
-                }
-        }
+        dot_rows_coop(as, DIN, wo.w + (long)o * DIN, DIN, T, sub, acc);
         const float bo = e2f(wo.b[o]);
-        __syncthreads();
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
-            if (t < T) {
+            if (t < T && sub == (t & (LPO - 1))) {
                 const float y = rnd(acc[t] + bo);
-                qs[t * D + o] = first ? y : rnd(xv[t * D + o] + y);
+                xs[t * D + o] = res != nullptr ? rnd(e2f(res[(n * T + t) * D + o]) + y) : y;
             }
     }
     __syncthreads();
-    layernorm_rows(qs, T, ln, eps, out + (long)n * T * D, wave, 4, lane);
+    layernorm_rows_keep(xs, T, ln, eps, out + n * T * D, wave, 16, lane);
+    token_projections(xs, tmp, qpe, T, ps, n, tid, 1024);
 }
 
-// ---- MLP block + LayerNorm (transformer.py:168-171): queries <- LN(queries + lin2(relu(lin1(queries)))) ------------------------------
-__global__ __launch_bounds__(1024) void sam_token_mlp_ln_kernel(const elem_t* __restrict__ queries, int T, int HID, LinW w1, LinW w2, LnW ln, float eps,
-                                                                elem_t* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = (float*)smem;                                 // [T][256]
-    float* hs = xs + TMAX * D;                                // [T][HID]
-    float* part = hs + TMAX * HID;                            // [4][T][256] partial sums of lin2
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const elem_t* qr = queries + (long)n * T * D;
-    for (int e = tid; e < T * D; e += 1024) xs[e] = e2f(qr[e]);
+// ---- MLP block (transformer.py:168-171), hidden dimension split over gridDim.x chunks of 256 units ---------------------------------------
+// part [n, chunks, T, 256] fp32 = partial lin2 sums of the chunk's hidden units (lin1 + ReLU computed in LDS)
+__global__ __launch_bounds__(1024) void sam_mlp_partial_kernel(const elem_t* __restrict__ queries, int T, int HID, LinW w1, LinW w2, float* __restrict__ part) {
+    __shared__ float xs[TMAX * D], hs[TMAX * 256];
+    const int ch = blockIdx.x, tid = threadIdx.x;
+    const long n = blockIdx.y;
+    for (int e = tid; e < T * D; e += 1024) xs[e] = e2f(queries[n * T * D + e]);
     __syncthreads();
-    for (int j = tid; j < HID; j += 1024) {
+    const int oi = tid / LPO, sub = tid % LPO;                // 256 units x LPO lanes
+    {
+        const int j = ch * 256 + oi;
         float acc[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
-        for (int c = 0; c < D; c += 8) {
-            float a[8];
-            unpack8(*(const uint4*)(w1.w + (long)j * D + c), a);
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[t] += xs[t * D + c + k] * a[k];
-                }
-        }
+        dot_rows_coop(xs, D, w1.w + (long)j * D, D, T, sub, acc);
         const float b = e2f(w1.b[j]);
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
-            if (t < T) hs[t * HID + j] = fmaxf(rnd(acc[t] + b), 0.f);
+            if (t < T && sub == (t & (LPO - 1))) hs[t * 256 + oi] = fmaxf(rnd(acc[t] + b), 0.f);
     }
     __syncthreads();
-    {   // lin2: output o = tid & 255, K split in 4 quarters (tid >> 8)
-        const int o = tid & 255, qd = tid >> 8;
-        const int k0 = qd * (HID / 4), k1 = k0 + HID / 4;
+    {
         float acc[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
-        for (int c = k0; c < k1; c += 8) {
-            float a[8];
-            unpack8(*(const uint4*)(w2.w + (long)o * HID + c), a);
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[t] += hs[t * HID + c + k] * a[k];
-                }
-        }
+        dot_rows_coop(hs, 256, w2.w + (long)oi * HID + ch * 256, 256, T, sub, acc);
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
-            if (t < T) part[(qd * TMAX + t) * D + o] = acc[t];
+            if (t < T && sub == (t & (LPO - 1))) part[((n * gridDim.x + ch) * TMAX + t) * D + oi] = acc[t];
     }
-    __syncthreads();
+}
+
+// out = LN(queries + (sum of the chunk partials + b2)) (+ projections for the attention that follows)
+__global__ __launch_bounds__(1024) void sam_mlp_reduce_ln_kernel(const float* __restrict__ part, int chunks, const elem_t* __restrict__ queries,
+                                                                const elem_t* __restrict__ qpe, int T, const elem_t* __restrict__ b2, LnW ln, float eps,
+                                                                elem_t* __restrict__ out, ProjSet ps) {
+    __shared__ float xs[TMAX * D], tmp[TMAX * D];
+    const long n = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < T * D; e += 1024) {
         const int o = e % D, t = e / D;
-        const float y = rnd(part[(0 * TMAX + t) * D + o] + part[(1 * TMAX + t) * D + o] + part[(2 * TMAX + t) * D + o] + part[(3 * TMAX + t) * D + o] +
-                            e2f(w2.b[o]));
-        hs[e] = rnd(xs[e] + y);                               // residual; hs reused as [T][256]
+        float acc = 0.f;
+        for (int c = 0; c < chunks; ++c) acc += part[((n * chunks + c) * TMAX + t) * D + o];
+        xs[e] = rnd(e2f(queries[n * T * D + e]) + rnd(acc + e2f(b2[o])));
     }
     __syncthreads();
-    layernorm_rows(hs, T, ln, eps, out + (long)n * T * D, wave, 16, lane);
+    layernorm_rows_keep(xs, T, ln, eps, out + n * T * D, wave, 16, lane);
+    token_projections(xs, tmp, qpe, T, ps, n, tid, 1024);
 }
 
 // ---- the four hyper-network MLPs + the IoU head (mask_decoder.py:137-164): y = L3(relu(L2(relu(L1(hs[n, row]))))) ----------------------
 struct Mlp3 { LinW l[3]; int row; int n_out; elem_t* out; int out_stride; };   // out[n * out_stride + o]
 struct Mlp3Set { Mlp3 m[5]; };
-__global__ __launch_bounds__(256) void sam_small_mlps_kernel(const elem_t* __restrict__ hs, int T, Mlp3Set set) {
+__global__ __launch_bounds__(1024) void sam_small_mlps_kernel(const elem_t* __restrict__ hs, int T, Mlp3Set set) {
     __shared__ float a0[D], a1[D];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n = blockIdx.x, tid = threadIdx.x, o = tid / LPO, sub = tid % LPO;
     const Mlp3& m = set.m[blockIdx.y];
-    a0[tid] = e2f(hs[((long)n * T + m.row) * D + tid]);
+    if (tid < D) a0[tid] = e2f(hs[((long)n * T + m.row) * D + tid]);
     __syncthreads();
-    a1[tid] = fmaxf(rnd(dot_row(a0, m.l[0].w + (long)tid * D, D) + e2f(m.l[0].b[tid])), 0.f);
+    float acc[TMAX];
+    dot_rows_coop(a0, D, m.l[0].w + (long)o * D, D, 1, sub, acc);
+    if (sub == 0) a1[o] = fmaxf(rnd(acc[0] + e2f(m.l[0].b[o])), 0.f);
     __syncthreads();
-    a0[tid] = fmaxf(rnd(dot_row(a1, m.l[1].w + (long)tid * D, D) + e2f(m.l[1].b[tid])), 0.f);
+    dot_rows_coop(a1, D, m.l[1].w + (long)o * D, D, 1, sub, acc);
     __syncthreads();
-    if (tid < m.n_out) m.out[(long)n * m.out_stride + tid] = f2e(dot_row(a0, m.l[2].w + (long)tid * D, D) + e2f(m.l[2].b[tid]));
+    if (sub == 0) a0[o] = fmaxf(rnd(acc[0] + e2f(m.l[1].b[o])), 0.f);
+    __syncthreads();
+    const int oc = o < m.n_out ? o : 0;                       // (all lanes run the shuffles)
+    dot_rows_coop(a0, D, m.l[2].w + (long)oc * D, D, 1, sub, acc);
+    if (sub == 0 && o < m.n_out) m.out[(long)n * m.out_stride + o] = f2e(acc[0] + e2f(m.l[2].b[o]));
 }
 
 // ---- helpers of the two cross-attention kernels --------------------------------------------------------------------------------------
@@ -254,288 +301,285 @@ ULL_DEV void stage_rows(const elem_t* __restrict__ a, const elem_t* __restrict__
     }
 }
 
-// Linear on the MFMA for one wave: out[feature f][row m] = sum_k W[f][k] * X[m][k] for the wave's 16 rows (LDS tile, pitch PXs) and
-// NF * 16 features; K in steps of 32.  acc[i][r] = out[feature i*16 + 4*(lane>>4) + r][row (lane & 15)].
-template <int NF, int KDIM, int PXs>
-ULL_DEV void mfma_linear(const elem_t* __restrict__ W, const elem_t* __restrict__ xt /* wave's first row */, f32x4_t (&acc)[NF], int lane) {
+// Block-cooperative Linear on the MFMA: out[feature f][row m] = sum_k W[f][k] * X[m][k] for the block's X tile in LDS (pitch PXs); every wave
+// owns RT row tiles of 16 rows starting at `xt`; W [NF*16, KDIM] is streamed through the LDS buffer `wsl` ([NF*16][WP]) in 32-wide
+// K-slices, so each weight byte is read from L2 once per block.  acc[rt][i][r] = out[feature i*16 + 4*(lane>>4) + r][row rt*16 + (lane&15)].
+constexpr int WP = 40;                                        // slice pitch (elements): 80-byte rows -> conflict-free ds_read_b128
+template <int NF, int KDIM, int PXs, int RT>
+ULL_DEV void block_linear(const elem_t* __restrict__ W, elem_t* __restrict__ wsl, const elem_t* __restrict__ xt, f32x4_t (&acc)[RT][NF], int tid, int nthr,
+                          int lane) {
     const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < NF; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < NF; ++i) acc[rt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int kk = 0; kk < KDIM / 32; ++kk) {
-        const uint4 xf = *(const uint4*)(xt + fr * PXs + kk * 32 + fg * 8);
+        __syncthreads();                                      // the previous slice has been consumed by every wave
+        for (int c = tid; c < NF * 16 * 4; c += nthr) {
+            const int r = c >> 2, ch = c & 3;
+            *(uint4*)(wsl + r * WP + ch * 8) = *(const uint4*)(W + (long)r * KDIM + kk * 32 + ch * 8);
+        }
+        __syncthreads();
+        uint4 xf[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xf[rt] = *(const uint4*)(xt + (rt * 16 + fr) * PXs + kk * 32 + fg * 8);
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            const uint4 wf = *(const uint4*)(W + (long)(i * 16 + fr) * KDIM + kk * 32 + fg * 8);
-            acc[i] = mfma16(wf, xf, acc[i]);
+            const uint4 wf = *(const uint4*)(wsl + (i * 16 + fr) * WP + fg * 8);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][i] = mfma16(wf, xf[rt], acc[rt][i]);
         }
     }
 }
 
 ULL_DEV float lin_out(float acc, float bias, bool late_bias) { return late_bias ? rnd(rnd(acc) + bias) : rnd(acc + bias); }
 
-// ---- token -> image attention, part 1: k / v projections of a 64-key tile + scores of the T tokens against it --------------------------
-// scores [n, 8, TMAX, P] (16-bit, already scaled), vproj [n, P, 128].
-__global__ __launch_bounds__(256) void sam_t2i_kv_scores_kernel(const elem_t* __restrict__ queries, const elem_t* __restrict__ qpe, int T,
-                                                                const elem_t* __restrict__ keys, const elem_t* __restrict__ pos, int P, LinW wq, LinW wk,
-                                                                LinW wv, int late_bias_kv, elem_t* __restrict__ scores, elem_t* __restrict__ vproj) {
+constexpr int KTB = 128;                                      // image rows per block in the cross-attention kernels
+constexpr int RT = 2;                                         // 16-row MFMA tiles per wave (4 waves x 2 x 16 = 128 rows)
+
+// ---- token -> image attention, part 1: v / k projections of a 128-key tile + scores of the T tokens against it -------------------------
+// qproj [n, T, 128] (from sam_out_ln / sam_mlp_reduce_ln); scores [n, 8, TMAX, P] (16-bit, already scaled); vproj [n, P, 128].
+__global__ __launch_bounds__(256) void sam_t2i_kv_scores_kernel(const elem_t* __restrict__ qproj, int T, const elem_t* __restrict__ keys,
+                                                                const elem_t* __restrict__ pos, int P, LinW wk, LinW wv, int late_bias_kv,
+                                                                elem_t* __restrict__ scores, elem_t* __restrict__ vproj) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    elem_t* kin = (elem_t*)smem;                              // [KT][PX]  keys + pe
-    elem_t* vin = kin + KT * PX;                              // [KT][PX]  keys
-    elem_t* kt = vin + KT * PX;                               // [KT][PI]  projected k tile
-    float* xq = (float*)(kt + KT * PI);                       // [T][256]  queries + pe
-    float* qs = xq + TMAX * D;                                // [T][128]  projected q
-    const int n = blockIdx.y, p0 = blockIdx.x * KT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const elem_t* kr = keys + ((long)n * P + p0) * D;
-    stage_rows(kr, pos + (long)p0 * D, kin, KT, tid, 256);
-    stage_rows(kr, nullptr, vin, KT, tid, 256);
-    for (int e = tid; e < T * D; e += 256) xq[e] = rnd(e2f(queries[(long)n * T * D + e]) + e2f(qpe[(long)n * T * D + e]));
-    __syncthreads();
-    if (tid < DI) {                                           // q projection (T x 128, fused bias): thread o = tid
-        float acc[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
-        for (int c = 0; c < D; c += 8) {
-            float a[8];
-            unpack8(*(const uint4*)(wq.w + (long)tid * D + c), a);
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[t] += xq[t * D + c + j] * a[j];
-                }
-        }
-        const float b = e2f(wq.b[tid]);
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < T) qs[t * DI + tid] = rnd(acc[t] + b);
-    }
+    elem_t* tile = (elem_t*)smem;                             // [KTB][PX]  keys, then keys + pe
+    elem_t* kt = tile + KTB * PX;                             // [KTB][PI]  projected k tile
+    elem_t* wsl = kt + KTB * PI;                              // [128][WP]  weight K-slice
+    float* qs = (float*)(wsl + DI * WP);                      // [T][128]
+    const long n = blockIdx.y;
+    const int p0 = blockIdx.x * KTB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    {   // k tile -> LDS, v tile -> global; wave w owns keys 16w .. 16w+15
-        f32x4_t acc[DI / 16];
-        mfma_linear<DI / 16, D, PX>(wk.w, kin + wave * 16 * PX, acc, lane);
+    const elem_t* kr = keys + (n * P + p0) * D;
+    stage_rows(kr, nullptr, tile, KTB, tid, 256);
+    for (int e = tid; e < T * DI; e += 256) qs[e] = e2f(qproj[n * T * DI + e]);
+    f32x4_t acc[RT][DI / 16];
+    block_linear<DI / 16, D, PX, RT>(wv.w, wsl, tile + wave * (RT * 16) * PX, acc, tid, 256, lane);       // v = keys Wv^T
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        elem_t* vo = vproj + (n * P + p0 + wave * (RT * 16) + rt * 16 + fr) * DI;
 #pragma unroll
         for (int i = 0; i < DI / 16; ++i) {
             float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = lin_out(acc[i][r], e2f(wk.b[i * 16 + fg * 4 + r]), late_bias_kv);
-            uint2 pk;
-            pk.x = pack2e(o[0], o[1]); pk.y = pack2e(o[2], o[3]);
-            *(uint2*)(kt + (wave * 16 + fr) * PI + i * 16 + fg * 4) = pk;
-        }
-        mfma_linear<DI / 16, D, PX>(wv.w, vin + wave * 16 * PX, acc, lane);
-        elem_t* vo = vproj + ((long)n * P + p0 + wave * 16 + fr) * DI;
-#pragma unroll
-        for (int i = 0; i < DI / 16; ++i) {
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = lin_out(acc[i][r], e2f(wv.b[i * 16 + fg * 4 + r]), late_bias_kv);
+            for (int r = 0; r < 4; ++r) o[r] = lin_out(acc[rt][i][r], e2f(wv.b[i * 16 + fg * 4 + r]), late_bias_kv);
             uint2 pk;
             pk.x = pack2e(o[0], o[1]); pk.y = pack2e(o[2], o[3]);
             *(uint2*)(vo + i * 16 + fg * 4) = pk;
         }
     }
-    __syncthreads();
-    constexpr int HD = DI / NH;                               // 16
-    for (int e = tid; e < KT * NH; e += 256) {                // scores of (key j, head h) against every token
-        const int j = e % KT, h = e / KT;
-        float kv[HD];
-        unpack8(*(const uint4*)(kt + j * PI + h * HD), kv);
-        unpack8(*(const uint4*)(kt + j * PI + h * HD + 8), kv + 8);
-        for (int t = 0; t < T; ++t) {
-            float acc = 0.f;
+    __syncthreads();                                          // every wave is done with the plain keys tile
+    for (int c = tid; c < KTB * (D / 8); c += 256) {          // tile <- rnd(keys + pe), in place
+        const int r = c / (D / 8), ch = c % (D / 8);
+        float x[8], y[8];
+        unpack8(*(const uint4*)(tile + r * PX + ch * 8), x);
+        unpack8(*(const uint4*)(pos + (long)(p0 + r) * D + ch * 8), y);
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc += qs[t * DI + h * HD + d] * kv[d];
-            scores[(((long)n * NH + h) * TMAX + t) * P + p0 + j] = f2e(rnd(acc) * 0.25f);      // / sqrt(16): exact scaling
-        }
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        *(uint4*)(tile + r * PX + ch * 8) = pack8(x);
     }
-}
-
-// ---- token -> image attention, part 2: exact softmax over all P keys, P V, out-projection, residual, LayerNorm --------------------------
-__global__ __launch_bounds__(512) void sam_t2i_softmax_out_ln_kernel(const elem_t* __restrict__ scores, const elem_t* __restrict__ vproj,
-                                                                     const elem_t* __restrict__ queries, int T, int P, LinW wo, LnW ln, float eps,
-                                                                     elem_t* __restrict__ out) {
-    __shared__ float os[TMAX * DI], xs[TMAX * D], mst[NH][TMAX], ist[NH][TMAX];
-    constexpr int HD = DI / NH;
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, h = tid >> 6;          // one wave per head
-    const elem_t* sh = scores + ((long)n * NH + h) * TMAX * P;
-    float* m = mst[h];
-    float* inv = ist[h];
-#pragma unroll 1
-    for (int t = 0; t < T; ++t) {                             // statistics of every row (fp32 over the 16-bit scores)
-        float mx = -INFINITY;
-#pragma unroll 1
-        for (int j = lane * 8; j < P; j += 512) {
-            float s[8];
-            unpack8(*(const uint4*)(sh + (long)t * P + j), s);
+    block_linear<DI / 16, D, PX, RT>(wk.w, wsl, tile + wave * (RT * 16) * PX, acc, tid, 256, lane);       // k = (keys + pe) Wk^T
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, s[e]);
-        }
-        mx = wave_max(mx);
-        float l = 0.f;
-#pragma unroll 1
-        for (int j = lane * 8; j < P; j += 512) {
-            float s[8];
-            unpack8(*(const uint4*)(sh + (long)t * P + j), s);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) l += __expf(s[e] - mx);
-        }
-        l = wave_sum(l);
-        if (lane == 0) { m[t] = mx; inv[t] = 1.0f / l; }
-    }
-    __syncthreads();
-    const elem_t* vh = vproj + (long)n * P * DI + h * HD;
-    constexpr int TG = 4;                                     // tokens per pass (register budget: acc 64 + probabilities 32 VGPRs)
-#pragma unroll 1
-    for (int t0 = 0; t0 < T; t0 += TG) {
-        float acc[TG][HD];
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-#pragma unroll
-            for (int d = 0; d < HD; ++d) acc[t][d] = 0.f;
-        float mg[TG], ig[TG];
-#pragma unroll
-        for (int t = 0; t < TG; ++t) { mg[t] = m[(t0 + t) & (TMAX - 1)]; ig[t] = inv[(t0 + t) & (TMAX - 1)]; }   // (rows >= T: unused)
-#pragma unroll 2
-        for (int j = lane; j < P; j += 64) {                  // one key per lane and iteration (keeps the V row + 4 probabilities in registers)
-            float v[HD];
-            unpack8(*(const uint4*)(vh + (long)j * DI), v);
-            unpack8(*(const uint4*)(vh + (long)j * DI + 8), v + 8);
-#pragma unroll
-            for (int t = 0; t < TG; ++t) {
-                const float pr = (t0 + t < T) ? rnd(__expf(e2f(sh[(long)(t0 + t) * P + j]) - mg[t]) * ig[t]) : 0.f;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) acc[t][d] += pr * v[d];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-            if (t0 + t < T) {
-#pragma unroll
-                for (int d = 0; d < HD; ++d) {
-                    const float v = wave_sum(acc[t][d]);
-                    if (lane == 0) os[(t0 + t) * DI + h * HD + d] = rnd(v);
-                }
-            }
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int e = tid; e < T * D; e += 512) {                  // out projection + residual
-        const int o = e % D, t = e / D;
-        const float y = rnd(dot_row(os + t * DI, wo.w + (long)o * DI, DI) + e2f(wo.b[o]));
-        xs[e] = rnd(e2f(queries[(long)n * T * D + e]) + y);
-    }
-    __syncthreads();
-    layernorm_rows(xs, T, ln, eps, out + (long)n * T * D, h, 8, lane);
-}
-
-// ---- image -> token attention, fused (transformer.py:173-180): keys <- LN(keys + attn(q = keys + pe, k = queries + qpe, v = queries)) --
-__global__ __launch_bounds__(256) void sam_i2t_fused_kernel(const elem_t* __restrict__ keys, const elem_t* __restrict__ pos, int P,
-                                                            const elem_t* __restrict__ queries, const elem_t* __restrict__ qpe, int T, LinW wq, LinW wk,
-                                                            LinW wv, LinW wo, int late_bias_q, LnW ln, float eps, elem_t* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    elem_t* kin = (elem_t*)smem;                              // [KT][PX]  keys + pe; later the pre-LayerNorm rows
-    elem_t* qt = kin + KT * PX;                               // [KT][PI]  projected q tile
-    elem_t* ot = qt + KT * PI;                                // [KT][PI]  attention output tile
-    float* xq = (float*)(ot + KT * PI);                       // [T][256]  queries + qpe
-    float* xv = xq + TMAX * D;                                // [T][256]  queries
-    float* ks = xv + TMAX * D;                                // [T][128]
-    float* vs = ks + TMAX * DI;                               // [T][128]
-    const int n = blockIdx.y, p0 = blockIdx.x * KT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fg = lane >> 4;
-    const elem_t* kr = keys + ((long)n * P + p0) * D;
-    stage_rows(kr, pos + (long)p0 * D, kin, KT, tid, 256);
-    for (int e = tid; e < T * D; e += 256) {
-        const float a = e2f(queries[(long)n * T * D + e]);
-        xv[e] = a;
-        xq[e] = rnd(a + e2f(qpe[(long)n * T * D + e]));
-    }
-    __syncthreads();
-    {   // k / v of the tokens: thread -> (matrix, feature)
-        const int o = tid & 127, which = tid >> 7;            // 0: k from xq, 1: v from xv
-        const LinW& w = which ? wv : wk;
-        const float* x = which ? xv : xq;
-        float acc[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) acc[t] = 0.f;
-        for (int c = 0; c < D; c += 8) {
-            float a[8];
-            unpack8(*(const uint4*)(w.w + (long)o * D + c), a);
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[t] += x[t * D + c + j] * a[j];
-                }
-        }
-        const float b = e2f(w.b[o]);
-        float* dst = which ? vs : ks;
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < T) dst[t * DI + o] = rnd(acc[t] + b);
-    }
-    {   // q tile on the MFMA
-        f32x4_t acc[DI / 16];
-        mfma_linear<DI / 16, D, PX>(wq.w, kin + wave * 16 * PX, acc, lane);
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int i = 0; i < DI / 16; ++i) {
             float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = lin_out(acc[i][r], e2f(wq.b[i * 16 + fg * 4 + r]), late_bias_q);
+            for (int r = 0; r < 4; ++r) o[r] = lin_out(acc[rt][i][r], e2f(wk.b[i * 16 + fg * 4 + r]), late_bias_kv);
             uint2 pk;
             pk.x = pack2e(o[0], o[1]); pk.y = pack2e(o[2], o[3]);
-            *(uint2*)(qt + (wave * 16 + fr) * PI + i * 16 + fg * 4) = pk;
+            *(uint2*)(kt + (wave * (RT * 16) + rt * 16 + fr) * PI + i * 16 + fg * 4) = pk;
+        }
+    __syncthreads();
+    constexpr int HD = DI / NH;                               // 16
+    for (int e = tid; e < KTB * NH; e += 256) {               // scores of (key j, head h) against every token
+        const int j = e % KTB, h = e / KTB;
+        float kv[HD];
+        unpack8(*(const uint4*)(kt + j * PI + h * HD), kv);
+        unpack8(*(const uint4*)(kt + j * PI + h * HD + 8), kv + 8);
+        for (int t = 0; t < T; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) a += qs[t * DI + h * HD + d] * kv[d];
+            scores[((n * NH + h) * TMAX + t) * P + p0 + j] = f2e(rnd(a) * 0.25f);       // / sqrt(16): exact scaling
+        }
+    }
+}
+
+// ---- token -> image attention, part 2: one (prompt, head) per block of 16 waves: exact fp32 softmax over all P keys, P V ------------------
+// att [n, T, 128] (the head's 16 columns).  P = 16 waves x 64 lanes x KPL keys.
+template <int KPL>
+__global__ __launch_bounds__(1024) void sam_t2i_softmax_pv_kernel(const elem_t* __restrict__ scores, const elem_t* __restrict__ vproj, int T, int P,
+                                                                  elem_t* __restrict__ att) {
+    constexpr int HD = DI / NH, NW = 16;
+    __shared__ float red[TMAX][NW], stat[2][TMAX], part[NW][TMAX * HD];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long n = blockIdx.y;
+    const elem_t* sh = scores + (n * NH + h) * TMAX * P;
+    const int j0 = (wave * 64 + lane) * KPL;                  // this lane's KPL consecutive keys
+    float sc[TMAX][KPL];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) sc[t][e] = (t < T) ? e2f(sh[(long)t * P + j0 + e]) : 0.f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        float mx = sc[t][0];
+#pragma unroll
+        for (int e = 1; e < KPL; ++e) mx = fmaxf(mx, sc[t][e]);
+        mx = wave_max(mx);
+        if (lane == 0) red[t][wave] = mx;
+    }
+    __syncthreads();
+    if (tid < TMAX) {
+        float mx = red[tid][0];
+        for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[tid][w]);
+        stat[0][tid] = mx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const float mx = stat[0][t];
+        float l = 0.f;
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) l += __expf(sc[t][e] - mx);
+        l = wave_sum(l);
+        if (lane == 0) red[t][wave] = l;
+    }
+    __syncthreads();
+    if (tid < TMAX) {
+        float l = 0.f;
+        for (int w = 0; w < NW; ++w) l += red[tid][w];
+        stat[1][tid] = 1.0f / l;
+    }
+    __syncthreads();
+    const elem_t* vh = vproj + n * P * DI + h * HD;
+    float v[KPL][HD];
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+        unpack8(*(const uint4*)(vh + (long)(j0 + e) * DI), v[e]);
+        unpack8(*(const uint4*)(vh + (long)(j0 + e) * DI + 8), v[e] + 8);
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        if (t < T) {                                          // (uniform)
+            const float mx = stat[0][t], inv = stat[1][t];
+            float acc[HD];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll
+            for (int e = 0; e < KPL; ++e) {
+                const float pr = rnd(__expf(sc[t][e] - mx) * inv);
+#pragma unroll
+                for (int d = 0; d < HD; ++d) acc[d] += pr * v[e][d];
+            }
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                const float s_ = wave_sum(acc[d]);
+                if (lane == 0) part[wave][t * HD + d] = s_;
+            }
         }
     }
     __syncthreads();
+    if (tid < T * HD) {
+        float a = 0.f;
+        for (int w = 0; w < NW; ++w) a += part[w][tid];
+        att[(n * T + tid / HD) * DI + h * HD + tid % HD] = f2e(a);
+    }
+}
+
+// ---- image -> token attention, fused (transformer.py:173-180): keys <- LN(keys + attn(q = keys + pe, k = queries + qpe, v = queries)) --
+// kproj / vproj [n, T, 128]: the token-side projections (from sam_mlp_reduce_ln).
+__global__ __launch_bounds__(256) void sam_i2t_fused_kernel(const elem_t* __restrict__ keys, const elem_t* __restrict__ pos, int P,
+                                                            const elem_t* __restrict__ kproj, const elem_t* __restrict__ vproj, int T, LinW wq, LinW wo,
+                                                            int late_bias_q, LnW ln, float eps, elem_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    elem_t* kin = (elem_t*)smem;                              // [KTB][PX]  keys + pe; later the pre-LayerNorm rows
+    elem_t* qt = kin + KTB * PX;                              // [KTB][PI]  projected q tile; later Wo's K-slices
+    elem_t* ot = qt + KTB * PI;                               // [KTB][PI]  Wq's K-slices, then the attention output tile
+    float* ks = (float*)(ot + KTB * PI);                      // [T][128]
+    float* vs = ks + TMAX * DI;                               // [T][128]
+    const long n = blockIdx.y;
+    const int p0 = blockIdx.x * KTB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const elem_t* kr = keys + (n * P + p0) * D;
+    stage_rows(kr, pos + (long)p0 * D, kin, KTB, tid, 256);
+    for (int e = tid; e < T * DI; e += 256) { ks[e] = e2f(kproj[n * T * DI + e]); vs[e] = e2f(vproj[n * T * DI + e]); }
+    {
+        f32x4_t acc[RT][DI / 16];
+        block_linear<DI / 16, D, PX, RT>(wq.w, ot, kin + wave * (RT * 16) * PX, acc, tid, 256, lane);     // q = (keys + pe) Wq^T
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < DI / 16; ++i) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = lin_out(acc[rt][i][r], e2f(wq.b[i * 16 + fg * 4 + r]), late_bias_q);
+                uint2 pk;
+                pk.x = pack2e(o[0], o[1]); pk.y = pack2e(o[2], o[3]);
+                *(uint2*)(qt + (wave * (RT * 16) + rt * 16 + fr) * PI + i * 16 + fg * 4) = pk;
+            }
+    }
+    __syncthreads();
     constexpr int HD = DI / NH;
-    for (int e = tid; e < KT * NH; e += 256) {                // (image row j, head h): softmax over the T tokens, P V
-        const int j = e % KT, h = e / KT;
+    for (int e = tid; e < KTB * NH; e += 256) {               // (image row j, head h): softmax over the T tokens, P V
+        const int j = e % KTB, h = e / KTB;
         float q[HD], s[TMAX];
         unpack8(*(const uint4*)(qt + j * PI + h * HD), q);
         unpack8(*(const uint4*)(qt + j * PI + h * HD + 8), q + 8);
         float mx = -INFINITY;
-        for (int t = 0; t < T; ++t) {
-            float acc = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc += q[d] * ks[t * DI + h * HD + d];
-            s[t] = rnd(rnd(acc) * 0.25f);
-            mx = fmaxf(mx, s[t]);
+        for (int t = 0; t < TMAX; ++t) {
+            s[t] = -INFINITY;
+            if (t < T) {
+                float a = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) a += q[d] * ks[t * DI + h * HD + d];
+                s[t] = rnd(a) * 0.25f;
+                mx = fmaxf(mx, s[t]);
+            }
         }
         float l = 0.f;
-        for (int t = 0; t < T; ++t) l += __expf(s[t] - mx);
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) l += __expf(s[t] - mx);
         const float inv = 1.0f / l;
         float o[HD];
 #pragma unroll
         for (int d = 0; d < HD; ++d) o[d] = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float pr = rnd(__expf(s[t] - mx) * inv);
 #pragma unroll
-            for (int d = 0; d < HD; ++d) o[d] += pr * vs[t * DI + h * HD + d];
-        }
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) {
+                const float pr = rnd(__expf(s[t] - mx) * inv);
+#pragma unroll
+                for (int d = 0; d < HD; ++d) o[d] += pr * vs[t * DI + h * HD + d];
+            }
         *(uint4*)(ot + j * PI + h * HD) = pack8(o);
         *(uint4*)(ot + j * PI + h * HD + 8) = pack8(o + 8);
     }
-    __syncthreads();
-    {   // out projection on the MFMA (256 features x 16 rows per wave), + residual -> kin (reused), then LayerNorm
-        f32x4_t acc[D / 16];
-        mfma_linear<D / 16, DI, PI>(wo.w, ot + wave * 16 * PI, acc, lane);
-        const elem_t* res = kr + (long)(wave * 16 + fr) * D;
+    {   // out projection on the MFMA (256 features), + bias + residual -> kin rows of this wave, then LayerNorm
+        f32x4_t acc[RT][D / 16];
+        block_linear<D / 16, DI, PI, RT>(wo.w, qt, ot + wave * (RT * 16) * PI, acc, tid, 256, lane);     // (its first barrier orders the ot writes)
 #pragma unroll
-        for (int i = 0; i < D / 16; ++i) {
-            float o[4];
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = wave * (RT * 16) + rt * 16 + fr;
+            const elem_t* res = kr + (long)row * D;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = i * 16 + fg * 4 + r;
-                o[r] = rnd(e2f(res[f]) + rnd(acc[i][r] + e2f(wo.b[f])));
+            for (int i = 0; i < D / 16; ++i) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = i * 16 + fg * 4 + r;
+                    o[r] = rnd(e2f(res[f]) + rnd(acc[rt][i][r] + e2f(wo.b[f])));
+                }
+                uint2 pk;
+                pk.x = pack2e(o[0], o[1]); pk.y = pack2e(o[2], o[3]);
+                *(uint2*)(kin + row * PX + i * 16 + fg * 4) = pk;          // kin was last read by the q projection: each wave rewrites its own rows
             }
-            uint2 pk;
-            pk.x = pack2e(o[0], o[1]); pk.y = pack2e(o[2], o[3]);
-            *(uint2*)(kin + (wave * 16 + fr) * PX + i * 16 + fg * 4) = pk;      // each wave rewrites only its own 16 rows
         }
     }
     __syncthreads();
-    for (int r = wave; r < KT; r += 4) {                      // LayerNorm, one wave per row
+    for (int r = wave; r < KTB; r += 4) {                     // LayerNorm, one wave per row
         float v[4], s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = e2f(kin[r * PX + lane + 64 * i]); s1 += v[i]; }
@@ -544,7 +588,7 @@ __global__ __launch_bounds__(256) void sam_i2t_fused_kernel(const elem_t* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
-        elem_t* orow = out + ((long)n * P + p0 + r) * D;
+        elem_t* orow = out + (n * P + p0 + r) * D;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = lane + 64 * i;
@@ -555,31 +599,59 @@ __global__ __launch_bounds__(256) void sam_i2t_fused_kernel(const elem_t* __rest
 
 inline LinW lw(const void* w, const void* b) { return LinW{(const elem_t*)w, (const elem_t*)b}; }
 
+// projs: HOST array of 3 x {w, b, out} device pointers (w == NULL: unused) + add_pe flags
+inline ProjSet make_projs(const void* const* projs, const int* add_pe) {
+    ProjSet ps;
+    for (int i = 0; i < 3; ++i) {
+        ps.p[i].w = projs ? lw(projs[3 * i], projs[3 * i + 1]) : LinW{nullptr, nullptr};
+        ps.p[i].out = projs ? (elem_t*)projs[3 * i + 2] : nullptr;
+        ps.p[i].add_pe = add_pe ? add_pe[i] : 0;
+    }
+    return ps;
+}
+
 }  // namespace
 
-// queries / qpe [n, T, 256]; weights nn.Linear layout; out [n, T, 256].  first != 0: layer 0 (no positional add, no residual).
-extern "C" int ULL_FN(ull_sam_token_self_attn_ln_)(const void* queries, const void* qpe, int64_t n, int64_t T, int first, const void* wq, const void* bq,
-                                               const void* wk, const void* bk, const void* wv, const void* bv, const void* wo, const void* bo,
-                                               const void* ln_w, const void* ln_b, float eps, void* out, void* stream) {
-    if (!queries || !qpe || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo || !ln_w || !ln_b || !out || n <= 0) return ULL_ERR_ARG;
+// (prompt, head) blocks: q/k/v projections of one head + attention over the T tokens; att [n, T, 256].
+extern "C" int ULL_FN(ull_sam_self_attn_heads_)(const void* queries, const void* qpe, int64_t n, int64_t T, int first, const void* wq, const void* bq,
+                                            const void* wk, const void* bk, const void* wv, const void* bv, void* att, void* stream) {
+    if (!queries || !qpe || !wq || !bq || !wk || !bk || !wv || !bv || !att || n <= 0) return ULL_ERR_ARG;
     if (T <= 0 || T > TMAX) return ULL_ERR_SHAPE;
-    hipLaunchKernelGGL(sam_token_self_attn_ln_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const elem_t*)queries, (const elem_t*)qpe,
-                       (int)T, first, lw(wq, bq), lw(wk, bk), lw(wv, bv), lw(wo, bo), LnW{(const elem_t*)ln_w, (const elem_t*)ln_b}, eps, (elem_t*)out);
+    hipLaunchKernelGGL(sam_self_attn_heads_kernel, dim3(NH, (unsigned)n), dim3(384), 0, (hipStream_t)stream, (const elem_t*)queries, (const elem_t*)qpe,
+                       (int)T, first, lw(wq, bq), lw(wk, bk), lw(wv, bv), (elem_t*)att);
     return ull_check_launch();
 }
 
-extern "C" int ULL_FN(ull_sam_token_mlp_ln_)(const void* queries, int64_t n, int64_t T, int64_t hidden, const void* w1, const void* b1, const void* w2,
-                                         const void* b2, const void* ln_w, const void* ln_b, float eps, void* out, void* stream) {
-    if (!queries || !w1 || !b1 || !w2 || !b2 || !ln_w || !ln_b || !out || n <= 0) return ULL_ERR_ARG;
-    if (T <= 0 || T > TMAX || hidden <= 0 || (hidden & 31) || hidden > 2048) return ULL_ERR_SHAPE;
-    const size_t lds = (size_t)(TMAX * D + TMAX * hidden + 4 * TMAX * D) * sizeof(float);
-    static UllOncePerDevice once;
-    if (once.first() && hipFuncSetAttribute((const void*)sam_token_mlp_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
-        (void)hipGetLastError();
-        return ULL_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(sam_token_mlp_ln_kernel, dim3((unsigned)n), dim3(1024), lds, (hipStream_t)stream, (const elem_t*)queries, (int)T, (int)hidden,
-                       lw(w1, b1), lw(w2, b2), LnW{(const elem_t*)ln_w, (const elem_t*)ln_b}, eps, (elem_t*)out);
+// out [n, T, 256] = LayerNorm(res + att Wo^T + bo) (res NULL: no residual), att [n, T, din] with din = 256 or 128; then up to three
+// token-side projections for the attention that follows: projs = HOST array of 3 x {w [128, 256], b [128], out [n, T, 128]} device
+// pointers (w NULL = unused, projs NULL = none), add_pe[i] != 0: the projection's input is out + qpe.
+extern "C" int ULL_FN(ull_sam_out_ln_)(const void* att, int64_t din, const void* res, const void* qpe, int64_t n, int64_t T, const void* wo, const void* bo,
+                                   const void* ln_w, const void* ln_b, float eps, void* out, const void* const* projs, const int* add_pe, void* stream) {
+    if (!att || !qpe || !wo || !bo || !ln_w || !ln_b || !out || n <= 0) return ULL_ERR_ARG;
+    if (T <= 0 || T > TMAX || (din != D && din != DI)) return ULL_ERR_SHAPE;
+    const ProjSet ps = make_projs(projs, add_pe);
+    const LnW ln{(const elem_t*)ln_w, (const elem_t*)ln_b};
+    if (din == D)
+        hipLaunchKernelGGL(sam_out_ln_kernel<D>, dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream, (const elem_t*)att, (const elem_t*)res,
+                           (const elem_t*)qpe, (int)T, lw(wo, bo), ln, eps, (elem_t*)out, ps);
+    else
+        hipLaunchKernelGGL(sam_out_ln_kernel<DI>, dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream, (const elem_t*)att, (const elem_t*)res,
+                           (const elem_t*)qpe, (int)T, lw(wo, bo), ln, eps, (elem_t*)out, ps);
+    return ull_check_launch();
+}
+
+// MLP block + LayerNorm in two launches: part_ws float32 [n * (hidden / 256) * 8 * 256] (caller-owned); projections as in ull_sam_out_ln.
+extern "C" int ULL_FN(ull_sam_token_mlp_ln_)(const void* queries, const void* qpe, int64_t n, int64_t T, int64_t hidden, const void* w1, const void* b1,
+                                         const void* w2, const void* b2, const void* ln_w, const void* ln_b, float eps, void* part_ws, void* out,
+                                         const void* const* projs, const int* add_pe, void* stream) {
+    if (!queries || !qpe || !w1 || !b1 || !w2 || !b2 || !ln_w || !ln_b || !part_ws || !out || n <= 0) return ULL_ERR_ARG;
+    if (T <= 0 || T > TMAX || hidden <= 0 || (hidden & 255)) return ULL_ERR_SHAPE;
+    const int chunks = (int)(hidden / 256);
+    hipLaunchKernelGGL(sam_mlp_partial_kernel, dim3(chunks, (unsigned)n), dim3(1024), 0, (hipStream_t)stream, (const elem_t*)queries, (int)T, (int)hidden,
+                       lw(w1, b1), lw(w2, b2), (float*)part_ws);
+    hipLaunchKernelGGL(sam_mlp_reduce_ln_kernel, dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream, (const float*)part_ws, chunks, (const elem_t*)queries,
+                       (const elem_t*)qpe, (int)T, (const elem_t*)b2, LnW{(const elem_t*)ln_w, (const elem_t*)ln_b}, eps, (elem_t*)out,
+                       make_projs(projs, add_pe));
     return ull_check_launch();
 }
 
@@ -595,49 +667,50 @@ extern "C" int ULL_FN(ull_sam_small_mlps_)(const void* hs, int64_t n, int64_t T,
         if (i < 4) { set.m[i].row = 1 + i; set.m[i].n_out = (int)hyper_out; set.m[i].out = (elem_t*)hyper + i * hyper_out; set.m[i].out_stride = (int)(4 * hyper_out); }
         else { set.m[i].row = 0; set.m[i].n_out = (int)n_iou; set.m[i].out = (elem_t*)iou; set.m[i].out_stride = (int)n_iou; }
     }
-    hipLaunchKernelGGL(sam_small_mlps_kernel, dim3((unsigned)n, 5), dim3(256), 0, (hipStream_t)stream, (const elem_t*)hs, (int)T, set);
+    hipLaunchKernelGGL(sam_small_mlps_kernel, dim3((unsigned)n, 5), dim3(1024), 0, (hipStream_t)stream, (const elem_t*)hs, (int)T, set);
     return ull_check_launch();
 }
 
-// token -> image attention of TwoWayAttentionBlock / final_attn_token_to_image, two launches on `stream`.  keys [n, P, 256], pos [P, 256],
-// queries / qpe [n, T, 256]; scratch: scores [n, 8, 8, P] + vproj [n, P, 128] elements (caller-owned); out [n, T, 256] = new queries.
-extern "C" int ULL_FN(ull_sam_t2i_attention_ln_)(const void* queries, const void* qpe, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P,
-                                             const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo,
-                                             const void* bo, int late_bias_kv, const void* ln_w, const void* ln_b, float eps, void* scores_ws,
-                                             void* vproj_ws, void* out, void* stream) {
-    if (!queries || !qpe || !keys || !pos || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo || !ln_w || !ln_b || !scores_ws || !vproj_ws || !out ||
-        n <= 0)
-        return ULL_ERR_ARG;
-    if (T <= 0 || T > TMAX || P <= 0 || (P % 512)) return ULL_ERR_SHAPE;
-    const size_t lds = (size_t)(2 * KT * PX + KT * PI) * sizeof(elem_t) + (size_t)(TMAX * D + TMAX * DI) * sizeof(float);
+// token -> image attention core (transformer.py:162-166, :100-105), two launches: (1) 128-key tiles: v / k projections on the MFMA from one
+// LDS-resident tile + scaled scores against qproj [n, T, 128]; (2) (prompt, head) blocks: exact fp32 softmax over all P keys and P V ->
+// att [n, T, 128] (out-projection / residual / LayerNorm: ull_sam_out_ln).  Caller-owned scratch: scores_ws [n*8*8*P], vproj_ws [n*P*128].
+extern "C" int ULL_FN(ull_sam_t2i_attention_)(const void* qproj, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P, const void* wk,
+                                          const void* bk, const void* wv, const void* bv, int late_bias_kv, void* scores_ws, void* vproj_ws, void* att,
+                                          void* stream) {
+    if (!qproj || !keys || !pos || !wk || !bk || !wv || !bv || !scores_ws || !vproj_ws || !att || n <= 0) return ULL_ERR_ARG;
+    if (T <= 0 || T > TMAX || (P != 4096 && P != 1024)) return ULL_ERR_SHAPE;
+    const size_t lds = (size_t)(KTB * PX + KTB * PI + DI * WP) * sizeof(elem_t) + (size_t)(TMAX * DI) * sizeof(float);
     static UllOncePerDevice once;
     if (once.first() && hipFuncSetAttribute((const void*)sam_t2i_kv_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
         (void)hipGetLastError();
         return ULL_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(sam_t2i_kv_scores_kernel, dim3((unsigned)(P / KT), (unsigned)n), dim3(256), lds, (hipStream_t)stream, (const elem_t*)queries,
-                       (const elem_t*)qpe, (int)T, (const elem_t*)keys, (const elem_t*)pos, (int)P, lw(wq, bq), lw(wk, bk), lw(wv, bv), late_bias_kv,
-                       (elem_t*)scores_ws, (elem_t*)vproj_ws);
-    hipLaunchKernelGGL(sam_t2i_softmax_out_ln_kernel, dim3((unsigned)n), dim3(512), 0, (hipStream_t)stream, (const elem_t*)scores_ws,
-                       (const elem_t*)vproj_ws, (const elem_t*)queries, (int)T, (int)P, lw(wo, bo), LnW{(const elem_t*)ln_w, (const elem_t*)ln_b}, eps,
-                       (elem_t*)out);
+    hipLaunchKernelGGL(sam_t2i_kv_scores_kernel, dim3((unsigned)(P / KTB), (unsigned)n), dim3(256), lds, (hipStream_t)stream, (const elem_t*)qproj, (int)T,
+                       (const elem_t*)keys, (const elem_t*)pos, (int)P, lw(wk, bk), lw(wv, bv), late_bias_kv, (elem_t*)scores_ws, (elem_t*)vproj_ws);
+    if (P == 4096)
+        hipLaunchKernelGGL(sam_t2i_softmax_pv_kernel<4>, dim3(NH, (unsigned)n), dim3(1024), 0, (hipStream_t)stream, (const elem_t*)scores_ws,
+                           (const elem_t*)vproj_ws, (int)T, (int)P, (elem_t*)att);
+    else
+        hipLaunchKernelGGL(sam_t2i_softmax_pv_kernel<1>, dim3(NH, (unsigned)n), dim3(1024), 0, (hipStream_t)stream, (const elem_t*)scores_ws,
+                           (const elem_t*)vproj_ws, (int)T, (int)P, (elem_t*)att);
     return ull_check_launch();
 }
 
-// image -> token attention of TwoWayAttentionBlock in one launch: out [n, P, 256] = LN(keys + attn(keys + pos, queries + qpe, queries)).
-extern "C" int ULL_FN(ull_sam_i2t_attention_ln_)(const void* keys, const void* pos, const void* queries, const void* qpe, int64_t n, int64_t T, int64_t P,
-                                             const void* wq, const void* bq, const void* wk, const void* bk, const void* wv, const void* bv, const void* wo,
-                                             const void* bo, int late_bias_q, const void* ln_w, const void* ln_b, float eps, void* out, void* stream) {
-    if (!keys || !pos || !queries || !qpe || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo || !ln_w || !ln_b || !out || n <= 0) return ULL_ERR_ARG;
-    if (T <= 0 || T > TMAX || P <= 0 || (P % KT) || keys == out) return ULL_ERR_SHAPE;
-    const size_t lds = (size_t)(KT * PX + 2 * KT * PI) * sizeof(elem_t) + (size_t)(2 * TMAX * D + 2 * TMAX * DI) * sizeof(float);
+// image -> token cross attention + norm4 (transformer.py:173-180) in ONE launch per 128 image rows; kproj / vproj [n, T, 128] = the
+// token-side projections (ull_sam_token_mlp_ln); out [n, P, 256] (must not alias keys).
+extern "C" int ULL_FN(ull_sam_i2t_attention_ln_)(const void* keys, const void* pos, const void* kproj, const void* vproj, int64_t n, int64_t T, int64_t P,
+                                             const void* wq, const void* bq, const void* wo, const void* bo, int late_bias_q, const void* ln_w,
+                                             const void* ln_b, float eps, void* out, void* stream) {
+    if (!keys || !pos || !kproj || !vproj || !wq || !bq || !wo || !bo || !ln_w || !ln_b || !out || n <= 0) return ULL_ERR_ARG;
+    if (T <= 0 || T > TMAX || P <= 0 || (P % KTB) || keys == out) return ULL_ERR_SHAPE;
+    const size_t lds = (size_t)(KTB * PX + 2 * KTB * PI) * sizeof(elem_t) + (size_t)(2 * TMAX * DI) * sizeof(float);
     static UllOncePerDevice once;
-    if (once.first() && hipFuncSetAttribute((const void*)sam_i2t_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+    if (once.first() && hipFuncSetAttribute((const void*)sam_i2t_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) {
         (void)hipGetLastError();
         return ULL_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(sam_i2t_fused_kernel, dim3((unsigned)(P / KT), (unsigned)n), dim3(256), lds, (hipStream_t)stream, (const elem_t*)keys,
-                       (const elem_t*)pos, (int)P, (const elem_t*)queries, (const elem_t*)qpe, (int)T, lw(wq, bq), lw(wk, bk), lw(wv, bv), lw(wo, bo),
-                       late_bias_q, LnW{(const elem_t*)ln_w, (const elem_t*)ln_b}, eps, (elem_t*)out);
+    hipLaunchKernelGGL(sam_i2t_fused_kernel, dim3((unsigned)(P / KTB), (unsigned)n), dim3(256), lds, (hipStream_t)stream, (const elem_t*)keys,
+                       (const elem_t*)pos, (int)P, (const elem_t*)kproj, (const elem_t*)vproj, (int)T, lw(wq, bq), lw(wo, bo), late_bias_q,
+                       LnW{(const elem_t*)ln_w, (const elem_t*)ln_b}, eps, (elem_t*)out);
     return ull_check_launch();
 }

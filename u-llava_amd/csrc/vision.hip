@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const elem_t* __restri
     const long r = blockIdx.x;
     const elem_t* s = src + idx[r] * lds_;
     elem_t* d = dst + r * ldd;
-    for (int c = threadIdx.x; c < (D >> 3); c += 256) *(uint4*)(d + c * 8) = *(const uint4*)(s + c * 8);
+    // long rows (the mask decoder gathers whole 2-MB image embeddings) are split over gridDim.y blocks
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < (D >> 3); c += 256 * gridDim.y) *(uint4*)(d + c * 8) = *(const uint4*)(s + c * 8);
 }
 
 // out = bf16(a + b[row % b_rows])   (row-broadcast add: residual adds, + positional tables)
@@ -229,7 +230,9 @@ extern "C" int ULL_FN(ull_gather_rows_)(const void* src, int64_t lds_, const voi
     if (!src || !idx || !dst) return ULL_ERR_ARG;
     if (n == 0) return ULL_OK;
     if ((D & 7) || (lds_ & 7) || (ldd & 7)) return ULL_ERR_SHAPE;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const elem_t*)src, lds_, (const int64_t*)idx,
+    const long chunks = D >> 3;
+    const unsigned ny = (unsigned)(chunks > 4096 ? (chunks / 2048 < 512 ? chunks / 2048 : 512) : 1);       // >= 8 chunks (128 B) per thread
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n, ny), dim3(256), 0, (hipStream_t)stream, (const elem_t*)src, lds_, (const int64_t*)idx,
                        (elem_t*)dst, ldd, (int)D);
     return ull_check_launch();
 }

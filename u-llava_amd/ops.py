@@ -699,23 +699,54 @@ def _lin_ptrs(*lins):
     return out
 
 
-def sam_token_self_attn_ln(queries, qpe, a, ln, first: bool, eps: float = 1e-5):
-    """queries / qpe [n, T, 256]; `a`: holder with q_proj / k_proj / v_proj / out_proj; ln: LayerNorm holder -> new queries."""
+def _proj_args(projs, n: int, T: int, like: torch.Tensor):
+    """projs: list of up to 3 (linear holder, add_pe) -> (ctypes pointer array or None, ctypes int array or None, output tensors)."""
+    import ctypes
+    if not projs:
+        return None, None, []
+    outs, ptrs, flags = [], [], []
+    for lin, add_pe in projs:
+        o = torch.empty(n, T, lin.weight.shape[0], device=like.device, dtype=like.dtype)
+        outs.append(o)
+        ptrs += [_p(lin.weight), _p(lin.bias), _p(o)]
+        flags.append(int(add_pe))
+    while len(flags) < 3:
+        ptrs += [None, None, None]
+        flags.append(0)
+    return (ctypes.c_void_p * 9)(*ptrs), (ctypes.c_int * 3)(*flags), outs
+
+
+def sam_self_attn_heads(queries, qpe, a, first: bool):
+    """queries / qpe [n, T, 256] -> concatenated head outputs [n, T, 256] of the token self attention (before out_proj)."""
     _chk(queries, "queries"); _chk(qpe, "qpe", queries.dtype)
     n, T, _ = queries.shape
-    out = torch.empty_like(queries)
-    _lib.call("ull_sam_token_self_attn_ln_" + _SFX[queries.dtype], _p(queries), _p(qpe), n, T, int(first), *_lin_ptrs(a.q_proj, a.k_proj, a.v_proj, a.out_proj),
-              _p(ln.weight), _p(ln.bias), float(eps), _p(out), _stream())
-    return out
+    att = torch.empty_like(queries)
+    _lib.call("ull_sam_self_attn_heads_" + _SFX[queries.dtype], _p(queries), _p(qpe), n, T, int(first), *_lin_ptrs(a.q_proj, a.k_proj, a.v_proj), _p(att),
+              _stream())
+    return att
 
 
-def sam_token_mlp_ln(queries, lin1, lin2, ln, eps: float = 1e-5):
-    _chk(queries, "queries")
+def sam_out_ln(att, res, qpe, out_proj, ln, projs=None, eps: float = 1e-5):
+    """LayerNorm(res + out_proj(att)) (res None: no residual) + token-side projections for the next attention -> (out, [proj outputs])."""
+    _chk(att, "att"); _chk(qpe, "qpe", att.dtype)
+    n, T, din = att.shape
+    out = torch.empty(n, T, 256, device=att.device, dtype=att.dtype)
+    pa, fa, outs = _proj_args(projs, n, T, att)
+    _lib.call("ull_sam_out_ln_" + _SFX[att.dtype], _p(att), din, _p(res), _p(qpe), n, T, _p(out_proj.weight), _p(out_proj.bias), _p(ln.weight), _p(ln.bias),
+              float(eps), _p(out), pa, fa, _stream())
+    return out, outs
+
+
+def sam_token_mlp_ln(queries, qpe, lin1, lin2, ln, projs=None, eps: float = 1e-5):
+    _chk(queries, "queries"); _chk(qpe, "qpe", queries.dtype)
     n, T, _ = queries.shape
+    hidden = lin1.weight.shape[0]
+    ws = torch.empty(n * (hidden // 256) * 8 * 256, device=queries.device, dtype=torch.float32)
     out = torch.empty_like(queries)
-    _lib.call("ull_sam_token_mlp_ln_" + _SFX[queries.dtype], _p(queries), n, T, lin1.weight.shape[0], *_lin_ptrs(lin1, lin2), _p(ln.weight), _p(ln.bias),
-              float(eps), _p(out), _stream())
-    return out
+    pa, fa, outs = _proj_args(projs, n, T, queries)
+    _lib.call("ull_sam_token_mlp_ln_" + _SFX[queries.dtype], _p(queries), _p(qpe), n, T, hidden, *_lin_ptrs(lin1, lin2), _p(ln.weight), _p(ln.bias),
+              float(eps), _p(ws), _p(out), pa, fa, _stream())
+    return out, outs
 
 
 def sam_small_mlps(hs, hyper_mlps, iou_head):
@@ -734,26 +765,25 @@ def sam_small_mlps(hs, hyper_mlps, iou_head):
     return hyper, iou
 
 
-def sam_t2i_attention_ln(queries, qpe, keys, pos, a, ln, late_bias_kv: bool, eps: float = 1e-5):
-    """token -> image attention + residual + LayerNorm: queries / qpe [n, T, 256], keys [n, P, 256], pos [P, 256] -> new queries."""
-    _chk(queries, "queries"); _chk(qpe, "qpe", queries.dtype); _chk(keys, "keys", queries.dtype); _chk(pos, "pos", queries.dtype)
-    n, T, _ = queries.shape
+def sam_t2i_attention(qproj, keys, pos, a, late_bias_kv: bool):
+    """token -> image attention core: qproj [n, T, 128], keys [n, P, 256], pos [P, 256] -> attention output [n, T, 128] (before out_proj)."""
+    _chk(qproj, "qproj"); _chk(keys, "keys", qproj.dtype); _chk(pos, "pos", qproj.dtype)
+    n, T, _ = qproj.shape
     P = keys.shape[1]
     ws_s = torch.empty(n * 8 * 8 * P, device=keys.device, dtype=keys.dtype)
     ws_v = torch.empty(n * P * 128, device=keys.device, dtype=keys.dtype)
-    out = torch.empty_like(queries)
-    _lib.call("ull_sam_t2i_attention_ln_" + _SFX[queries.dtype], _p(queries), _p(qpe), _p(keys), _p(pos), n, T, P,
-              *_lin_ptrs(a.q_proj, a.k_proj, a.v_proj, a.out_proj), int(late_bias_kv), _p(ln.weight), _p(ln.bias), float(eps), _p(ws_s), _p(ws_v), _p(out),
-              _stream())
-    return out
+    att = torch.empty(n, T, 128, device=keys.device, dtype=keys.dtype)
+    _lib.call("ull_sam_t2i_attention_" + _SFX[qproj.dtype], _p(qproj), _p(keys), _p(pos), n, T, P, *_lin_ptrs(a.k_proj, a.v_proj), int(late_bias_kv),
+              _p(ws_s), _p(ws_v), _p(att), _stream())
+    return att
 
 
-def sam_i2t_attention_ln(keys, pos, queries, qpe, a, ln, late_bias_q: bool, eps: float = 1e-5):
+def sam_i2t_attention_ln(keys, pos, kproj, vproj, a, ln, late_bias_q: bool, eps: float = 1e-5):
     """image -> token attention + residual + LayerNorm in one launch -> new keys [n, P, 256]."""
-    _chk(keys, "keys"); _chk(pos, "pos", keys.dtype); _chk(queries, "queries", keys.dtype); _chk(qpe, "qpe", keys.dtype)
-    n, T, _ = queries.shape
+    _chk(keys, "keys"); _chk(pos, "pos", keys.dtype); _chk(kproj, "kproj", keys.dtype); _chk(vproj, "vproj", keys.dtype)
+    n, T, _ = kproj.shape
     P = keys.shape[1]
     out = torch.empty_like(keys)
-    _lib.call("ull_sam_i2t_attention_ln_" + _SFX[keys.dtype], _p(keys), _p(pos), _p(queries), _p(qpe), n, T, P,
-              *_lin_ptrs(a.q_proj, a.k_proj, a.v_proj, a.out_proj), int(late_bias_q), _p(ln.weight), _p(ln.bias), float(eps), _p(out), _stream())
+    _lib.call("ull_sam_i2t_attention_ln_" + _SFX[keys.dtype], _p(keys), _p(pos), _p(kproj), _p(vproj), n, T, P, *_lin_ptrs(a.q_proj, a.out_proj),
+              int(late_bias_q), _p(ln.weight), _p(ln.bias), float(eps), _p(out), _stream())
     return out

@@ -247,12 +247,14 @@ class SamEngine:
 
     def _fusable(self, D, P, T, nm) -> bool:
         c = self.cfg
-        return D == 256 and c.decoder_heads == 8 and c.decoder_mlp_dim <= 2048 and c.decoder_mlp_dim % 32 == 0 and P % 512 == 0 and T <= 8 and nm == 4 \
+        return D == 256 and c.decoder_heads == 8 and c.decoder_mlp_dim % 256 == 0 and P in (4096, 1024) and T <= 8 and nm == 4 \
             and self.sam.mask_decoder.transformer.layers[0].cross_attn_token_to_image.q_proj.weight.shape[0] == 128
 
     def _decode_fused(self, image_embedding_tm, tokens, image_index, n, D, P, g, nm, T):
-        """decode() with every attention / MLP block of the TwoWayTransformer as one or two launches (17 launches per decode instead
-        of ~70; LDS-resident key tiles, nothing but the block outputs written to HBM).  Same rounding points as the op-by-op chain."""
+        """decode() on the fused kernels of csrc/sam_decoder.hip: 8 launches per TwoWayAttentionBlock (self-attention heads, out+LN,
+        k/v tile projections + scores, softmax + PV, out+LN, MLP partials, reduce+LN, image->token attention in one launch) -- 27 per
+        decode instead of ~85, key tiles LDS-resident, weights streamed through LDS once per block.  Same rounding points as the
+        op-by-op chain."""
         md, tr, pk = self.sam.mask_decoder, self.sam.mask_decoder.transformer, self.pk()
         src = ops.add_rows(image_embedding_tm.reshape(-1, D), self.sam.prompt_encoder.no_mask_embed.weight)
         if image_index is None:
@@ -261,13 +263,21 @@ class SamEngine:
             keys = ops.gather_rows(src.view(-1, P * D), image_index).view(n, P, D)
         pos = self.dense_pe()
         queries = tokens
+        nl = len(tr.layers)
         for i, l in enumerate(tr.layers):
-            queries = ops.sam_token_self_attn_ln(queries, tokens, l.self_attn, l.norm1, first=(i == 0))
+            att = ops.sam_self_attn_heads(queries, tokens, l.self_attn, first=(i == 0))
+            queries, (q_t2i,) = ops.sam_out_ln(att, None if i == 0 else queries, tokens, l.self_attn.out_proj, l.norm1,
+                                               projs=[(l.cross_attn_token_to_image.q_proj, True)])
             # layer 0: the image keys are still non-contiguous views in the reference -> at::linear's unfused-bias path (see _attn)
-            queries = ops.sam_t2i_attention_ln(queries, tokens, keys, pos, l.cross_attn_token_to_image, l.norm2, late_bias_kv=(i == 0))
-            queries = ops.sam_token_mlp_ln(queries, l.mlp.lin1, l.mlp.lin2, l.norm3)
-            keys = ops.sam_i2t_attention_ln(keys, pos, queries, tokens, l.cross_attn_image_to_token, l.norm4, late_bias_q=(i == 0))
-        hs = ops.sam_t2i_attention_ln(queries, tokens, keys, pos, tr.final_attn_token_to_image, tr.norm_final_attn, late_bias_kv=False)
+            att = ops.sam_t2i_attention(q_t2i, keys, pos, l.cross_attn_token_to_image, late_bias_kv=(i == 0))
+            queries, _ = ops.sam_out_ln(att, queries, tokens, l.cross_attn_token_to_image.out_proj, l.norm2)
+            projs = [(l.cross_attn_image_to_token.k_proj, True), (l.cross_attn_image_to_token.v_proj, False)]
+            if i == nl - 1:
+                projs.append((tr.final_attn_token_to_image.q_proj, True))
+            queries, pr = ops.sam_token_mlp_ln(queries, tokens, l.mlp.lin1, l.mlp.lin2, l.norm3, projs=projs)
+            keys = ops.sam_i2t_attention_ln(keys, pos, pr[0], pr[1], l.cross_attn_image_to_token, l.norm4, late_bias_q=(i == 0))
+        att = ops.sam_t2i_attention(pr[2], keys, pos, tr.final_attn_token_to_image, late_bias_kv=False)
+        hs, _ = ops.sam_out_ln(att, queries, tokens, tr.final_attn_token_to_image.out_proj, tr.norm_final_attn)
         ln = md.output_upscaling[1]
         y1 = ops.linear(keys.view(n * P, D), pk["up0_w"], pk["up0_b"])
         y1 = ops.layernorm2d_cl(y1.view(-1, D // 4), ln.weight, ln.bias, 1e-6, gelu=True)
