@@ -369,11 +369,14 @@ def sam_attention(sd, p: str, x: Tensor, n_heads: int) -> Tensor:
     return linear(o, sd, p + "proj")
 
 
-def sam_image_encoder(sd, scfg: dict, x: Tensor, pfx: str = "visual_model.image_encoder.") -> Tensor:
-    """ImageEncoderViT.forward (image_encoder.py:110-125); bf16/fp32 go straight through the neck."""
+def sam_image_encoder(sd, scfg: dict, x: Tensor, pfx: str = "visual_model.image_encoder.", trace: Optional[dict] = None) -> Tensor:
+    """ImageEncoderViT.forward (image_encoder.py:110-125); bf16/fp32 go straight through the neck.
+    trace: optional dict receiving the stage outputs ([B, H, W, C] after the patch embedding and after every block)."""
     ps = scfg["patch_size"]
     x = F.conv2d(x, sd[pfx + "patch_embed.proj.weight"], sd[pfx + "patch_embed.proj.bias"], stride=ps).permute(0, 2, 3, 1)
     x = x + sd[pfx + "pos_embed"]
+    if trace is not None:
+        trace["embed"] = x
     for i in range(scfg["depth"]):
         p = f"{pfx}blocks.{i}."
         ws = 0 if i in scfg["global_attn_indexes"] else scfg["window_size"]
@@ -386,8 +389,12 @@ def sam_image_encoder(sd, scfg: dict, x: Tensor, pfx: str = "visual_model.image_
         if ws > 0:
             y = window_unpartition(y, ws, pad_hw, (Hh, Ww))
         x = sc + y
+        if trace is not None:
+            trace[f"block{i}.attn"] = x
         y = layer_norm(x, sd, p + "norm2", 1e-6)
         x = x + linear(F.gelu(linear(y, sd, p + "mlp.lin1")), sd, p + "mlp.lin2")
+        if trace is not None:
+            trace[f"block{i}"] = x
     x = x.permute(0, 3, 1, 2)
     x = F.conv2d(x, sd[pfx + "neck.0.weight"])
     x = layer_norm_2d(x, sd[pfx + "neck.1.weight"], sd[pfx + "neck.1.bias"])

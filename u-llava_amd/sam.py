@@ -151,8 +151,8 @@ class SamEngine:
         return self._pk if self._pk is not None else self.pack()
 
     # -- image encoder (image_encoder.py:110-125) ------------------------------------------------------------------
-    def encode(self, pixel_values: torch.Tensor) -> torch.Tensor:
-        """[B,3,S,S] -> token-major embeddings [B, g*g, out_chans]."""
+    def encode(self, pixel_values: torch.Tensor, trace: Optional[dict] = None) -> torch.Tensor:
+        """[B,3,S,S] -> token-major embeddings [B, g*g, out_chans].  trace: optional dict receiving the stage outputs [B, g, g, C]."""
         cfg, enc, pk = self.cfg, self.sam.image_encoder, self.pk()
         B = pixel_values.shape[0]
         C, nH = cfg.embed_dim, cfg.num_heads
@@ -164,6 +164,8 @@ class SamEngine:
             cols = ops.im2col(pixel_values.to(enc.pos_embed.dtype).contiguous(), cfg.patch_size, pk["patch_w"].shape[1])
             x = ops.linear(cols, pk["patch_w"], enc.patch_embed.proj.bias)       # [B*g*g, C]
         x = ops.add_rows(x, pk["pos"])
+        if trace is not None:
+            trace["embed"] = x.view(B, g, g, C)
         for i, blk in enumerate(enc.blocks):
             glob = i in cfg.global_attn_indexes
             ws = 0 if glob else cfg.window_size
@@ -195,9 +197,13 @@ class SamEngine:
                 x = ops.window_unpartition_add(o, x, B, g, g, ws)
             else:
                 x = ops.linear(att, blk.attn.proj.weight, blk.attn.proj.bias, residual=x)
+            if trace is not None:
+                trace[f"block{i}.attn"] = x.view(B, g, g, C)
             y = ops.layernorm(x, blk.norm2.weight, blk.norm2.bias, 1e-6)
             f = ops.linear(y, blk.mlp.lin1.weight, blk.mlp.lin1.bias, act="gelu")
             x = ops.linear(f, blk.mlp.lin2.weight, blk.mlp.lin2.bias, residual=x)
+            if trace is not None:
+                trace[f"block{i}"] = x.view(B, g, g, C)
         x = ops.linear(x, pk["neck0"])
         x = ops.layernorm2d_cl(x, enc.neck[1].weight, enc.neck[1].bias, 1e-6)
         x = ops.linear(ops.im2col3x3(x, B, g, g), pk["neck2"])
