@@ -53,9 +53,11 @@ extern "C" {
  * slabs of 256 KiB there and summed by a finalize launch on the same stream).  NULL / 0 = never split.  The library keeps no
  * buffer and no per-stream state of its own: concurrent calls on different streams are independent as long as each passes its own
  * workspace (ull_gemm_streamk_ws_bytes() is enough for any shape).  Whether to split at all is the caller's policy.
- * Bits 16..20 of flags are per-call tuning overrides for tools/ (ULL_GEMM_TUNE_*); 0 = shipped heuristics. */
+ * Bits 16..22 of flags are per-call tuning overrides for tools/ (ULL_GEMM_TUNE_*); 0 = shipped heuristics. */
 #define ULL_GEMM_TUNE_GROUP_M(g) (((g) & 15) << 16) /* tile raster: M-tiles walked before the next N-tile */
 #define ULL_GEMM_TUNE_SMALL_KERNEL (1 << 20)        /* force the 128x128 kernel */
+#define ULL_GEMM_TUNE_WAVES8 (1 << 21)              /* 256x256 tile on 8 waves of 128x64, whatever the shape */
+#define ULL_GEMM_TUNE_WAVES4 (1 << 22)              /* 256x256 tile on 4 waves of 128x128, whatever the shape */
 int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                   int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream);
 

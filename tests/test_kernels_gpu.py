@@ -499,3 +499,45 @@ def test_qkv_gemm_with_fused_rope_is_bit_identical_to_gemm_then_rope(M, D, dt):
     got = ops.linear_qkv_rope(x, w, cs, sn, 2 * D, hd)
     assert torch.equal(got[:, 2 * D:], v_before), "v columns must pass through"
     assert torch.equal(got, ref), f"fused RoPE differs: {int((got != ref).sum())} elements"
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind", ["plain", "bias_gelu_resid", "swiglu", "f32", "f32_bias_relu", "rope", "tiled_w"])
+def test_gemm_256_tile_on_4_and_8_waves_agree(kind, dt):
+    """The two forms of the 256x256 kernel (4 waves of 128x128 with AGPR accumulators, 8 waves of 128x64) are forced through every
+    epilogue on shapes with ragged edges, a stream-K tail and a long K: bit-identical to each other, and checked against fp32 math."""
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    for (M, N, K) in ((256 * 5 + 37, 256 * 3 + 128, 512), (256 * 41 + 5, 256 * 7, 1024), (1029, 1024, 11008)):
+        g = torch.Generator().manual_seed(M + K)
+        x = torch.randn(M, K, generator=g).to(dt).to(DEV)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(DEV)
+        b = torch.randn(N, generator=g).to(dt).to(DEV)
+        r = torch.randn(M, N, generator=g).to(dt).to(DEV)
+        outs = []
+        for tune in (ops.GEMM_TUNE_WAVES4, ops.GEMM_TUNE_WAVES8):
+            if kind == "plain":
+                y = ops.linear(x, w, tune=tune)
+            elif kind == "bias_gelu_resid":
+                y = ops.linear(x, w, b, act="gelu", residual=r, tune=tune)
+            elif kind == "swiglu":
+                y = ops.linear(x, w, swiglu=True, tune=tune)
+            elif kind == "f32":
+                y = ops.linear(x, w, out_f32=True, tune=tune)
+            elif kind == "f32_bias_relu":
+                y = ops.linear(x, w, b, act="relu", out_f32=True, tune=tune)
+            elif kind == "rope":
+                pos = (torch.arange(M) % 643).to(DEV)
+                inv = (1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float) / 128))).to(DEV)
+                cs, sn = ops.rope_table(pos, inv, dt)
+                y = ops.linear_qkv_rope(x, w, cs, sn, (N // 128 // 2) * 128 or 128, 128, tune=tune)
+            else:
+                ops.register_tiled(w)
+                y = ops.linear(x, w, b, tune=tune)
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]), f"{kind} {M}x{N}x{K}: {int((outs[0] != outs[1]).sum())} elements differ between the wave forms"
+        if kind == "plain":
+            ref = x.float() @ w.float().t()
+            assert float((outs[0].float() - ref).abs().max()) <= 2.0 ** (-8 if dt == torch.bfloat16 else -11) * float(ref.abs().max()) * 1.01
+        elif kind == "f32":
+            ref = x.float() @ w.float().t()
+            assert float((outs[0] - ref).abs().max()) <= 1e-4 * float(ref.abs().max())

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Kernel A/B experiments only: links copies of the library whose GEMM was compiled with one ULL_ABL_* switch (results are garbage with
+# most of them; they answer "what does the K-loop cost without X").  Output: tools/probes/lib_<name>.so, loaded through ULL_LIB_PATH.
+set -e
+cd "$(dirname "$0")/../u-llava_amd/csrc"
+OTHERS=$(ls *.o | grep -v '^gemm\.o$')
+for abl in "$@"; do
+  DEFS=$(echo $abl | tr '+' '\n' | sed 's/^/-DULL_ABL_/' | tr '\n' ' ')      # A+B = both switches
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $DEFS -c gemm.hip -o /tmp/gemm_$abl.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probes/lib_$abl.so /tmp/gemm_$abl.o $OTHERS
+done

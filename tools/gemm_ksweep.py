@@ -5,6 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("u-llava_amd.ops")
 dev = "cuda:0"
+TUNE = int(os.environ.get("TUNE", 0))
 g = torch.Generator(device=dev).manual_seed(0)
 for name, M, N, sw in (("qkv", 20576, 12288, False), ("gateup", 20576, 22016, True), ("o/down", 20576, 4096, False), ("full27", 256 * 27, 256 * 256, False)):
     res = []
@@ -13,11 +14,11 @@ for name, M, N, sw in (("qkv", 20576, 12288, False), ("gateup", 20576, 22016, Tr
         w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)
         out = torch.empty(M, N // 2 if sw else N, device=dev, dtype=torch.bfloat16)
         for _ in range(2):
-            ops.linear(x, w, swiglu=sw, out=out)
+            ops.linear(x, w, swiglu=sw, out=out, tune=TUNE)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(8):
-            ops.linear(x, w, swiglu=sw, out=out)
+            ops.linear(x, w, swiglu=sw, out=out, tune=TUNE)
         e1.record(); e1.synchronize()
         res.append((K, e0.elapsed_time(e1) / 8))
     (k1, t1), (k2, t2) = res[1], res[3]

@@ -12,5 +12,5 @@ w = (torch.randn(N, K, device="cuda:0", generator=g) * K ** -0.5).to(torch.bfloa
 ops.register_tiled(w)          # tile-major copy, as pack_weights() does for the model's Linears
 out = torch.empty(M, N // 2 if sw else N, device="cuda:0", dtype=torch.bfloat16)
 for _ in range(3):
-    ops.linear(x, w, swiglu=sw, out=out)
+    ops.linear(x, w, swiglu=sw, out=out, tune=int(os.environ.get('TUNE', 0)))
 torch.cuda.synchronize()

@@ -22,6 +22,7 @@
 //     tile space, walked in GROUP_M-row groups so co-resident blocks share X / W panels in that L2).
 #include "ull_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -82,7 +83,9 @@ ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */)
 // ROPE (fused q|k|v projection): a head of 128 columns is parked by two neighbouring waves (64 columns each); after a block barrier
 // every wave rotates its half against the partner's: out = rnd(x * cos) + rnd(-+x_partner * sin), rounded once more by the store --
 // the three roundings of apply_rotary_pos_emb on 16-bit tensors (hf modeling_llama.py:129-159), same as rope_inplace_kernel.
-template <bool SWIGLU, int JT, bool ROPE = false>
+// PHASE: 0 = park + finish (with the block barrier between them when ROPE); 1 = park only, 2 = finish only -- for a wave that owns both
+// halves of a head (the 4-wave kernel) and parks them in two regions before finishing either.
+template <bool SWIGLU, int JT, bool ROPE = false, int PHASE = 0>
 ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg, int lane, int mrow0, int nw0, const char* reg_partner = nullptr) {
     constexpr int ROWS = JT * 16;
     const int fr = lane & 15, fg = lane >> 4;
@@ -162,6 +165,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
     if (!raw_f32) {
         constexpr int WCOLS = SWIGLU ? 32 : 64;            // output columns of this wave
         constexpr int PITCH = WCOLS * 2 + 16;              // bytes; +16 keeps 16-byte alignment and spreads banks
+        if constexpr (PHASE != 2) {
 #pragma clang loop unroll(full)
         for (int j = 0; j < JT; ++j) {
             if constexpr (SWIGLU) {
@@ -191,7 +195,9 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region only: no block barrier needed
-        if constexpr (ROPE) __builtin_amdgcn_s_barrier();      // ... unless the partner wave's half of the head is read below
+        }
+        if constexpr (PHASE == 1) return;
+        if constexpr (ROPE && PHASE == 0) __builtin_amdgcn_s_barrier();   // ... unless the partner wave's half of the head is read below
         constexpr int LPR = WCOLS / 8;                         // lanes per row (16 B each)
         constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
 #pragma unroll 2
@@ -627,6 +633,249 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     staged_epilogue<SWIGLU, 8, ROPE>(p, acc, smem + wave * (128 * 144), lane, m0 + wm * 128, n0 + wn * 64, smem + (wave ^ 1) * (128 * 144));
 }
 
+// ---- 4-wave form of the same tile ---------------------------------------------------------------------------------------------
+// Same 256x256x64 block tile, LDS layout, raster and stream-K tail, but 256 threads = 4 waves (2 x 2), 128(m) x 128(n) per wave:
+// 64 accumulators (256 registers; one wave per SIMD owns the SIMD's whole 512-entry register file) and 16 fragment reads per 64 MFMAs
+// instead of 12 per 32 -- a K-step reads 128 KiB of fragments from LDS per CU instead of 192 KiB.  Counters on the gate/up launch
+// (profiles/r02_gemm_notes.md) put the 8-wave kernel and the vendor BLAS's kernel at the same L2 requests, hit rate and fabric bytes,
+// and differ in exactly this: LDS instructions (8.6e7 vs 5.8e7), VALU/SALU instructions and the share of cycles the MFMA pipe is busy
+// (68 % vs 84 %), so the staging path was never the bound -- the CU-side instruction stream was.
+// With a single wave per SIMD nothing hides an issue stall, so the K-step is scheduled by hand in chunks of 4 MFMAs with a
+// sched_barrier between chunks (schedule: at the loop).
+// DMA addressing: scalar base (advanced per K-step) + one 32-bit VGPR offset per piece.
+struct Frags4 { uint4 w[8]; uint4 x[8]; };
+constexpr int LDS_BYTES_W4 = LDS_BYTES + 16 * 1024;   // + the dump of the last two steps' prefetches: all 160 KiB of the CU
+
+// The accumulators are pinned to the AGPR half of the register file and accumulated in place through inline asm: with the builtin,
+// hipcc's allocator splits the 64 accumulators between VGPRs and AGPRs under the 512-register pressure and shuffles them with
+// ~340 v_accvgpr moves per K-step.  (The asm is opaque to the hazard recognizer: the K-loop never re-reads an accumulator sooner than
+// 64 MFMAs later, and the epilogue waits out the last MFMA explicitly.)
+#ifdef ULL_ELEM_F16
+#define ULL_MFMA16_ASM "v_mfma_f32_16x16x32_f16"
+#else
+#define ULL_MFMA16_ASM "v_mfma_f32_16x16x32_bf16"
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+ULL_DEV void mfma16_inplace(f32x4_t& c, const uint4& a, const uint4& b) {
+    const u32x4_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+#if !defined(ULL_ABL_NOMMA)
+    asm volatile(ULL_MFMA16_ASM " %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+#else
+    asm volatile("" : "+a"(c) : "v"(av), "v"(bv));
+#endif
+}
+
+ULL_DEV void glds16s(const void* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_byte_addr /* wave-uniform */) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
+template <bool SWIGLU, bool ROPE = false>
+__global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    int bid = blockIdx.x;
+    int slice = 0;
+    const bool split = bid >= p.t_full;
+    if (!split) {
+        const int nwg = p.t_full;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective for any nwg
+    } else {
+        const int r = bid - p.t_full;
+        bid = p.t_full + r / p.sk;
+        slice = r % p.sk;
+    }
+    const int per_group = p.group_m * p.nbn;
+    const int gid = bid / per_group;
+    const int first_m = gid * p.group_m;
+    const int gsz = min(p.nbm - first_m, p.group_m);
+    const int bm = first_m + (bid % per_group) % gsz;
+    const int bn = (bid % per_group) / gsz;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nk_total = p.K / BK;
+    const bool w_tiled = p.flags & EPI_W_TILED, x_tiled = p.flags & EPI_X_TILED;
+
+    // DMA: a 1-KiB piece = 8 rows x 128 B; wave w stages pieces 8w..8w+7 of X and of W.
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    uint32_t xo[8], wo[8];                            // byte offsets from the tile's first row
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (wave * 8 + i) * 8 + srow;
+        xo[i] = x_tiled ? (uint32_t)(r * BK + schunk * 8) * 2 : (uint32_t)(((long)(min(m0 + r, p.M - 1) - m0) * p.ldx + schunk * 8) * 2);
+        wo[i] = w_tiled ? (uint32_t)(r * BK + schunk * 8) * 2 : (uint32_t)(((long)(min(n0 + r, p.N - 1) - n0) * p.ldw + schunk * 8) * 2);
+    }
+    const elem_t* xbase = x_tiled ? p.X + ((long)bm * nk_total) * BM * BK : p.X + (long)m0 * p.ldx;
+    const elem_t* wbase = w_tiled ? p.W + ((long)bn * nk_total) * BN * BK : p.W + (long)n0 * p.ldw;
+    const long xstep = x_tiled ? BM * BK : BK, wstep = w_tiled ? BN * BK : BK;    // elements between consecutive K-tiles
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    const uint32_t piece_off = wave * 8 * 1024;
+    // piece c of tile kt: c < 8 -> X piece, else W piece
+    auto dma_piece = [&](const elem_t* xk, const elem_t* wk, uint32_t slot_addr, int c) {
+#if defined(ULL_ABL_DMASAME)     // every piece re-reads the same KiB: the issue cost of the DMA without its memory traffic
+        glds16s(p.X, (uint32_t)lane * 16, slot_addr + c * 1024);
+        return;
+#endif
+        if (c < 8) glds16s(xk, xo[c], slot_addr + c * 1024);
+        else glds16s(wk, wo[c - 8], slot_addr + OP_BYTES + (c - 8) * 1024);
+    };
+    auto stage_all = [&](int kt) {
+        const elem_t* xk = xbase + (long)kt * xstep;
+        const elem_t* wk = wbase + (long)kt * wstep;
+        const uint32_t sa = lds_base + (kt & 1) * SLOT_BYTES + piece_off;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dma_piece(xk, wk, sa, c);
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int swz[2];
+    swz[0] = ((0 + fg) ^ (lane & 7)) << 4;
+    swz[1] = ((4 + fg) ^ (lane & 7)) << 4;
+    const int xoff = (wm * 128 + fr) * (BK * 2);
+    const int woff = OP_BYTES + (wn * 128 + fr) * (BK * 2);
+    // c-th fragment read of a half step: the 8 W fragments first (all of them feed the first two chunks), then X in use order
+    auto read_one = [&](int kt, int kk, Frags4& f, int c) {
+        const char* base = smem + (kt & 1) * SLOT_BYTES + swz[kk];
+        if (c < 8) f.w[c] = *(const uint4*)(base + woff + c * 16 * (BK * 2));
+        else f.x[c - 8] = *(const uint4*)(base + xoff + (c - 8) * 16 * (BK * 2));
+    };
+
+    f32x4_t acc[2][4][8];                             // [half of the 128 n-columns][i][j]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[h][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // chunk c of a half step: MFMAs (j = c / 2, i = 4 (c % 2) .. + 3)
+    auto chunk_mma = [&](const Frags4& f, int c) {
+        const int j = c >> 1, h = c & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mfma16_inplace(acc[h][i][j], f.w[h * 4 + i], f.x[j]);
+    };
+
+    int nk = p.K / BK;                                // >= 2 (host dispatch, also per K-slice)
+    if (split) {
+        const int kt0 = (int)((long)nk * slice / p.sk), kt1 = (int)((long)nk * (slice + 1) / p.sk);
+        xbase += (long)kt0 * xstep; wbase += (long)kt0 * wstep;
+        nk = kt1 - kt0;
+    }
+    stage_all(0);
+    stage_all(1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // tile 0 landed, tile 1 in flight
+    __builtin_amdgcn_s_barrier();
+    Frags4 fa, fb;                                    // fa: half 0 of the current tile, fb: half 1
+#pragma unroll
+    for (int c = 0; c < 16; ++c) read_one(0, 0, fa, c);
+    // One loop over all K-steps and nothing between it and the epilogue that touches an accumulator: the register allocator puts any
+    // accumulator copy it wants (loop exit, a second loop's entry) directly behind the last MFMA, which is an opaque asm to it and so
+    // gets no wait states.  Hence: the last two steps (nothing left to prefetch) skip their DMA pieces through wave-uniform branches
+    // instead of living in a loop of their own, the fragment reads of "tile nk" in the very last step fetch stale LDS that is never
+    // used, and the wait for the matrix pipe sits inside the loop body, at the end of the last step.
+    // A K-step is 128 slots of one MFMA each (0..63 on fa = k-half 0 of tile kt, 64..127 on fb = k-half 1), every slot fenced by a
+    // sched_barrier.  A SIMD with one wave issues one instruction per 4 clocks and an MFMA holds the matrix pipe for 16, so at most
+    // three other instructions fit behind an MFMA for free, and a group of them anywhere idles the pipe: everything else is dealt out
+    // one or two instructions per slot.
+    //   slots   0..15  read fb <- (kt, half 1), one fragment per slot
+    //   slot   32      lgkmcnt(0) + barrier A: every wave is done with slot kt
+    //   slots  32..95  one DMA piece of tile kt+2 per 4 slots into that slot (m0 write, the MFMA as its wait state, the load: one asm)
+    //   slot   96      vmcnt(16): tile kt+1 (issued a step ago) has landed, tile kt+2 stays in flight; barrier B: visible to all
+    //   slots  96..127 read fa <- (kt+1, half 0), one fragment per 2 slots, in first-use order
+    // so the memory pipe is never drained (1.0-1.5 steps for a piece to land) and never sees a burst.  The last two steps have nothing
+    // to prefetch: they re-fetch the last tile (L2 hits) into a 16-KiB dump behind the epilogue regions instead of branching.
+    constexpr int USE_ORDER[16] = {0, 8, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15};   // read_one index: w0, x0, w1..w7, x1..x7
+    // slot s of a half: accumulator (j = s / 8, h = (s / 4) % 2, i = s % 4)
+    auto slot_mma = [&](const Frags4& f, int s) {
+        const int j = s >> 3, h = (s >> 2) & 1, i = s & 3;
+        mfma16_inplace(acc[h][i][j], f.w[h * 4 + i], f.x[j]);
+    };
+    auto slot_mma_dma = [&](const Frags4& f, int s, const void* sbase, uint32_t voff, uint32_t lds_addr) {
+        const int j = s >> 3, h = (s >> 2) & 1, i = s & 3;
+        const uint4 &a = f.w[h * 4 + i], &b = f.x[j];
+        const u32x4_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+#if defined(ULL_ABL_NODMA)
+        asm volatile(ULL_MFMA16_ASM " %0, %1, %2, %0" : "+a"(acc[h][i][j]) : "v"(av), "v"(bv));
+#elif defined(ULL_ABL_NOMMA)
+        asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4"
+                     : "+a"(acc[h][i][j]) : "v"(av), "v"(bv), "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+#else
+        asm volatile("s_mov_b32 m0, %5\n\t" ULL_MFMA16_ASM " %0, %1, %2, %0\n\tglobal_load_lds_dwordx4 %3, %4"
+                     : "+a"(acc[h][i][j]) : "v"(av), "v"(bv), "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+#endif
+    };
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(m0_keep));        // the loop writes m0 without saving it (the compiler emits nothing that reads it there)
+    const uint32_t dump = lds_base + LDS_BYTES;               // 16 KiB, all four waves
+#pragma clang loop unroll(disable)                      // also keeps the unroller from peeling the first step off into a copy of the loop
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool with_dma = kt + 2 < nk;
+        const int ktd = with_dma ? kt + 2 : nk - 1;
+        const elem_t* xk = xbase + (long)ktd * xstep;
+        const elem_t* wk = wbase + (long)ktd * wstep;
+        const uint32_t sa = with_dma ? lds_base + (kt & 1) * SLOT_BYTES + piece_off : dump;
+        const uint32_t sw = with_dma ? sa + OP_BYTES : dump;
+#pragma clang loop unroll(full)
+        for (int s = 0; s < 128; ++s) {
+            if (s == 32) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(ULL_ABL_NOBAR)
+                __builtin_amdgcn_s_barrier();
+#endif
+            }
+            if (s == 96) {
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#if !defined(ULL_ABL_NOBAR)
+                __builtin_amdgcn_s_barrier();
+#endif
+            }
+#if !defined(ULL_ABL_NOREAD)
+            if (s < 16) read_one(kt, 1, fb, s);
+            if (s >= 96 && !(s & 1)) read_one(kt + 1, 0, fa, USE_ORDER[(s - 96) >> 1]);
+#endif
+            if (s >= 32 && s < 96 && !(s & 3)) {
+                const int pc = (s - 32) >> 2;             // piece: 0..7 of X, 8..15 of W
+                if (pc < 8) slot_mma_dma(fa /* s < 64 */, s, xk, xo[pc], sa + pc * 1024);
+                else slot_mma_dma(fb, s - 64, wk, wo[pc - 8], sw + (pc - 8) * 1024);
+            } else if (s < 64) slot_mma(fa, s);
+            else slot_mma(fb, s - 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kt == nk - 1) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    }
+    asm volatile("s_mov_b32 m0, %0\n\ts_waitcnt vmcnt(0)" :: "s"(m0_keep) : "memory");   // (the dump's pieces: nothing may be in flight at exit)
+
+    // ---- epilogue: acc[h][i][j][r] = D[n = n0 + wn*128 + h*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
+    if (split) {
+        float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 8; ++j)
+#pragma clang loop unroll(full)
+            for (int h = 0; h < 2; ++h)
+#pragma clang loop unroll(full)
+                for (int i = 0; i < 4; ++i)
+                    *(f32x4_t*)(slab + (wm * 128 + j * 16 + fr) * BN + wn * 128 + h * 64 + i * 16 + fg * 4) = acc[h][i][j];
+        return;
+    }
+    __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
+    char* reg0 = smem + wave * (2 * 128 * 144);
+    char* reg1 = reg0 + 128 * 144;
+    const int mrow0 = m0 + wm * 128, nw0 = n0 + wn * 128;
+    if constexpr (ROPE) {
+        // the wave owns whole heads (128 columns): park both halves, then rotate each against the other
+        staged_epilogue<SWIGLU, 8, true, 1>(p, acc[0], reg0, lane, mrow0, nw0);
+        staged_epilogue<SWIGLU, 8, true, 1>(p, acc[1], reg1, lane, mrow0, nw0 + 64);
+        staged_epilogue<SWIGLU, 8, true, 2>(p, acc[0], reg0, lane, mrow0, nw0, reg1);
+        staged_epilogue<SWIGLU, 8, true, 2>(p, acc[1], reg1, lane, mrow0, nw0 + 64, reg0);
+    } else {
+        staged_epilogue<SWIGLU, 8, false>(p, acc[0], reg0, lane, mrow0, nw0);
+        staged_epilogue<SWIGLU, 8, false>(p, acc[1], reg1, lane, mrow0, nw0 + 64);
+    }
+}
+
 // (A v_mfma_f32_32x32x16_bf16 variant of this kernel measured 6-11 % slower in this structure and was removed;
 // numbers in profiles/r01_gemm_notes.md.)
 
@@ -732,6 +981,9 @@ static int gemm_device_state(int* n_cu_out) {
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
+        (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
+        (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
@@ -760,6 +1012,8 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
     // per-call tuning overrides (tools/ only; 0 = the shipped policy)
     const int tune_group_m = (flags >> 16) & 15;
     const bool force_small = flags & (1 << 20);
+    const bool force_waves8 = flags & (1 << 21);
+    const bool force_waves4 = (flags & (1 << 22)) && ldx < (1 << 21) && ldw < (1 << 21);
     flags &= 0xffff;
     if ((flags & EPI_BIAS_ROUNDED) && (flags & EPI_SWIGLU)) return ULL_ERR_SHAPE;
     GemmArgs a;
@@ -795,7 +1049,19 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
         // measured sweep at M=20576 (profiles/r01_gemm_notes.md): 4 M-tiles x 8 N-tiles per XCD wave beats 8 x 4 by ~5 %
         a.group_m = tune_group_m ? tune_group_m : 4;
         const int grid = a.sk > 1 ? a.t_full + rem * a.sk : T;
-        if (flags & EPI_SWIGLU)
+        // The 4-wave form has the faster K-loop and the slower tile turn-around (one wave per SIMD: nothing overlaps the epilogue's and
+        // the prologue's latencies), so it takes the long-K, many-round launches -- the LLaMA layer -- and the 8-wave form the ViT /
+        // SAM shapes (measured crossover, tools/gemm_bench.py: K = 3072 and 2.5 rounds still favour 8 waves by 1-3 %).  It addresses
+        // its DMA pieces with 32-bit offsets from the tile's first row.
+        const bool waves4 = force_waves4 || (!force_waves8 && K >= 4096 && T >= 4 * n_cu && ldx < (1 << 21) && ldw < (1 << 21));
+        if (waves4) {
+            if (flags & EPI_SWIGLU)
+                hipLaunchKernelGGL(big::gemm256w4_kernel<true>, dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
+            else if (rope)
+                hipLaunchKernelGGL((big::gemm256w4_kernel<false, true>), dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(big::gemm256w4_kernel<false>, dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
+        } else if (flags & EPI_SWIGLU)
             hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
         else if (rope)
             hipLaunchKernelGGL((big::gemm256_kernel<false, true>), dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);

@@ -221,8 +221,11 @@ def rope_table(positions: torch.Tensor, inv_freq: torch.Tensor, dtype) -> tuple:
     return cs, sn
 
 
+GEMM_TUNE_WAVES8, GEMM_TUNE_WAVES4 = 1 << 21, 1 << 22     # ULL_GEMM_TUNE_*: force one form of the 256x256 kernel (tests / tools)
+
+
 def linear_qkv_rope(x: torch.Tensor, w: torch.Tensor, rope_cos: torch.Tensor, rope_sin: torch.Tensor, rope_cols: int, head_dim: int,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, tune: int = 0) -> torch.Tensor:
     """Fused q|k|v projection + RoPE on the first `rope_cols` output columns (q and k heads), head_dim 128, K % 64 == 0, M > 4.
     Bit-identical to linear() followed by rope_inplace()."""
     _chk(x, "x"); _chk(w, "w", x.dtype); _chk(rope_cos, "rope_cos", x.dtype); _chk(rope_sin, "rope_sin", x.dtype)
@@ -243,10 +246,10 @@ def linear_qkv_rope(x: torch.Tensor, w: torch.Tensor, rope_cos: torch.Tensor, ro
         ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
     if wt is not None:
         _lib.call("ull_gemm_qkv_rope_" + _SFX[x.dtype], _p(x), ldx, _p(wt), K, _p(out), ldc, M, N, K, _p(rope_cos), _p(rope_sin), rope_cols,
-                  head_dim, EPI_W_TILED, ws_ptr, ws_bytes, st)
+                  head_dim, EPI_W_TILED | tune, ws_ptr, ws_bytes, st)
     else:
         _lib.call("ull_gemm_qkv_rope_" + _SFX[x.dtype], _p(x), ldx, _p(w), w.stride(0), _p(out), ldc, M, N, K, _p(rope_cos), _p(rope_sin),
-                  rope_cols, head_dim, 0, ws_ptr, ws_bytes, st)
+                  rope_cols, head_dim, tune, ws_ptr, ws_bytes, st)
     return out
 
 
