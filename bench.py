@@ -117,8 +117,10 @@ def gemm_sources_sha():
     return h.hexdigest()[:16]
 
 
-def gemm_roofline(cfg, tokens, device, iters=5):
-    """Time the four GEMM launches of one LLaMA layer at the benchmark's token count with HIP events on the launch stream."""
+def gemm_roofline(cfg, tokens, device, iters=40, warm=10):
+    """Time the four GEMM launches of one LLaMA layer at the benchmark's token count with HIP events on the launch stream.
+    The chip runs these kernels against its socket power cap (1.4 kW: tools/hot_power.sh), and the clock needs a few launches to settle
+    after the host-side set-up of each shape, so every shape gets `warm` untimed launches and the average is taken over `iters`."""
     ops = importlib.import_module("u-llava_amd.ops")
     D, I = cfg.hidden_size, cfg.intermediate_size
     shapes = [("qkv", 3 * D, D, False), ("o_proj", D, D, False), ("gate_up+swiglu", 2 * I, D, True), ("down", D, I, False)]
@@ -130,7 +132,7 @@ def gemm_roofline(cfg, tokens, device, iters=5):
         w = (torch.randn(N, K, device=device, generator=g) * 0.02).to(torch.bfloat16)
         ops.register_tiled(w)
         out = torch.empty(tokens, N // 2 if sw else N, device=device, dtype=torch.bfloat16)
-        for _ in range(2):
+        for _ in range(warm):
             ops.linear(x, w, swiglu=sw, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -163,7 +165,7 @@ def gemm_roofline(cfg, tokens, device, iters=5):
                 detail = {"record": "profiles/" + fn, "stale": True,
                           "note": f"PMC record was taken on kernel source {tj.get('kernel_source_sha')}, current source is {sha}: not quoted"}
             break
-    return dict(bound="mfma", kernel="big::gemm256_kernel (LLaMA-7B layer: qkv, o, gate/up+SwiGLU, down; 2*M*N*K flop per launch)",
+    return dict(bound="mfma", kernel="big::gemm256w4_kernel (LLaMA-7B layer: qkv, o, gate/up+SwiGLU, down; 2*M*N*K flop per launch)",
                 achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                 traffic=traffic, traffic_detail=detail, per_launch=per)
 

@@ -85,7 +85,9 @@ ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */)
 // the three roundings of apply_rotary_pos_emb on 16-bit tensors (hf modeling_llama.py:129-159), same as rope_inplace_kernel.
 // PHASE: 0 = park + finish (with the block barrier between them when ROPE); 1 = park only, 2 = finish only -- for a wave that owns both
 // halves of a head (the 4-wave kernel) and parks them in two regions before finishing either.
-template <bool SWIGLU, int JT, bool ROPE = false, int PHASE = 0>
+// RAW1 (a region of JT*16 rows x 272 B): the fp32 path parks all rows in one pass, so that it splits into the two phases as well.
+// UNR: unroll of the finish loop -- with one wave per SIMD nothing else hides the LDS / residual latencies of an iteration.
+template <bool SWIGLU, int JT, bool ROPE = false, int PHASE = 0, bool RAW1 = false, int UNR = 2>
 ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg, int lane, int mrow0, int nw0, const char* reg_partner = nullptr) {
     constexpr int ROWS = JT * 16;
     const int fr = lane & 15, fg = lane >> 4;
@@ -200,7 +202,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
         if constexpr (ROPE && PHASE == 0) __builtin_amdgcn_s_barrier();   // ... unless the partner wave's half of the head is read below
         constexpr int LPR = WCOLS / 8;                         // lanes per row (16 B each)
         constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
-#pragma unroll 2
+#pragma unroll UNR
         for (int it = 0; it < ROWS / RPI; ++it) {
             const int row = it * RPI + lane / LPR, c8 = lane % LPR;
             const int m = mrow0 + row, n = ncol0 + c8 * 8;
@@ -223,21 +225,26 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
     } else {
         // fp32 output of the bare accumulator (+bias): two passes of ROWS/2 rows x 64 fp32 columns through the same region
         constexpr int PITCH = 64 * 4 + 16;
-        constexpr int JH = JT / 2;
+        constexpr int NPASS = RAW1 ? 1 : 2;
+        constexpr int JH = JT / NPASS;
+        static_assert(RAW1 || PHASE == 0, "the two-pass fp32 path parks and finishes in one call");
 #pragma clang loop unroll(full)
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NPASS; ++h) {
+            if constexpr (PHASE != 2) {
 #pragma clang loop unroll(full)
-            for (int jj = 0; jj < JH; ++jj) {
+                for (int jj = 0; jj < JH; ++jj) {
 #pragma clang loop unroll(full)
-                for (int i = 0; i < 4; ++i) {
-                    f32x4_t o = acc[i][h * JH + jj];
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4_t o = acc[i][h * JH + jj];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] += bias_v[i][r];
-                    *(f32x4_t*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fg * 4) * 4) = o;
+                        for (int r = 0; r < 4; ++r) o[r] += bias_v[i][r];
+                        *(f32x4_t*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fg * 4) * 4) = o;
+                    }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 2
+            if constexpr (PHASE == 1) return;
+#pragma unroll UNR
             for (int it = 0; it < JH * 2; ++it) {
                 const int row = it * 8 + (lane >> 3), c8 = lane & 7;
                 const int m = mrow0 + h * (JH * 16) + row, n = ncol0 + c8 * 8;
@@ -861,18 +868,24 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
         return;
     }
     __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
-    char* reg0 = smem + wave * (2 * 128 * 144);
+    char* reg0 = smem + wave * (2 * 128 * 144);      // 36 KiB per wave: two bf16 regions, or one fp32 region of 128 rows x 272 B
     char* reg1 = reg0 + 128 * 144;
     const int mrow0 = m0 + wm * 128, nw0 = n0 + wn * 128;
+    // The flag-dependent half of the epilogue (finish) never touches an accumulator, so it is compiled once and run per 64-column half.
     if constexpr (ROPE) {
         // the wave owns whole heads (128 columns): park both halves, then rotate each against the other
-        staged_epilogue<SWIGLU, 8, true, 1>(p, acc[0], reg0, lane, mrow0, nw0);
-        staged_epilogue<SWIGLU, 8, true, 1>(p, acc[1], reg1, lane, mrow0, nw0 + 64);
-        staged_epilogue<SWIGLU, 8, true, 2>(p, acc[0], reg0, lane, mrow0, nw0, reg1);
-        staged_epilogue<SWIGLU, 8, true, 2>(p, acc[1], reg1, lane, mrow0, nw0 + 64, reg0);
+        staged_epilogue<SWIGLU, 8, true, 1, true, 4>(p, acc[0], reg0, lane, mrow0, nw0);
+        staged_epilogue<SWIGLU, 8, true, 1, true, 4>(p, acc[1], reg1, lane, mrow0, nw0 + 64);
+#pragma clang loop unroll(disable)
+        for (int h = 0; h < 2; ++h)
+            staged_epilogue<SWIGLU, 8, true, 2, true, 4>(p, acc[0], h ? reg1 : reg0, lane, mrow0, nw0 + 64 * h, h ? reg0 : reg1);
     } else {
-        staged_epilogue<SWIGLU, 8, false>(p, acc[0], reg0, lane, mrow0, nw0);
-        staged_epilogue<SWIGLU, 8, false>(p, acc[1], reg1, lane, mrow0, nw0 + 64);
+#pragma clang loop unroll(disable)
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0) staged_epilogue<SWIGLU, 8, false, 1, true, 4>(p, acc[0], reg0, lane, mrow0, nw0);
+            else staged_epilogue<SWIGLU, 8, false, 1, true, 4>(p, acc[1], reg0, lane, mrow0, nw0 + 64);
+            staged_epilogue<SWIGLU, 8, false, 2, true, 4>(p, acc[0], reg0, lane, mrow0, nw0 + 64 * h);
+        }
     }
 }
 
@@ -1053,7 +1066,9 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
         // the prologue's latencies), so it takes the long-K, many-round launches -- the LLaMA layer -- and the 8-wave form the ViT /
         // SAM shapes (measured crossover, tools/gemm_bench.py: K = 3072 and 2.5 rounds still favour 8 waves by 1-3 %).  It addresses
         // its DMA pieces with 32-bit offsets from the tile's first row.
-        const bool waves4 = force_waves4 || (!force_waves8 && K >= 4096 && T >= 4 * n_cu && ldx < (1 << 21) && ldw < (1 << 21));
+        // (An output whose rows are not 16-byte aligned -- lm_head, V = 32011 -- is stored element by element: latency again, 8 waves.)
+        const bool c_rows_aligned = (flags & EPI_OUT_F32) ? (ldc & 3) == 0 : (ldc & 7) == 0;
+        const bool waves4 = force_waves4 || (!force_waves8 && K >= 4096 && T >= 4 * n_cu && c_rows_aligned && ldx < (1 << 21) && ldw < (1 << 21));
         if (waves4) {
             if (flags & EPI_SWIGLU)
                 hipLaunchKernelGGL(big::gemm256w4_kernel<true>, dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
