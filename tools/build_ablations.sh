@@ -5,7 +5,8 @@ set -e
 cd "$(dirname "$0")/../u-llava_amd/csrc"
 OTHERS=$(ls *.o | grep -v '^gemm\.o$')
 for abl in "$@"; do
-  DEFS=$(echo $abl | tr '+' '\n' | sed 's/^/-DULL_ABL_/' | tr '\n' ' ')      # A+B = both switches
+  # A+B = both switches; a switch with '=' is a schedule knob: BAR_A=16 -> -DULL_W4_BAR_A=16
+  DEFS=$(echo $abl | tr '+' '\n' | sed -e '/=/s/^/-DULL_W4_/' -e '/^W4_/s/^/-DULL_/' -e '/^-D/!s/^/-DULL_ABL_/' | tr '\n' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $DEFS -c gemm.hip -o /tmp/gemm_$abl.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/probes/lib_$abl.so /tmp/gemm_$abl.o $OTHERS
 done

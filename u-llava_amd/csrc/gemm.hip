@@ -87,8 +87,12 @@ ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */)
 // halves of a head (the 4-wave kernel) and parks them in two regions before finishing either.
 // RAW1 (a region of JT*16 rows x 272 B): the fp32 path parks all rows in one pass, so that it splits into the two phases as well.
 // UNR: unroll of the finish loop -- with one wave per SIMD nothing else hides the LDS / residual latencies of an iteration.
-template <bool SWIGLU, int JT, bool ROPE = false, int PHASE = 0, bool RAW1 = false, int UNR = 2>
-ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg, int lane, int mrow0, int nw0, const char* reg_partner = nullptr) {
+// SW2 (SwiGLU, wave tile 128 accumulator columns wide): the two 64-column halves park their 32 outputs side by side in ONE region
+// (sw_half = 0 / 1 picks the side) and a single finish pass stores 64 outputs = whole 128-byte lines per row; finishing the halves
+// separately wrote every output line in two 64-byte pieces at different times (WRITE_SIZE +30 %).  nw0 = the tile's first column.
+template <bool SWIGLU, int JT, bool ROPE = false, int PHASE = 0, bool RAW1 = false, int UNR = 2, bool SW2 = false>
+ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg, int lane, int mrow0, int nw0, const char* reg_partner = nullptr,
+                             int sw_half = 0) {
     constexpr int ROWS = JT * 16;
     const int fr = lane & 15, fg = lane >> 4;
     const int flags = p.flags;
@@ -165,7 +169,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
         }
 
     if (!raw_f32) {
-        constexpr int WCOLS = SWIGLU ? 32 : 64;            // output columns of this wave
+        constexpr int WCOLS = (SWIGLU && !SW2) ? 32 : 64;  // output columns of the region
         constexpr int PITCH = WCOLS * 2 + 16;              // bytes; +16 keeps 16-byte alignment and spreads banks
         if constexpr (PHASE != 2) {
 #pragma clang loop unroll(full)
@@ -184,7 +188,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                     uint2 o;
                     o.x = pack2e(v[0], v[1]);
                     o.y = pack2e(v[2], v[3]);
-                    *(uint2*)(reg + (j * 16 + fr) * PITCH + (ip * 16 + fg * 4) * 2) = o;
+                    *(uint2*)(reg + (j * 16 + fr) * PITCH + (SW2 ? sw_half * 64 : 0) + (ip * 16 + fg * 4) * 2) = o;
                 }
             } else {
 #pragma clang loop unroll(full)
@@ -794,6 +798,34 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
     //   slots  96..127 read fa <- (kt+1, half 0), one fragment per 2 slots, in first-use order
     // so the memory pipe is never drained (1.0-1.5 steps for a piece to land) and never sees a burst.  The last two steps have nothing
     // to prefetch: they re-fetch the last tile (L2 hits) into a 16-KiB dump behind the epilogue regions instead of branching.
+    // schedule knobs (tools/build_ablations.sh overrides them with -D for sweeps)
+#ifndef ULL_W4_BAR_A
+#define ULL_W4_BAR_A 20
+#endif
+#ifndef ULL_W4_BAR_B
+#define ULL_W4_BAR_B 96
+#endif
+#ifndef ULL_W4_FB_STRIDE
+#define ULL_W4_FB_STRIDE 1
+#endif
+#ifndef ULL_W4_FA_FIRST
+#define ULL_W4_FA_FIRST 96
+#endif
+#ifndef ULL_W4_FA_STRIDE
+#define ULL_W4_FA_STRIDE 2
+#endif
+#ifndef ULL_W4_DMA_FIRST
+#define ULL_W4_DMA_FIRST 20
+#endif
+#ifndef ULL_W4_DMA_STRIDE
+#define ULL_W4_DMA_STRIDE 7
+#endif
+    constexpr int W4_BAR_A = ULL_W4_BAR_A, W4_BAR_B = ULL_W4_BAR_B, W4_FB_STRIDE = ULL_W4_FB_STRIDE, W4_FA_FIRST = ULL_W4_FA_FIRST,
+                  W4_FA_STRIDE = ULL_W4_FA_STRIDE, W4_DMA_FIRST = ULL_W4_DMA_FIRST, W4_DMA_STRIDE = ULL_W4_DMA_STRIDE;
+    constexpr int W4_ISSUED = (W4_BAR_B - W4_DMA_FIRST + W4_DMA_STRIDE - 1) / W4_DMA_STRIDE;   // pieces of tile kt+2 issued before barrier B
+    constexpr int W4_INFLIGHT = W4_ISSUED < 0 ? 0 : W4_ISSUED > 16 ? 16 : W4_ISSUED;
+    static_assert(W4_BAR_A >= 15 * W4_FB_STRIDE + 1 && W4_DMA_FIRST >= W4_BAR_A && W4_FA_FIRST >= W4_BAR_B, "schedule order");
+    static_assert(W4_DMA_FIRST + 15 * W4_DMA_STRIDE < 128 && W4_FA_FIRST + 15 * W4_FA_STRIDE < 128, "schedule fits the step");
     constexpr int USE_ORDER[16] = {0, 8, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15};   // read_one index: w0, x0, w1..w7, x1..x7
     // slot s of a half: accumulator (j = s / 8, h = (s / 4) % 2, i = s % 4)
     auto slot_mma = [&](const Frags4& f, int s) {
@@ -827,28 +859,35 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
         const uint32_t sw = with_dma ? sa + OP_BYTES : dump;
 #pragma clang loop unroll(full)
         for (int s = 0; s < 128; ++s) {
-            if (s == 32) {
+            if (s == W4_BAR_A) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if !defined(ULL_ABL_NOBAR)
                 __builtin_amdgcn_s_barrier();
 #endif
             }
-            if (s == 96) {
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (s == W4_BAR_B) {
+#if defined(ULL_W4_NODUMP)
+                if (!with_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
+#endif
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_INFLIGHT) : "memory");
 #if !defined(ULL_ABL_NOBAR)
                 __builtin_amdgcn_s_barrier();
 #endif
             }
 #if !defined(ULL_ABL_NOREAD)
-            if (s < 16) read_one(kt, 1, fb, s);
-            if (s >= 96 && !(s & 1)) read_one(kt + 1, 0, fa, USE_ORDER[(s - 96) >> 1]);
+            if (s < 16 * W4_FB_STRIDE && s % W4_FB_STRIDE == 0) read_one(kt, 1, fb, s / W4_FB_STRIDE);
+            if (s >= W4_FA_FIRST && (s - W4_FA_FIRST) % W4_FA_STRIDE == 0 && (s - W4_FA_FIRST) / W4_FA_STRIDE < 16)
+                read_one(kt + 1, 0, fa, USE_ORDER[(s - W4_FA_FIRST) / W4_FA_STRIDE]);
 #endif
-            if (s >= 32 && s < 96 && !(s & 3)) {
-                const int pc = (s - 32) >> 2;             // piece: 0..7 of X, 8..15 of W
-                if (pc < 8) slot_mma_dma(fa /* s < 64 */, s, xk, xo[pc], sa + pc * 1024);
-                else slot_mma_dma(fb, s - 64, wk, wo[pc - 8], sw + (pc - 8) * 1024);
-            } else if (s < 64) slot_mma(fa, s);
-            else slot_mma(fb, s - 64);
+            const Frags4& f = s < 64 ? fa : fb;
+            const int pc = (s - W4_DMA_FIRST) / W4_DMA_STRIDE;   // piece: 0..7 of X, 8..15 of W
+            if (s >= W4_DMA_FIRST && (s - W4_DMA_FIRST) % W4_DMA_STRIDE == 0 && pc < 16) {
+#if defined(ULL_W4_NODUMP)
+                if (!with_dma) slot_mma(f, s & 63); else
+#endif
+                if (pc < 8) slot_mma_dma(f, s & 63, xk, xo[pc], sa + pc * 1024);
+                else slot_mma_dma(f, s & 63, wk, wo[pc - 8], sw + (pc - 8) * 1024);
+            } else slot_mma(f, s & 63);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (kt == nk - 1) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
@@ -880,11 +919,17 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
         for (int h = 0; h < 2; ++h)
             staged_epilogue<SWIGLU, 8, true, 2, true, 4>(p, acc[0], h ? reg1 : reg0, lane, mrow0, nw0 + 64 * h, h ? reg0 : reg1);
     } else {
+        if constexpr (SWIGLU) {
+            staged_epilogue<true, 8, false, 1, true, 4, true>(p, acc[0], reg0, lane, mrow0, nw0, nullptr, 0);
+            staged_epilogue<true, 8, false, 1, true, 4, true>(p, acc[1], reg0, lane, mrow0, nw0, nullptr, 1);
+            staged_epilogue<true, 8, false, 2, true, 4, true>(p, acc[0], reg0, lane, mrow0, nw0);
+        } else {
 #pragma clang loop unroll(disable)
-        for (int h = 0; h < 2; ++h) {
-            if (h == 0) staged_epilogue<SWIGLU, 8, false, 1, true, 4>(p, acc[0], reg0, lane, mrow0, nw0);
-            else staged_epilogue<SWIGLU, 8, false, 1, true, 4>(p, acc[1], reg0, lane, mrow0, nw0 + 64);
-            staged_epilogue<SWIGLU, 8, false, 2, true, 4>(p, acc[0], reg0, lane, mrow0, nw0 + 64 * h);
+            for (int h = 0; h < 2; ++h) {
+                if (h == 0) staged_epilogue<false, 8, false, 1, true, 4>(p, acc[0], reg0, lane, mrow0, nw0);
+                else staged_epilogue<false, 8, false, 1, true, 4>(p, acc[1], reg0, lane, mrow0, nw0 + 64);
+                staged_epilogue<false, 8, false, 2, true, 4>(p, acc[0], reg0, lane, mrow0, nw0 + 64 * h);
+            }
         }
     }
 }
