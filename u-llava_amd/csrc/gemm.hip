@@ -1108,12 +1108,13 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
         a.group_m = tune_group_m ? tune_group_m : 4;
         const int grid = a.sk > 1 ? a.t_full + rem * a.sk : T;
         // The 4-wave form has the faster K-loop and the slower tile turn-around (one wave per SIMD: nothing overlaps the epilogue's and
-        // the prologue's latencies), so it takes the long-K, many-round launches -- the LLaMA layer -- and the 8-wave form the ViT /
-        // SAM shapes (measured crossover, tools/gemm_bench.py: K = 3072 and 2.5 rounds still favour 8 waves by 1-3 %).  It addresses
-        // its DMA pieces with 32-bit offsets from the tile's first row.
+        // the prologue's latencies, and the last two steps of every tile re-fetch a K-tile), so it takes the long-K launches -- the
+        // LLaMA layer, SAM's lin2 -- and the 8-wave form the K = 1024 / 1280 shapes of the ViTs (measured crossover, tools/gemm_bench.py:
+        // K = 3072 +4 %, K = 2048 -2 %, K = 1280 -9 %; under two rounds of tiles the two are equal).  It addresses its DMA pieces with
+        // 32-bit offsets from the tile's first row.
         // (An output whose rows are not 16-byte aligned -- lm_head, V = 32011 -- is stored element by element: latency again, 8 waves.)
         const bool c_rows_aligned = (flags & EPI_OUT_F32) ? (ldc & 3) == 0 : (ldc & 7) == 0;
-        const bool waves4 = force_waves4 || (!force_waves8 && K >= 4096 && T >= 4 * n_cu && c_rows_aligned && ldx < (1 << 21) && ldw < (1 << 21));
+        const bool waves4 = force_waves4 || (!force_waves8 && K >= 3072 && T >= 2 * n_cu && c_rows_aligned && ldx < (1 << 21) && ldw < (1 << 21));
         if (waves4) {
             if (flags & EPI_SWIGLU)
                 hipLaunchKernelGGL(big::gemm256w4_kernel<true>, dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
