@@ -482,15 +482,15 @@ __global__ __launch_bounds__(256, 2) void patchify_gemm_kernel(GemmArgs p, Patch
 //   * MFMA fragments are double-buffered in REGISTERS at half-K-step granularity: while the MFMAs of (tile k, half h)
 //     issue, the fragments of the next half are read from LDS.  Tile k therefore lives in registers while tile k+1 is
 //     being read from one LDS slot and tile k+2 is being DMA'd into the other: two slots give a prefetch distance of 2.
-//   * one barrier per BK=64 step; the DMA of tile k+2 is issued right after it and is waited for a full step later.
-//   * the steady-state loop is branch-free (a conditional ds_read block makes hipcc join paths with lgkmcnt(0) in front
-//     of the MFMAs), and sched_group_barrier pins the 1-read : 2-MFMA software pipeline hipcc would otherwise collapse.
+//   * two barriers per BK=64 step and a hand-dealt slot schedule (at the loop): one MFMA per slot, the fragment reads and the DMA
+//     pieces of tile k+2 spread between them so that the memory pipe sees an even stream and is never drained.
 namespace big {
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int OP_BYTES = BM * BK * 2;             // 32 KiB per operand per slot
 constexpr int SLOT_BYTES = 2 * OP_BYTES;          // 64 KiB
 constexpr int LDS_BYTES = 8 * 128 * (64 * 2 + 16);   // 144 KiB: two 64-KiB K-tile slots, re-used by the 8 x 18-KiB epilogue regions
+constexpr int LDS_BYTES_W4 = LDS_BYTES + 16 * 1024;   // + the dump of the last two steps' prefetches: all 160 KiB of the CU
 
 struct Frags { uint4 w[4]; uint4 x[8]; };
 
@@ -569,28 +569,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](const Frags& f) {
-#if !defined(ULL_ABL_NOMMA)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(f.w[i], f.x[j], acc[i][j]);
-#else
-        for (int i_ = 0; i_ < 4; ++i_) asm volatile("" :: "v"(f.w[i_].x), "v"(f.w[i_].w));
-        for (int j_ = 0; j_ < 8; ++j_) asm volatile("" :: "v"(f.x[j_].x), "v"(f.x[j_].w));
-#endif
-    };
-    // the 12 fragment reads of the NEXT half step are issued up front, one per two MFMAs of the current half (left alone,
-    // hipcc sinks them behind ~22 MFMAs to save registers and then stalls on them)
-    auto pipeline_hint = [&]() {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    };
-
     int nk = p.K / BK;                                // >= 2 (host dispatch, also per K-slice)
     if (split) {
         const int kt0 = (int)((long)nk * slice / p.sk), kt1 = (int)((long)nk * (slice + 1) / p.sk);
@@ -598,37 +576,77 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         for (int i = 0; i < 4; ++i) { xsrc[i] += (long)kt0 * xstep; wsrc[i] += (long)kt0 * wstep; }
         nk = kt1 - kt0;
     }
+    // Same step schedule as the 4-wave kernel (see there), 64 MFMA slots per wave and step: the 12 fragment reads of the tile's second
+    // half first, barrier A, the 8 DMA pieces of tile kt+2 dealt out one per 6 slots (a burst of all 64 pieces of a CU right behind
+    // the barrier measured 3-7 % slower end to end: the memory pipe wants an even stream), barrier B with the newest pieces still in
+    // flight, then the first-half fragments of tile kt+1.  The last two steps re-fetch the last tile into a 16-KiB dump.
+#ifndef ULL_W8_BAR_A
+#define ULL_W8_BAR_A 14
+#endif
+#ifndef ULL_W8_DMA_STRIDE
+#define ULL_W8_DMA_STRIDE 6
+#endif
+#ifndef ULL_W8_BAR_B
+#define ULL_W8_BAR_B 40
+#endif
+#ifndef ULL_W8_FA_STRIDE
+#define ULL_W8_FA_STRIDE 2
+#endif
+    constexpr int W8_BAR_A = ULL_W8_BAR_A, W8_DMA_STRIDE = ULL_W8_DMA_STRIDE, W8_BAR_B = ULL_W8_BAR_B, W8_FA_STRIDE = ULL_W8_FA_STRIDE;
+    constexpr int W8_ISSUED = (W8_BAR_B - W8_BAR_A + W8_DMA_STRIDE - 1) / W8_DMA_STRIDE;
+    constexpr int W8_INFLIGHT = W8_ISSUED > 8 ? 8 : W8_ISSUED;
+    static_assert(W8_BAR_A >= 12 && W8_BAR_B >= W8_BAR_A && W8_BAR_A + 7 * W8_DMA_STRIDE < 64 && W8_BAR_B + 11 * W8_FA_STRIDE < 64, "schedule");
+    constexpr int USE_ORDER[12] = {0, 4, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11};    // w0, x0, w1..w3, x1..x7
+    auto read1 = [&](int kt, int kk, Frags& f, int r) {
+        const char* base = smem + (kt & 1) * SLOT_BYTES + swz[kk];
+        if (r < 4) f.w[r] = *(const uint4*)(base + woff + r * 16 * (BK * 2));
+        else f.x[r - 4] = *(const uint4*)(base + xoff + (r - 4) * 16 * (BK * 2));
+    };
+    auto mma1 = [&](const Frags& f, int s) {
+        const int j = s >> 2, i = s & 3;
+#if !defined(ULL_ABL_NOMMA)
+        acc[i][j] = mfma16(f.w[i], f.x[j], acc[i][j]);
+#endif
+    };
     stage(0);
     stage(1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed, tile 1 in flight
     __builtin_amdgcn_s_barrier();
     Frags fa, fb;                                     // fa: half 0 of the current tile, fb: half 1
     read_frags(0, 0, fa);
-    for (int kt = 0; kt < nk - 2; ++kt) {
-        read_frags(kt, 1, fb);
-        mma(fa);
-        pipeline_hint();
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed (issued a full step ago); my reads of tile kt done
-        __builtin_amdgcn_s_barrier();                 // tile kt+1 visible to all; slot of tile kt free
+    const uint32_t dump = lds_base + LDS_BYTES;
+#pragma clang loop unroll(disable)
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool with_dma = kt + 2 < nk;
+        const int ktd = with_dma ? kt + 2 : nk - 1;
+        const long kox = (long)ktd * xstep, kow = (long)ktd * wstep;
+        const uint32_t bx = with_dma ? lds_base + (kt & 1) * SLOT_BYTES + piece_off : dump;
+        const uint32_t bw = with_dma ? bx + OP_BYTES : dump + 4096;
+#pragma clang loop unroll(full)
+        for (int s = 0; s < 64; ++s) {
+            if (s == W8_BAR_A) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (s == W8_BAR_B) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W8_INFLIGHT) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (s < 12) read1(kt, 1, fb, s);
+            if (s >= W8_BAR_B && (s - W8_BAR_B) % W8_FA_STRIDE == 0 && (s - W8_BAR_B) / W8_FA_STRIDE < 12)
+                read1(kt + 1, 0, fa, USE_ORDER[(s - W8_BAR_B) / W8_FA_STRIDE]);
 #if !defined(ULL_ABL_NODMA)
-        stage(kt + 2);
+            if (s >= W8_BAR_A && (s - W8_BAR_A) % W8_DMA_STRIDE == 0 && (s - W8_BAR_A) / W8_DMA_STRIDE < 8) {
+                const int pc = (s - W8_BAR_A) / W8_DMA_STRIDE;
+                if (pc < 4) glds16(xsrc[pc] + kox, bx + pc * 1024);
+                else glds16(wsrc[pc - 4] + kow, bw + (pc - 4) * 1024);
+            }
 #endif
-        read_frags(kt + 1, 0, fa);
-        mma(fb);
-        pipeline_hint();
+            mma1(s < 32 ? fa : fb, s & 31);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    {   // kt = nk - 2: nothing left to prefetch
-        const int kt = nk - 2;
-        read_frags(kt, 1, fb);
-        mma(fa);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        read_frags(kt + 1, 0, fa);
-        mma(fb);
-        read_frags(kt + 1, 1, fb);
-        mma(fa);
-        mma(fb);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the dump's pieces: nothing may be in flight at exit)
 
     // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
     if (split) {
@@ -655,7 +673,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 // sched_barrier between chunks (schedule: at the loop).
 // DMA addressing: scalar base (advanced per K-step) + one 32-bit VGPR offset per piece.
 struct Frags4 { uint4 w[8]; uint4 x[8]; };
-constexpr int LDS_BYTES_W4 = LDS_BYTES + 16 * 1024;   // + the dump of the last two steps' prefetches: all 160 KiB of the CU
 
 // The accumulators are pinned to the AGPR half of the register file and accumulated in place through inline asm: with the builtin,
 // hipcc's allocator splits the 64 accumulators between VGPRs and AGPRs under the 512-register pressure and shuffles them with
@@ -1036,9 +1053,9 @@ static int gemm_device_state(int* n_cu_out) {
     if (!n_cu[dev]) {
         hipDeviceProp_t prop;
         const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
+        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
+        (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
@@ -1123,11 +1140,11 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
             else
                 hipLaunchKernelGGL(big::gemm256w4_kernel<false>, dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
         } else if (flags & EPI_SWIGLU)
-            hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(big::gemm256_kernel<true>, dim3(grid), dim3(512), big::LDS_BYTES_W4, (hipStream_t)stream, a);
         else if (rope)
-            hipLaunchKernelGGL((big::gemm256_kernel<false, true>), dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+            hipLaunchKernelGGL((big::gemm256_kernel<false, true>), dim3(grid), dim3(512), big::LDS_BYTES_W4, (hipStream_t)stream, a);
         else
-            hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES_W4, (hipStream_t)stream, a);
         if (a.sk > 1) hipLaunchKernelGGL(big::splitk_finalize_kernel, dim3(32, rem), dim3(256), 0, (hipStream_t)stream, a);
         return ull_check_launch();
     }
