@@ -72,6 +72,78 @@ ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
+// Same with a scalar base and a 32-bit per-lane byte offset (saddr form).
+ULL_DEV void glds16s(const void* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_byte_addr /* wave-uniform */) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
+// Flag-dependent tail of every epilogue: finish 8 consecutive outputs of row m starting at column n (late bias, activation, residual,
+// store).  The values arrive as the rounded Linear output (or the bare fp32 accumulator on the raw_f32 path).
+struct EpiCtx {
+    const GemmArgs& p;
+    int act, n_out;
+    bool out_f32, has_res, bias_late, c_al, r_al;
+};
+ULL_DEV EpiCtx epi_ctx(const GemmArgs& p, bool swiglu) {
+    const int flags = p.flags;
+    const bool out_f32 = flags & EPI_OUT_F32;
+    return EpiCtx{p, (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT, swiglu ? p.N / 2 : p.N, out_f32, (flags & EPI_RESID) != 0,
+                  !swiglu && (flags & EPI_BIAS) && (flags & EPI_BIAS_ROUNDED), out_f32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0, (p.ldr & 7) == 0};
+}
+ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n) {
+        if (c.bias_late) {
+#pragma unroll 1
+            for (int e = 0; e < 8; ++e)
+                if (n + e < c.n_out) a[e] = rnd(a[e] + e2f(c.p.bias[n + e]));
+        }
+        if (c.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_e(a[e]);
+        } else if (c.act == 2) {
+#pragma unroll 1
+            for (int e = 0; e < 8; ++e) a[e] = rnd(act_gelu_erf(a[e]));
+        } else if (c.act == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.f);
+        }
+        const bool full = n + 8 <= c.n_out;
+        if (c.has_res) {
+            const elem_t* rp = c.p.R + (long)m * c.p.ldr + n;
+            if (full && c.r_al) {
+                float b[8];
+                unpack8(*(const uint4*)rp, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < c.n_out) a[e] = rnd(e2f(rp[e]) + a[e]);
+            }
+        }
+        if (c.out_f32) {
+            float* cp = (float*)c.p.C + (long)m * c.p.ldc + n;
+            if (full && c.c_al) {
+                *(float4*)cp = make_float4(a[0], a[1], a[2], a[3]);
+                *(float4*)(cp + 4) = make_float4(a[4], a[5], a[6], a[7]);
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < c.n_out) cp[e] = a[e];
+            }
+        } else {
+            elem_t* cp = (elem_t*)c.p.C + (long)m * c.p.ldc + n;
+            if (full && c.c_al) {
+                *(uint4*)cp = pack8(a);
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < c.n_out) cp[e] = f2e(a[e]);
+            }
+        }
+    }
+
 // ---- LDS-staged epilogue shared by both kernels ------------------------------------------------------------------------
 // A wave owns JT*16 rows (m) x 64 W-rows (n): acc[i][j][r] = D[n = nw0 + i*16 + 4*(lane>>4) + r][m = mrow0 + j*16 + (lane&15)].
 // Two things were measured on the earlier register-direct form (profiles/r01_gemm_notes.md): scattered 16-row x 32-B stores,
@@ -101,64 +173,14 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
     const bool has_res = flags & EPI_RESID;
     const int n_out = SWIGLU ? p.N / 2 : p.N;
     const bool bias_late = !SWIGLU && (flags & EPI_BIAS) && (flags & EPI_BIAS_ROUNDED);   // added in finish8, after the first rounding
-    const bool raw_f32 = !SWIGLU && out_f32 && !act && !has_res && !bias_late;   // fp32 result of the accumulator, never rounded
+    // fp32 result of the accumulator, never rounded.  (A caller that splits into phases without RAW1 routes this case to PHASE 0 itself.)
+    const bool raw_f32 = (PHASE == 0 || RAW1) && !SWIGLU && out_f32 && !act && !has_res && !bias_late;
     const bool c_al = out_f32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0;   // 16-byte row alignment of C / R
     const bool r_al = (p.ldr & 7) == 0;
     const int ncol0 = SWIGLU ? nw0 / 2 : nw0;
 
-    // finish 8 consecutive outputs of row m starting at column n: activation, residual, store
-    auto finish8 = [&](float (&a)[8], int m, int n) {
-        if (bias_late) {
-#pragma unroll 1
-            for (int e = 0; e < 8; ++e)
-                if (n + e < n_out) a[e] = rnd(a[e] + e2f(p.bias[n + e]));
-        }
-        if (act == 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_e(a[e]);
-        } else if (act == 2) {
-#pragma unroll 1
-            for (int e = 0; e < 8; ++e) a[e] = rnd(act_gelu_erf(a[e]));
-        } else if (act == 3) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.f);
-        }
-        const bool full = n + 8 <= n_out;
-        if (has_res) {
-            const elem_t* rp = p.R + (long)m * p.ldr + n;
-            if (full && r_al) {
-                float b[8];
-                unpack8(*(const uint4*)rp, b);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
-            } else {
-#pragma unroll 1
-                for (int e = 0; e < 8; ++e)
-                    if (n + e < n_out) a[e] = rnd(e2f(rp[e]) + a[e]);
-            }
-        }
-        if (out_f32) {
-            float* cp = (float*)p.C + (long)m * p.ldc + n;
-            if (full && c_al) {
-                *(float4*)cp = make_float4(a[0], a[1], a[2], a[3]);
-                *(float4*)(cp + 4) = make_float4(a[4], a[5], a[6], a[7]);
-            } else {
-#pragma unroll 1
-                for (int e = 0; e < 8; ++e)
-                    if (n + e < n_out) cp[e] = a[e];
-            }
-        } else {
-            elem_t* cp = (elem_t*)p.C + (long)m * p.ldc + n;
-            if (full && c_al) {
-                *(uint4*)cp = pack8(a);
-            } else {
-#pragma unroll 1
-                for (int e = 0; e < 8; ++e)
-                    if (n + e < n_out) cp[e] = f2e(a[e]);
-            }
-        }
-    };
-
+    const EpiCtx ectx = epi_ctx(p, SWIGLU);
+    auto finish8 = [&](float (&a)[8], int m, int n) { big_finish8(ectx, a, m, n); };
     float bias_v[4][4];                                    // -0.0f: x + (-0.0f) == x bit-for-bit when there is no bias
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -226,7 +248,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
             }
             finish8(a, m, n);
         }
-    } else {
+    } else if constexpr (PHASE == 0 || RAW1) {
         // fp32 output of the bare accumulator (+bias): two passes of ROWS/2 rows x 64 fp32 columns through the same region
         constexpr int PITCH = 64 * 4 + 16;
         constexpr int NPASS = RAW1 ? 1 : 2;
@@ -662,6 +684,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     staged_epilogue<SWIGLU, 8, ROPE>(p, acc, smem + wave * (128 * 144), lane, m0 + wm * 128, n0 + wn * 64, smem + (wave ^ 1) * (128 * 144));
 }
 
+// (A persistent form of this kernel -- one workgroup per CU walking its tiles, K-tile 0 of the next tile prefetched by step nk-2, the
+// epilogue staged through the slot the last step frees, K-tile 1 issued behind it -- was built and measured twice, rounds 1 and 2:
+// bit-identical results, 5-8 % SLOWER on every shape from K = 1024 to K = 11008.  The hardware's block hand-over plus a cold
+// prologue costs less than an in-kernel tile turn-around with its extra barrier and branchy DMA slots; profiles/r02_gemm_notes.md.)
+
 // ---- 4-wave form of the same tile ---------------------------------------------------------------------------------------------
 // Same 256x256x64 block tile, LDS layout, raster and stream-K tail, but 256 threads = 4 waves (2 x 2), 128(m) x 128(n) per wave:
 // 64 accumulators (256 registers; one wave per SIMD owns the SIMD's whole 512-entry register file) and 16 fragment reads per 64 MFMAs
@@ -693,11 +720,6 @@ ULL_DEV void mfma16_inplace(f32x4_t& c, const uint4& a, const uint4& b) {
 #endif
 }
 
-ULL_DEV void glds16s(const void* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_byte_addr /* wave-uniform */) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-}
 
 template <bool SWIGLU, bool ROPE = false>
 __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
