@@ -92,7 +92,7 @@ ULL_DEV EpiCtx epi_ctx(const GemmArgs& p, bool swiglu) {
     return EpiCtx{p, (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT, swiglu ? p.N / 2 : p.N, out_f32, (flags & EPI_RESID) != 0,
                   !swiglu && (flags & EPI_BIAS) && (flags & EPI_BIAS_ROUNDED), out_f32 ? (p.ldc & 3) == 0 : (p.ldc & 7) == 0, (p.ldr & 7) == 0};
 }
-ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n) {
+ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_pre = false, uint4 res_pre = uint4{0, 0, 0, 0}) {
         if (c.bias_late) {
 #pragma unroll 1
             for (int e = 0; e < 8; ++e)
@@ -113,7 +113,7 @@ ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n) {
             const elem_t* rp = c.p.R + (long)m * c.p.ldr + n;
             if (full && c.r_al) {
                 float b[8];
-                unpack8(*(const uint4*)rp, b);
+                unpack8(has_pre ? res_pre : *(const uint4*)rp, b);       // res_pre: the caller fetched these 16 bytes ahead of time
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
             } else {
@@ -228,25 +228,49 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
         if constexpr (ROPE && PHASE == 0) __builtin_amdgcn_s_barrier();   // ... unless the partner wave's half of the head is read below
         constexpr int LPR = WCOLS / 8;                         // lanes per row (16 B each)
         constexpr int RPI = 64 / LPR;                          // rows per wave-instruction
-#pragma unroll UNR
-        for (int it = 0; it < ROWS / RPI; ++it) {
-            const int row = it * RPI + lane / LPR, c8 = lane % LPR;
-            const int m = mrow0 + row, n = ncol0 + c8 * 8;
-            if (m >= p.M || n >= n_out) continue;
-            float a[8];
-            unpack8(*(const uint4*)(reg + row * PITCH + c8 * 16), a);
-            if constexpr (ROPE) {
-                if (n < p.rope_cols) {
-                    float b[8], cs[8], sn[8];
-                    unpack8(*(const uint4*)(reg_partner + row * PITCH + c8 * 16), b);
-                    unpack8(*(const uint4*)(p.rope_cos + (long)m * 64 + c8 * 8), cs);
-                    unpack8(*(const uint4*)(p.rope_sin + (long)m * 64 + c8 * 8), sn);
-                    const bool first_half = (n & 64) == 0;         // dims 0..63 of the head: rotate_half contributes -x[d + 64]
+        // UNR iterations at a time: first every load of the group (LDS rows, RoPE table rows, residual rows -- from clamped, always
+        // valid addresses, so nothing branches), then the arithmetic and the stores.  With one wave per SIMD an iteration that loads,
+        // waits, computes and stores exposes every latency in turn (the RoPE epilogue cost 116 us per qkv launch that way).
+        constexpr int NIT = ROWS / RPI;
+        static_assert(NIT % UNR == 0, "finish loop groups");
+        const int c8 = lane % LPR;
+        const int n = ncol0 + c8 * 8;
+        const bool rope_on = ROPE && n < p.rope_cols;
+        const bool res_pre = has_res && r_al && n + 8 <= n_out;
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += UNR) {
+            uint4 va[UNR], vb[UNR], vc[UNR], vs[UNR], vr[UNR];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] = rnd(a[e] * cs[e]) + rnd((first_half ? -b[e] : b[e]) * sn[e]);
+            for (int u = 0; u < UNR; ++u) {
+                const int row = (it0 + u) * RPI + lane / LPR;
+                const long mc = min(mrow0 + row, p.M - 1);
+                va[u] = *(const uint4*)(reg + row * PITCH + c8 * 16);
+                if constexpr (ROPE) {
+                    vb[u] = *(const uint4*)(reg_partner + row * PITCH + c8 * 16);
+                    vc[u] = *(const uint4*)(p.rope_cos + mc * 64 + c8 * 8);     // always a valid address (64 columns, clamped row): the
+                    vs[u] = *(const uint4*)(p.rope_sin + mc * 64 + c8 * 8);     // v columns load and ignore them rather than branch
                 }
+                if (res_pre) vr[u] = *(const uint4*)(p.R + mc * p.ldr + n);
             }
-            finish8(a, m, n);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int m = mrow0 + (it0 + u) * RPI + lane / LPR;
+                if (m >= p.M || n >= n_out) continue;
+                float a[8];
+                unpack8(va[u], a);
+                if constexpr (ROPE) {
+                    if (rope_on) {
+                        float b[8], cs[8], sn[8];
+                        unpack8(vb[u], b);
+                        unpack8(vc[u], cs);
+                        unpack8(vs[u], sn);
+                        const bool first_half = (n & 64) == 0;         // dims 0..63 of the head: rotate_half contributes -x[d + 64]
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = rnd(a[e] * cs[e]) + rnd((first_half ? -b[e] : b[e]) * sn[e]);
+                    }
+                }
+                big_finish8(ectx, a, m, n, res_pre, vr[u]);
+            }
         }
     } else if constexpr (PHASE == 0 || RAW1) {
         // fp32 output of the bare accumulator (+bias): two passes of ROWS/2 rows x 64 fp32 columns through the same region
