@@ -515,3 +515,32 @@ def test_fused_decoder_kernels_match_the_op_by_op_chain(dt):
     f4 = float((k1.view(4096, 256) != ref4).float().mean())
     print(f"{dt} block 0, fraction of elements differing from the op-by-op chain: t2i {f2:.4f}, mlp {f3:.4f}, i2t {f4:.5f}")
     assert f2 <= 0.02 * flip and f3 <= 0.02 * flip and f4 <= 0.002 * flip
+
+
+def test_evaluate_with_four_sam_images_matches_one_by_one():
+    """evaluate() on a batch of 4 (different original sizes; the SAM encoder runs on its own stream beside the LLM, the mask decoder of
+    all prompts as one chain of launches) returns, row by row, what four single-image calls return: ids identical, masks / boxes equal."""
+    fx = load_fixture("g11_evaluate_bf16.pt")
+    model, sd = _full_model(fx)
+    g = torch.Generator().manual_seed(77)
+    images_sam = torch.randn(4, 3, 1024, 1024, generator=g).to(BF).to(DEV)
+    images = torch.cat([fx["images"]] * 4).to(DEV)
+    images = (images.float() * torch.tensor([1.0, 0.9, 1.1, 0.8], device=DEV).view(4, 1, 1, 1)).to(BF)
+    ids = torch.cat([fx["input_ids"]] * 4).to(DEV)
+    sizes = [fx["size"], (37, 53), (64, 48), (50, 50)]
+    resizes = [fx["resize"], (712, 1024), (1024, 768), (1024, 1024)]
+    for use_cache in (False, True):
+        model.llm.config.use_cache = use_cache
+        seq4, masks4, boxes4 = model.evaluate(images_sam, images, ids, sizes, resizes, max_new_tokens=6, temperature=0)
+        assert len(masks4) == 4 and seq4.shape[0] == 4
+        for b in range(4):
+            seq1, masks1, boxes1 = model.evaluate(images_sam[b:b + 1], images[b:b + 1], ids[b:b + 1], [sizes[b]], [resizes[b]],
+                                                  max_new_tokens=6, temperature=0)
+            n = seq1.shape[1]
+            assert torch.equal(seq4[b, :n], seq1[0]), (b, seq4[b].tolist(), seq1[0].tolist())
+            assert tuple(masks4[b].shape) == tuple(masks1[0].shape) and tuple(masks4[b].shape[1:]) == tuple(sizes[b])
+            if masks1[0].numel():
+                scale = float(masks1[0].abs().max()) + 1e-6
+                assert float((masks4[b] - masks1[0]).abs().max()) <= 2e-2 * scale, (b, float((masks4[b] - masks1[0]).abs().max()), scale)
+            if boxes1[0].numel():
+                assert float((boxes4[b].float() - boxes1[0].float()).abs().max()) <= 2e-2
