@@ -542,3 +542,28 @@ def test_gemm_256_tile_on_4_and_8_waves_agree(kind, dt):
         elif kind == "f32":
             ref = x.float() @ w.float().t()
             assert float((outs[0] - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gelu_erf_over_every_16_bit_input(dt):
+    """The activation sees 16-bit inputs only, so it is checked on ALL of them against torch's CPU kernel of the same dtype: results may
+    differ only where the reference's own 1 + erf(x / sqrt 2) has cancelled (x < -3, |GELU| < 3e-3), and only in a few dozen inputs."""
+    ops = pkg("ops")
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(dt)
+    keep = torch.isfinite(x.float()) & (x.float().abs() > 1e-4 if dt == torch.float16 else x.float().abs() > 1e-30) & (x.float().abs() < 1e30)
+    x = x[keep].contiguous()
+    ref = torch.nn.functional.gelu(x)
+    got = ops.gelu_fwd(x.to(DEV)).cpu()
+    bad = got != ref
+    nbad = int(bad.sum())
+    print(f"GELU(erf) {dt}: {nbad} of {x.numel()} inputs differ from torch CPU")
+    assert nbad <= (64 if dt == torch.bfloat16 else 400), nbad
+    if nbad and dt == torch.bfloat16:
+        assert float(x[bad].float().max()) < -2.5 and float(ref[bad].float().abs().max()) < 4e-3
+        assert float((got[bad].float() - ref[bad].float()).abs().max()) < 4e-5
+    elif nbad:
+        # fp16 keeps 11 bits: a 1e-7 relative difference flips a rounding now and then anywhere -- by one unit in the last place
+        ulp = torch.maximum(ref[bad].float().abs(), torch.tensor(6.2e-5)) * 2.0 ** -10
+        tail = x[bad].float() < -2.5
+        assert bool(((got[bad].float() - ref[bad].float()).abs() <= torch.where(tail, torch.tensor(4e-5), ulp * 1.01)).all())

@@ -18,7 +18,7 @@ def t(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 b = torch.randn(N, device=dev, generator=g).to(BF); r = torch.randn(M, N, device=dev, generator=g).to(BF)
 out = torch.empty(M, N, device=dev, dtype=BF)
-for K in (128, 256, 512, 1024, 2048):
+for K in (128, 1024):
     x = torch.randn(M, K, device=dev, generator=g).to(BF)
     w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(BF)
     ops.register_tiled(w)
@@ -27,4 +27,7 @@ for K in (128, 256, 512, 1024, 2048):
         a1 = t(lambda: ops.linear(x, w, b, out=out, tune=TUNE))
         a2 = t(lambda: ops.linear(x, w, b, act="gelu", out=out, tune=TUNE))
         a3 = t(lambda: ops.linear(x, w, b, residual=r, out=out, tune=TUNE))
-    print(f"K={K:5d} ({K // 64:2d} steps)  per round: plain {a0 / 4:6.2f} us  bias {a1 / 4:6.2f}  bias+gelu {a2 / 4:6.2f}  bias+resid {a3 / 4:6.2f}")
+        a4 = t(lambda: ops.linear(x, w, b, act="quick_gelu", out=out, tune=TUNE))
+        a5 = t(lambda: ops.linear(x, w, swiglu=True, out=out[:, :N // 2], tune=TUNE))
+    print(f"K={K:5d} ({K // 64:2d} steps)  per round: plain {a0 / 4:6.2f} us  bias {a1 / 4:6.2f}  bias+gelu {a2 / 4:6.2f}  bias+resid {a3 / 4:6.2f}"
+          f"  bias+quick_gelu {a4 / 4:6.2f}  swiglu {a5 / 4:6.2f}")
