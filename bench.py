@@ -37,6 +37,8 @@ WORKLOADS = {
     # full RES path: + SAM ViT-H encoder on 1024x1024, 3 [SEG]+[LOC] rounds per sample, prompt-encoder + mask decoder + postprocess
     "res": (224, 120, 8, "C3: full RES forward (ViT-L/14-224 + LLaMA-7B + SAM ViT-H 1024x1024 + MaskDecoder, 3 [SEG]/[LOC] per image), batch 8"),
     "c5": (224, 32, 8, "C5: video forward, 8-frame 224x224 clips (per-frame ViT-L, 8+256 pooled tokens) + 32-token prompt (S=299), 8 clips/GPU"),
+    # forward with labels + loss.backward() + gradient exchange, the reference's stage-2 trainable set (train_ullava.py:229-261)
+    "train": (224, 64, 8, "F4: training step, ViT-L/14-224 + LLaMA-7B (S=323), trainable lm_head + embed_tokens + projector + q/v projections, batch 8/GPU"),
 }
 PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 SEG, LOC = 32007, 32008
@@ -287,6 +289,26 @@ def workload_step(name, dev, rank, batch_override=None):
         def step():
             return model.forward(images_sam=images_sam, images=vis, input_ids=ids, labels=None, attention_mask=mask,
                                  mask_list=[None] * batch, size_list=sizes, resize_list=resizes, bbox_list=[None] * batch, inference=True)
+    elif name == "train":
+        Dm = importlib.import_module("u-llava_amd.dist")
+        labels = ids.clone()
+        labels[:, :P + 3] = -100
+        trainable = []
+        for n, p_ in model.named_parameters():
+            p_.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or n.startswith("vision_projector") or
+                                (n.startswith("model.") and (".q_proj." in n or ".v_proj." in n)))
+            if p_.requires_grad:
+                trainable.append(p_)
+        flops_img *= 3                                           # forward + ~2x backward (dW only for the trainable set: an upper bound)
+
+        def step():
+            for p_ in trainable:
+                p_.grad = None
+            out = model.forward(input_ids=ids, attention_mask=mask, images=vis, labels=labels)
+            out.loss.backward()
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                Dm.allreduce_gradients(trainable)
+            return out.loss
     elif video:
         def step():
             return model.forward(input_ids=ids, attention_mask=mask, videos=vis)
@@ -362,13 +384,13 @@ def main():
             dist.destroy_process_group()
         return
 
-    with torch.no_grad():
+    with (torch.enable_grad() if a.workload == "train" else torch.no_grad()):
         step, batch, S, cfg, desc, flops_img, model = workload_step(a.workload, dev, rank, a.batch)
         value, total_images, elapsed = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
         image_size, prompt = WORKLOADS[a.workload][:2]
         res_rec = None
         roof = None
-        if rank == 0 and not a.no_roofline:
+        if rank == 0 and not a.no_roofline and a.workload != "train":
             roof = gemm_roofline(cfg, batch * S, dev)
         if a.workload == "c4" and not a.no_res:
             # second half of BASELINE.json's metric: the full RES forward (C3), same timing protocol, same process

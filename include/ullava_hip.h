@@ -296,6 +296,13 @@ int ull_attention_bwd_bf16(const void* Q, const void* K, const void* V, const vo
                            const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal,
                            float mult, void* scratch, void* stream);
 
+/* The same backward on the matrix cores, for hd = 64 / 128 (the LLaMA block): same arguments plus Qt, Kt, dOt = the
+ * ull_transpose_v_bf16 images [B, H, hd, pitch] of Q, K and dO (pitch >= ceil64(max(Sq, Sk))); every stride a multiple of 4
+ * elements, token strides of 8.  scratch: float32 [2 * B * H * ceil64(Sq)].  No atomics, same fp32 softmax recomputation. */
+int ull_attention_bwd_mfma_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* Qt, const void* Kt,
+                                const void* dOt, int64_t pitch, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask,
+                                int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
+
 /* Backward of ull_shifted_cross_entropy_bf16: dlogits [B, S, V] (same ld); stats = the forward's float[2]; gout = upstream gradient
  * of the mean loss (one float32 on the device). */
 int ull_shifted_cross_entropy_bwd_bf16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, const void* stats,
@@ -330,6 +337,10 @@ int ull_sum_slabs_bf16(const void* x, void* out, int64_t R, int64_t n, float sca
 
 /* out float32 [N] = column sums of x [rows, N] (bias gradients). */
 int ull_colsum_bf16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
+
+/* y[c][r] = x[r][c] (x [R, C] with row stride ldx, y [C, R] with row stride ldy): the transposed operands of the Linear backward
+ * (torch.autograd of nn.Linear: dX = dY W, dW = dY^T X), which run through the NT GEMM of ull_gemm_bf16. */
+int ull_transpose2d_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t R, int64_t C, void* stream);
 
 /* Backward of ull_mask_loss_sums_f32 (g float32 [n_masks, 4] -> dlogits float32 [n_masks, hw]), of ull_box_losses_f32 (gw float32[2] ->
  * dpred float32 [n, 4]) and the adjoint of ull_bilinear_f32 (din float32, zeroed by the caller; atomics). */
@@ -379,6 +390,7 @@ int ull_swiglu_fwd_f16(const void* gu, void* a, int64_t M, int64_t I, void* stre
 int ull_swiglu_bwd_f16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream);
 int ull_rope_bwd_inplace_f16(void* dx, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads, int64_t hd, void* stream);
 int ull_attention_bwd_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
+int ull_attention_bwd_mfma_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* Qt, const void* Kt, const void* dOt, int64_t pitch, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
 int ull_shifted_cross_entropy_bwd_f16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, const void* stats, const void* gout, void* dlogits, void* stream);
 int ull_embed_splice_bwd_f16(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
 int ull_layernorm_bwd_f16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, void* db, int64_t rows, int64_t D, float eps, void* stream);
@@ -388,6 +400,7 @@ int ull_gelu_bwd_f16(const void* x, const void* dy, void* dx, int64_t n, void* s
 int ull_mask_matmul_bwd_f16(const void* hyper, const void* up, const void* dmasks, void* dhyper, void* dup, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
 int ull_sum_slabs_f16(const void* x, void* out, int64_t R, int64_t n, float scale, void* stream);
 int ull_colsum_f16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
+int ull_transpose2d_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t R, int64_t C, void* stream);
 /* ==== END fp16 twins ==== */
 
 #ifdef __cplusplus

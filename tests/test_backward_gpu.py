@@ -82,7 +82,8 @@ def test_rmsnorm_swiglu_rope_backward():
     assert rel_l2(qd.grad, qs.grad) < 6e-3
 
 
-@pytest.mark.parametrize("B,H,S,hd,masked", [(2, 2, 37, 16, False), (2, 4, 130, 32, True), (1, 2, 70, 128, True)])
+@pytest.mark.parametrize("B,H,S,hd,masked", [(2, 2, 37, 16, False), (2, 4, 130, 32, True), (1, 2, 70, 128, True), (2, 3, 150, 128, True),
+                                             (1, 2, 643, 128, False), (2, 2, 100, 64, True), (1, 1, 64, 128, False), (1, 2, 129, 64, False)])
 def test_causal_self_attention_backward(B, H, S, hd, masked):
     """dQ / dK / dV of the causal, key-masked LLaMA attention vs autograd of the eager recipe (fp32)."""
     A = pkg("autograd_ops")
@@ -294,3 +295,17 @@ def test_full_training_path_matches_reference_gradients_g13():
             worst = (n, e_hip)
         assert e_hip <= max(3.0 * e_ref, 0.03), (n, e_hip, e_ref)
     print("worst sampled gradient:", worst)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("R,C,pad", [(64, 64, 0), (300, 129, 0), (2584, 4096, 0), (1, 77, 0), (515, 1000, 24), (128, 8, 8)])
+def test_transpose2d_is_exact(R, C, pad, dt):
+    """The operand transposes of the Linear backward: bit-exact data movement, ragged shapes and strided rows (transpose-detecting:
+    random, non-symmetric input)."""
+    ops = pkg("ops")
+    g = torch.Generator().manual_seed(R * 7 + C)
+    base = torch.randn(R, C + pad, generator=g).to(dt).to(DEV)
+    x = base[:, :C]
+    y = ops.transpose2d(x)
+    assert y.shape == (C, R) and y.is_contiguous()
+    assert torch.equal(y.cpu(), x.cpu().t().contiguous())

@@ -15,9 +15,30 @@ from . import ops
 
 def _t(x: torch.Tensor) -> torch.Tensor:
     """[R, C] -> contiguous [C, R] (data movement for the transposed-operand GEMMs of Linear backward)."""
-    out = torch.empty(x.shape[1], x.shape[0], device=x.device, dtype=x.dtype)      # fresh buffer: canonical strides also for size-1 dims
-    out.copy_(x.t())
-    return out
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    return ops.transpose2d(x)
+
+
+_T_CACHE: dict = {}
+
+
+def _t_frozen(w: torch.Tensor) -> torch.Tensor:
+    """Transposed copy of a FROZEN weight (dX = dY @ W needs W^T as the GEMM's row-major operand), kept across steps: the reference's
+    stage-2 recipe freezes every LLaMA Linear but the LoRA targets, so the 13 GB of transposes are paid once, not per backward.
+    Keyed by storage pointer / shape / version counter (an in-place update of the weight rebuilds the copy)."""
+    if w.requires_grad or w.grad_fn is not None:
+        return _t(w)
+    key = (w.data_ptr(), tuple(w.shape), w.dtype)
+    hit = _T_CACHE.get(key)
+    if hit is None or hit[0] != w._version:
+        hit = (w._version, _t(w))
+        _T_CACHE[key] = hit
+    return hit[1]
+
+
+def clear_transpose_cache():
+    _T_CACHE.clear()
 
 
 class _Linear(torch.autograd.Function):
@@ -40,7 +61,7 @@ class _Linear(torch.autograd.Function):
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(g2, _t(w)).view(x.shape)                                     # [M, N] x [K, N]^T
+            dx = ops.linear(g2, _t_frozen(w)).view(x.shape)                              # [M, N] x [K, N]^T
         if ctx.needs_input_grad[1]:
             dw = ops.linear(_t(g2), _t(x2))                                              # [N, M] x [K, M]^T
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -266,6 +266,224 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     }
 }
 
+// ---- the same backward on the matrix cores (head dim 64 / 128: the LLaMA block) ------------------------------------------------------
+// Mirrors the forward kernel's "swapped" products: an MFMA of A = key rows and B = query rows leaves, in lane (fr, fg), the scores of
+// query fr against keys 4fg + r of a 16-key block -- and eight of those values, packed, ARE the B operand of the next product over the
+// keys of a 32-key block, provided the other operand comes with its keys permuted the same way (slot 8g + 4a + r <- key 16a + 4g + r:
+// the layout transpose_v_kernel writes).  So:
+//   dQ kernel  (block = 64 queries, wave = 16): per 64-key tile  S = K Q^T, dP = V dO^T, dS = P o (dP - delta) mult,
+//              dQ^T += Kt_perm dS        (Kt = transpose_v(K));  first a pass over the keys for the row statistics (lse), delta = dO . O
+//   dKV kernel (block = 64 keys, wave = 16):    per 64-query tile S^T = Q K^T, dP^T = dO V^T (A = query rows, B = key rows),
+//              dV^T += dOt_perm P^T, dK^T += Qt_perm dS^T        (Qt / dOt = transpose_v(Q / dO))
+// Operand fragments come straight from global memory (a (batch, head) is 82-164 KB per tensor: L2-resident); no atomics, fp32 softmax
+// recomputation exactly like the scalar kernels above, P and dS rounded to the element type where they enter an MFMA (the reference's
+// 16-bit autograd rounds them at the same place).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnBwdArgs p, const elem_t* __restrict__ Kt, int pitch, int sqp) {
+    constexpr int NKS = HD / 32, NDB = HD / 16;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+    const int q = blockIdx.x * 64 + wave * 16 + fr;
+    const int qc = min(q, p.Sq - 1);
+    const int shift = p.Sk - p.Sq;
+    uint4 qf[NKS], gf[NKS];
+    float delta = 0.f;
+    {
+        const elem_t* qp = p.Q + b * p.q_bs + h * p.q_hs + (long)qc * p.q_ss;
+        const elem_t* gp = p.dO + b * p.g_bs + h * p.g_hs + (long)qc * p.g_ss;
+        const elem_t* op = p.O + b * p.o_bs + h * p.o_hs + (long)qc * p.o_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[ks] = *(const uint4*)(qp + ks * 32 + fg * 8);
+            gf[ks] = *(const uint4*)(gp + ks * 32 + fg * 8);
+            float g8[8], o8[8];
+            unpack8(gf[ks], g8);
+            unpack8(*(const uint4*)(op + ks * 32 + fg * 8), o8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta += g8[e] * o8[e];
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+    }
+    // keys this block can see at all (block-uniform)
+    const int kend = p.causal ? min(p.Sk, blockIdx.x * 64 + 63 + shift + 1) : p.Sk;
+    const int nkt = (kend + 63) / 64;
+    const elem_t* kbase = p.K + b * p.k_bs + h * p.k_hs;
+    const elem_t* vbase = p.V + b * p.v_bs + h * p.v_hs;
+    const int32_t* km = p.key_mask ? p.key_mask + (long)b * p.Sk : nullptr;
+    auto visible = [&](int key) { return key < p.Sk && (!p.causal || key <= q + shift) && (km == nullptr || km[key] != 0); };
+    // ---- pass 1: log-sum-exp of the row ------------------------------------------------------------------------------------------
+    float m = -INFINITY, l = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        float sv[16];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int kr = min(kt * 64 + cb * 16 + fr, p.Sk - 1);
+            const elem_t* kp = kbase + (long)kr * p.k_ss;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) acc = mfma16(*(const uint4*)(kp + ks * 32 + fg * 8), qf[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = visible(kt * 64 + cb * 16 + fg * 4 + r) ? acc[r] * p.mult : -INFINITY;
+                sv[cb * 4 + r] = sc;
+                mt = fmaxf(mt, sc);
+            }
+        }
+        const float mn = fmaxf(m, mt);
+        if (mn > -INFINITY) {
+            float add = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) add += __expf(sv[e] - mn);
+            l = l * __expf(m - mn) + add;
+            m = mn;
+        }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+        const float mn = fmaxf(m, m2);
+        if (mn > -INFINITY) l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+        m = mn;
+    }
+    const float lse = l > 0.f ? m + __logf(l) : INFINITY;          // a fully masked row: every probability is exp(s - inf) = 0
+    if (fg == 0 && q < p.Sq) {
+        p.lse[(long)bh * sqp + q] = lse;
+        p.delta[(long)bh * sqp + q] = delta;
+    }
+    // ---- pass 2: dS and dQ^T ---------------------------------------------------------------------------------------------------------
+    f32x4_t dq[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) dq[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const elem_t* ktb = Kt + (long)bh * HD * pitch;
+    for (int kt = 0; kt < nkt; ++kt) {
+        uint32_t dsp[8];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int kr = min(kt * 64 + cb * 16 + fr, p.Sk - 1);
+            const elem_t* kp = kbase + (long)kr * p.k_ss;
+            const elem_t* vp = vbase + (long)kr * p.v_ss;
+            f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                sa = mfma16(*(const uint4*)(kp + ks * 32 + fg * 8), qf[ks], sa);
+                da = mfma16(*(const uint4*)(vp + ks * 32 + fg * 8), gf[ks], da);
+            }
+            float ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = visible(kt * 64 + cb * 16 + fg * 4 + r) ? __expf(sa[r] * p.mult - lse) : 0.f;
+                ds[r] = pr * (da[r] - delta) * p.mult;
+            }
+            dsp[cb * 2] = pack2e(ds[0], ds[1]);
+            dsp[cb * 2 + 1] = pack2e(ds[2], ds[3]);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const uint4 bf = make_uint4(dsp[4 * a], dsp[4 * a + 1], dsp[4 * a + 2], dsp[4 * a + 3]);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                dq[db] = mfma16(*(const uint4*)(ktb + (long)(db * 16 + fr) * pitch + kt * 64 + a * 32 + fg * 8), bf, dq[db]);
+        }
+    }
+    // dq[db][r] = dQ^T[d = db*16 + 4fg + r][query fr]
+    if (q < p.Sq) {
+        elem_t* dst = p.dQ + b * p.dq_bs + h * p.dq_hs + (long)q * p.dq_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            uint2 o;
+            o.x = pack2e(dq[db][0], dq[db][1]);
+            o.y = pack2e(dq[db][2], dq[db][3]);
+            *(uint2*)(dst + db * 16 + fg * 4) = o;
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnBwdArgs p, const elem_t* __restrict__ Qt, const elem_t* __restrict__ dOt,
+                                                                int pitch, int sqp) {
+    constexpr int NKS = HD / 32, NDB = HD / 16;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+    const int j = blockIdx.x * 64 + wave * 16 + fr;           // this lane's key (B-operand row)
+    const int jc = min(j, p.Sk - 1);
+    const int shift = p.Sk - p.Sq;
+    uint4 kf[NKS], vf[NKS];
+    {
+        const elem_t* kp = p.K + b * p.k_bs + h * p.k_hs + (long)jc * p.k_ss;
+        const elem_t* vp = p.V + b * p.v_bs + h * p.v_hs + (long)jc * p.v_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *(const uint4*)(kp + ks * 32 + fg * 8);
+            vf[ks] = *(const uint4*)(vp + ks * 32 + fg * 8);
+        }
+    }
+    const bool key_ok = j < p.Sk && (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0);
+    const int qbeg = p.causal ? max(0, blockIdx.x * 64 - shift) : 0;        // first query that can see a key of this block
+    const int nqt = (p.Sq + 63) / 64;
+    const elem_t* qbase = p.Q + b * p.q_bs + h * p.q_hs;
+    const elem_t* gbase = p.dO + b * p.g_bs + h * p.g_hs;
+    const elem_t* qtb = Qt + (long)bh * HD * pitch;
+    const elem_t* gtb = dOt + (long)bh * HD * pitch;
+    const float* lsep = p.lse + (long)bh * sqp;
+    const float* delp = p.delta + (long)bh * sqp;
+    f32x4_t dk[NDB], dv[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) { dk[db] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int qt = qbeg / 64; qt < nqt; ++qt) {
+        uint32_t pp[8], dsp[8];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const int ir = min(qt * 64 + qb * 16 + fr, p.Sq - 1);        // A-operand row of this lane: a query
+            const elem_t* qp = qbase + (long)ir * p.q_ss;
+            const elem_t* gp = gbase + (long)ir * p.g_ss;
+            f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                sa = mfma16(*(const uint4*)(qp + ks * 32 + fg * 8), kf[ks], sa);
+                da = mfma16(*(const uint4*)(gp + ks * 32 + fg * 8), vf[ks], da);
+            }
+            // sa[r] = S[query i = qt*64 + qb*16 + 4fg + r][key j]
+            const int i0 = qt * 64 + qb * 16 + fg * 4;
+            const f32x4_t l4 = *(const f32x4_t*)(lsep + i0), d4 = *(const f32x4_t*)(delp + i0);
+            float pr[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r;
+                const bool vis = key_ok && i < p.Sq && (!p.causal || j <= i + shift);
+                pr[r] = vis ? __expf(sa[r] * p.mult - l4[r]) : 0.f;
+                ds[r] = vis ? pr[r] * (da[r] - d4[r]) * p.mult : 0.f;
+            }
+            pp[qb * 2] = pack2e(pr[0], pr[1]); pp[qb * 2 + 1] = pack2e(pr[2], pr[3]);
+            dsp[qb * 2] = pack2e(ds[0], ds[1]); dsp[qb * 2 + 1] = pack2e(ds[2], ds[3]);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const uint4 bp = make_uint4(pp[4 * a], pp[4 * a + 1], pp[4 * a + 2], pp[4 * a + 3]);
+            const uint4 bd = make_uint4(dsp[4 * a], dsp[4 * a + 1], dsp[4 * a + 2], dsp[4 * a + 3]);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const long off = (long)(db * 16 + fr) * pitch + qt * 64 + a * 32 + fg * 8;
+                dv[db] = mfma16(*(const uint4*)(gtb + off), bp, dv[db]);
+                dk[db] = mfma16(*(const uint4*)(qtb + off), bd, dk[db]);
+            }
+        }
+    }
+    if (j < p.Sk) {
+        elem_t* dkp = p.dK + b * p.dk_bs + h * p.dk_hs + (long)j * p.dk_ss;
+        elem_t* dvp = p.dV + b * p.dv_bs + h * p.dv_hs + (long)j * p.dv_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            uint2 o;
+            o.x = pack2e(dk[db][0], dk[db][1]); o.y = pack2e(dk[db][2], dk[db][3]);
+            *(uint2*)(dkp + db * 16 + fg * 4) = o;
+            o.x = pack2e(dv[db][0], dv[db][1]); o.y = pack2e(dv[db][2], dv[db][3]);
+            *(uint2*)(dvp + db * 16 + fg * 4) = o;
+        }
+    }
+}
+
 // ---- models/ullava_core.py:327-338 backward: d/dlogits of mean CE(logits[:, :-1], labels[:, 1:]) ----------------------------------
 // dlogits[b, s, :] = (softmax(logits[b, s]) - onehot(labels[b, s + 1])) * g / count for counted positions, 0 elsewhere.
 // stats float[2] = {sum of token losses, counted tokens} from the forward; gout = pointer to the upstream gradient (one float).
@@ -556,6 +774,42 @@ extern "C" int ULL_FN(ull_attention_bwd_)(const void* Q, const void* K, const vo
     return ull_check_launch();
 }
 
+// MFMA form (head dim 64 or 128, hd contiguous, 8-byte aligned rows).  Qt / Kt / dOt: transpose_v images [B, H, hd, pitch] of Q, K and dO
+// (keys permuted inside 32-blocks, zero-filled behind the sequence); scratch: float [2, B, H, ceil64(Sq)].
+extern "C" int ULL_FN(ull_attention_bwd_mfma_)(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* Qt, const void* Kt,
+                                           const void* dOt, int64_t pitch, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask,
+                                           int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream) {
+    if (!Q || !K || !V || !O || !dO || !Qt || !Kt || !dOt || !dQ || !dK || !dV || !strides || !scratch || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0)
+        return ULL_ERR_ARG;
+    if (hd != 64 && hd != 128) return ULL_ERR_SHAPE;
+    const int64_t need = ((Sq > Sk ? Sq : Sk) + 63) / 64 * 64;
+    if (pitch < need || (pitch & 7)) return ULL_ERR_SHAPE;
+    for (int i = 0; i < 24; ++i)
+        if (strides[i] & 3) return ULL_ERR_SHAPE;              // 8-byte fragment stores / 16-byte loads need aligned rows
+    AttnBwdArgs p;
+    p.Q = (const elem_t*)Q; p.K = (const elem_t*)K; p.V = (const elem_t*)V; p.O = (const elem_t*)O; p.dO = (const elem_t*)dO;
+    p.dQ = (elem_t*)dQ; p.dK = (elem_t*)dK; p.dV = (elem_t*)dV;
+    const int64_t* s = strides;
+    p.q_bs = s[0]; p.q_hs = s[1]; p.q_ss = s[2]; p.k_bs = s[3]; p.k_hs = s[4]; p.k_ss = s[5]; p.v_bs = s[6]; p.v_hs = s[7]; p.v_ss = s[8];
+    p.o_bs = s[9]; p.o_hs = s[10]; p.o_ss = s[11]; p.g_bs = s[12]; p.g_hs = s[13]; p.g_ss = s[14];
+    p.dq_bs = s[15]; p.dq_hs = s[16]; p.dq_ss = s[17]; p.dk_bs = s[18]; p.dk_hs = s[19]; p.dk_ss = s[20]; p.dv_bs = s[21]; p.dv_hs = s[22]; p.dv_ss = s[23];
+    for (int i = 2; i < 24; i += 3)
+        if (s[i] & 7) return ULL_ERR_SHAPE;                    // token strides: 16-byte fragment loads
+    p.key_mask = (const int32_t*)key_mask;
+    const int sqp = (int)((Sq + 63) / 64 * 64);
+    p.lse = (float*)scratch; p.delta = (float*)scratch + B * H * sqp;
+    p.B = (int)B; p.H = (int)H; p.Sq = (int)Sq; p.Sk = (int)Sk; p.hd = (int)hd; p.causal = causal; p.mult = mult;
+    const dim3 gq((unsigned)((Sq + 63) / 64), (unsigned)(B * H)), gk((unsigned)((Sk + 63) / 64), (unsigned)(B * H));
+    if (hd == 128) {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<128>, gq, dim3(256), 0, (hipStream_t)stream, p, (const elem_t*)Kt, (int)pitch, sqp);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<128>, gk, dim3(256), 0, (hipStream_t)stream, p, (const elem_t*)Qt, (const elem_t*)dOt, (int)pitch, sqp);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<64>, gq, dim3(256), 0, (hipStream_t)stream, p, (const elem_t*)Kt, (int)pitch, sqp);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<64>, gk, dim3(256), 0, (hipStream_t)stream, p, (const elem_t*)Qt, (const elem_t*)dOt, (int)pitch, sqp);
+    }
+    return ull_check_launch();
+}
+
 extern "C" int ULL_FN(ull_shifted_cross_entropy_bwd_)(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V,
                                                   const void* stats, const void* gout, void* dlogits, void* stream) {
     if (!logits || !labels || !stats || !gout || !dlogits || B <= 0 || S <= 0 || V <= 0) return ULL_ERR_ARG;
@@ -571,6 +825,56 @@ extern "C" int ULL_FN(ull_embed_splice_bwd_)(const void* ids, const void* demb, 
     hipLaunchKernelGGL(embed_splice_bwd_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, (const elem_t*)demb,
                        (float*)d_table, (elem_t*)d_img, (int)n_img_tok, (int)img_pitch, (int)img_off, (elem_t*)d_vid, (int)n_vid_tok,
                        (const int32_t*)spans, (int)S, (int)D, (long)vocab);
+    return ull_check_launch();
+}
+
+// out[c][r] = x[r][c]: 64 x 64 tiles through LDS, 16-byte accesses on both sides when the shape allows (the transposed operands of the
+// Linear backward: dW = dY^T X wants dY^T and X^T row-major, dX = dY W wants W^T; a strided elementwise copy ran at 0.1-0.5 TB/s).
+namespace {
+__global__ __launch_bounds__(256) void transpose2d_kernel(const elem_t* __restrict__ x, long ldx, elem_t* __restrict__ y, long ldy, int R, int C) {
+    __shared__ __attribute__((aligned(16))) elem_t t[64][72];              // [c][r]; 144-byte rows keep the 16-byte reads aligned
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const bool fast = ((ldx | ldy) & 7) == 0 && r0 + 64 <= R && c0 + 64 <= C &&
+                      (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    if (fast) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int r = i >> 3, cc = (i & 7) * 8;
+            const uint4 v = *(const uint4*)(x + (long)(r0 + r) * ldx + c0 + cc);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[cc + 2 * j][r] = (elem_t)(w[j] & 0xffff);
+                t[cc + 2 * j + 1][r] = (elem_t)(w[j] >> 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int c = i >> 3, rr = (i & 7) * 8;
+            *(uint4*)(y + (long)(c0 + c) * ldy + r0 + rr) = *(const uint4*)&t[c][rr];
+        }
+    } else {
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            if (r0 + r < R && c0 + c < C) t[c][r] = x[(long)(r0 + r) * ldx + c0 + c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int c = i >> 6, r = i & 63;
+            if (r0 + r < R && c0 + c < C) y[(long)(c0 + c) * ldy + r0 + r] = t[c][r];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ULL_FN(ull_transpose2d_)(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t R, int64_t C, void* stream) {
+    if (!x || !y || R <= 0 || C <= 0 || ldx < C || ldy < R) return ULL_ERR_ARG;
+    if (R > (1 << 30) || C > (1 << 30)) return ULL_ERR_SHAPE;
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const elem_t*)x, (long)ldx, (elem_t*)y, (long)ldy, (int)R, (int)C);
     return ull_check_launch();
 }
 

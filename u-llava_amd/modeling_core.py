@@ -32,6 +32,12 @@ def _param(*shape, device=None, dtype=BF16):
     return nn.Parameter(torch.empty(*shape, device=device, dtype=dtype), requires_grad=False)
 
 
+
+def _clear_transposes():
+    from .autograd_ops import clear_transpose_cache
+    clear_transpose_cache()
+
+
 class Linear(nn.Module):
     def __init__(self, in_features, out_features, bias=True, device=None, dtype=BF16):
         super().__init__()
@@ -207,6 +213,7 @@ class UllavaCoreForCausalLM(nn.Module):
         derived from the parameters and are rebuilt from the moved / cast ones on the next forward."""
         out = super()._apply(fn, *args, **kwargs)
         self._packed = None
+        _clear_transposes()          # cached W^T copies of the training path describe the old weights
         self._inv_freq = None
         return out
 
@@ -234,6 +241,7 @@ class UllavaCoreForCausalLM(nn.Module):
             self.lm_head.out_features = new_num_tokens
             self.config.vocab_size = new_num_tokens
             self._packed = None
+            _clear_transposes()          # cached W^T copies of the training path describe the old weights
         return emb
 
     def get_output_embeddings(self):
@@ -259,6 +267,7 @@ class UllavaCoreForCausalLM(nn.Module):
         sd = {k.replace("vision_encoder.vision_model.", "vision_encoder."): v for k, v in state_dict.items()}
         sd = {k: v for k, v in sd.items() if not k.endswith("position_ids") and "rotary_emb.inv_freq" not in k}
         self._packed = None
+        _clear_transposes()          # cached W^T copies of the training path describe the old weights
         return super().load_state_dict(sd, strict=strict, assign=assign)
 
     # -- weight re-layout ----------------------------------------------------------------------------------

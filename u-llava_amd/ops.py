@@ -563,6 +563,17 @@ def attention_bwd(q, k, v, o, do, dq, dk, dv, strides, key_mask, B: int, H: int,
     flat = [int(x) for tr in strides for x in tr]
     assert len(flat) == 24
     arr = (ctypes.c_int64 * 24)(*flat)
+    (q_bs, q_hs, q_ss), (k_bs, k_hs, k_ss), _, _, (g_bs, g_hs, g_ss) = strides[:5]
+    if hd in (64, 128) and q_hs == hd and k_hs == hd and g_hs == hd and all(x % 4 == 0 for x in flat) and all(flat[i] % 8 == 0 for i in range(2, 24, 3)):
+        # matrix-core kernels: they want Q, K and dO also as transpose_v images (keys / queries permuted inside 32-blocks)
+        pitch = ((max(Sq, Sk) + 63) // 64) * 64
+        qt = transpose_v(q, q_bs, q_ss, B, Sq, H, hd, pitch)
+        kt = transpose_v(k, k_bs, k_ss, B, Sk, H, hd, pitch)
+        gt = transpose_v(do, g_bs, g_ss, B, Sq, H, hd, pitch)
+        scratch = torch.empty(2 * B * H * (((Sq + 63) // 64) * 64), device=q.device, dtype=torch.float32)
+        _lib.call("ull_attention_bwd_mfma_" + _SFX[q.dtype], _p(q), _p(k), _p(v), _p(o), _p(do), _p(qt), _p(kt), _p(gt), pitch, _p(dq), _p(dk), _p(dv),
+                  arr, _p(key_mask), B, H, Sq, Sk, hd, int(causal), float(mult), _p(scratch), _stream())
+        return
     scratch = torch.empty(2 * B * H * Sq, device=q.device, dtype=torch.float32)
     _lib.call("ull_attention_bwd_" + _SFX[q.dtype], _p(q), _p(k), _p(v), _p(o), _p(do), _p(dq), _p(dk), _p(dv), arr, _p(key_mask), B, H, Sq, Sk, hd,
               int(causal), float(mult), _p(scratch), _stream())
@@ -599,6 +610,17 @@ def embed_splice_bwd(ids, demb, vocab: int, img_shape=None, vid_shape=None, span
     _lib.call("ull_embed_splice_bwd_" + _SFX[demb.dtype], _p(ids), _p(demb.contiguous()), _p(d_table), _p(d_img), img_tokens, img_pitch, img_off,
               _p(d_vid), n_vid, _p(spans), B, S, D, vocab, _stream())
     return d_table, d_img, d_vid
+
+
+def transpose2d(x: torch.Tensor) -> torch.Tensor:
+    """[R, C] (last dim contiguous, any row stride) -> fresh contiguous [C, R]."""
+    _chk(x, "x")
+    if x.dim() != 2:
+        raise RuntimeError("u-llava_amd.transpose2d: needs a 2-D tensor")
+    R, C = x.shape
+    y = torch.empty(C, R, device=x.device, dtype=x.dtype)
+    _lib.call("ull_transpose2d_" + _SFX[x.dtype], _p(x), x.stride(0) if R > 1 else C, _p(y), R, R, C, _stream())
+    return y
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:
