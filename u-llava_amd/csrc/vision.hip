@@ -64,33 +64,43 @@ __global__ __launch_bounds__(256) void im2col_kernel(const elem_t* __restrict__ 
 // spans[b] = {kind (0 text, 1 image, 2 video), first start pos, feature index, error flag}
 __global__ void mm_spans_kernel(const int64_t* __restrict__ ids, int B, int S, int img_start, int img_end, int vid_start, int vid_end,
                                 long vocab, int32_t* __restrict__ spans) {
-    // single block; thread b scans sample b, then an in-block prefix count assigns feature indices
-    __shared__ int kind_s[1024];
-    const int b = threadIdx.x;
-    int kind = 0, pos = -1, err = 0;
-    if (b < B) {
-        int nis = 0, nie = 0, nvs = 0, nve = 0, pi = -1, pv = -1;
-        for (int s = 0; s < S; ++s) {
+    // single block of 1024 threads; wave w scans samples w, w + 16, ... (64 ids per load, coalesced: one thread per sample took 0.29 ms
+    // at B = 32, S = 643), then an in-block prefix count assigns feature indices
+    __shared__ int kind_s[1024], pos_s[1024], err_s[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int b = wave; b < B; b += nwave) {
+        int nis = 0, nie = 0, nvs = 0, nve = 0, pi = 0x7fffffff, pv = 0x7fffffff, err = 0;
+        for (int s = lane; s < S; s += 64) {
             const int64_t t = ids[(long)b * S + s];
-            if (t == img_start) { if (pi < 0) pi = s; ++nis; }
+            if (t == img_start) { pi = min(pi, s); ++nis; }
             if (t == img_end) ++nie;
-            if (t == vid_start) { if (pv < 0) pv = s; ++nvs; }
+            if (t == vid_start) { pv = min(pv, s); ++nvs; }
             if (t == vid_end) ++nve;
             if (vocab > 0 && (t < 0 || t >= vocab)) err |= 2;   // nn.Embedding raises IndexError (ullava_core.py:191)
         }
-        if (nis != nie || nvs != nve) err |= 1;    // reference asserts (ullava_core.py:209-211)
-        if (nis > 0) { kind = 1; pos = pi; }
-        else if (nvs > 0) { kind = 2; pos = pv; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            nis += __shfl_xor(nis, o, 64); nie += __shfl_xor(nie, o, 64); nvs += __shfl_xor(nvs, o, 64); nve += __shfl_xor(nve, o, 64);
+            pi = min(pi, __shfl_xor(pi, o, 64)); pv = min(pv, __shfl_xor(pv, o, 64)); err |= __shfl_xor(err, o, 64);
+        }
+        if (lane == 0) {
+            if (nis != nie || nvs != nve) err |= 1;    // reference asserts (ullava_core.py:209-211)
+            int kind = 0, pos = -1;
+            if (nis > 0) { kind = 1; pos = pi; }
+            else if (nvs > 0) { kind = 2; pos = pv; }
+            kind_s[b] = kind; pos_s[b] = pos; err_s[b] = err;
+        }
     }
-    kind_s[threadIdx.x] = (b < B) ? kind : 0;
     __syncthreads();
+    const int b = threadIdx.x;
     if (b < B) {
+        const int kind = kind_s[b];
         int idx = 0;
         for (int j = 0; j < b; ++j) idx += (kind_s[j] == kind);
         spans[b * 4 + 0] = kind;
-        spans[b * 4 + 1] = pos;
+        spans[b * 4 + 1] = pos_s[b];
         spans[b * 4 + 2] = idx;
-        spans[b * 4 + 3] = err;
+        spans[b * 4 + 3] = err_s[b];
     }
 }
 
@@ -195,8 +205,7 @@ extern "C" int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_s
                             int64_t vocab, void* spans, void* stream) {
     if (!ids || !spans || B <= 0 || S <= 0) return ULL_ERR_ARG;
     if (B > 1024) return ULL_ERR_SHAPE;
-    const int threads = (int)((B + 63) / 64) * 64;
-    hipLaunchKernelGGL(mm_spans_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, (const int64_t*)ids, (int)B, (int)S, (int)img_start,
+    hipLaunchKernelGGL(mm_spans_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int64_t*)ids, (int)B, (int)S, (int)img_start,
                        (int)img_end, (int)vid_start, (int)vid_end, (long)vocab, (int32_t*)spans);
     return ull_check_launch();
 }
