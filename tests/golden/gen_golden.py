@@ -418,6 +418,61 @@ def gen_sam_blocks(name, dtype, seed):
                     embedding_abs_sum=r.double().abs().sum().item(), embedding_max=r.float().abs().max().item()))
 
 
+# --------------------------------------------------------------------------- G6 per-op outputs at REAL dims
+def _digest(t):
+    """Strided sample (<= 16384 elements) + sums + sha256 of the raw bytes: enough to check an op bit for bit without storing it."""
+    import hashlib
+    flat = t.contiguous().view(-1)
+    step = max(1, flat.numel() // 16384)
+    raw = flat.view(torch.int16 if t.element_size() == 2 else torch.int32).numpy().tobytes()
+    return dict(shape=tuple(t.shape), dtype=str(t.dtype), sample=flat[::step].clone(), step=step, sum=flat.double().sum().item(),
+                abs_sum=flat.double().abs().sum().item(), sha256=hashlib.sha256(raw).hexdigest())
+
+
+def gen_per_op(name, dtype, seed):
+    """G6: the hot elementwise / normalisation / embedding ops of the path, evaluated by the REFERENCE's own modules (transformers'
+    LlamaRMSNorm, apply_rotary_pos_emb + LlamaRotaryEmbedding, SiLU * up, QuickGELU, GELU, CLIPVisionEmbeddings + pre_layrnorm) at the
+    BASELINE dims (d = 4096, hd = 128, positions 0..1023, ViT-L/14 at 224 and 336)."""
+    print(f"[{name}]")
+    from transformers import LlamaConfig, CLIPVisionConfig
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm, LlamaRotaryEmbedding, apply_rotary_pos_emb
+    from transformers.models.clip.modeling_clip import CLIPVisionEmbeddings
+    from transformers.activations import ACT2FN
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import per_op_inputs
+    x = per_op_inputs(seed, dtype)
+    out = {}
+    with torch.no_grad():
+        norm = LlamaRMSNorm(4096, eps=1e-6).to(dtype)
+        norm.weight.copy_(x["rms_w"])
+        out["rmsnorm"] = norm(x["rms_x"])
+        eq(O.rms_norm(x["rms_x"], x["rms_w"], 1e-6), out["rmsnorm"], "RMSNorm(4096)")
+        lc = LlamaConfig(hidden_size=256, num_attention_heads=2, num_hidden_layers=1, intermediate_size=64, vocab_size=32, max_position_embeddings=2048)
+        lc.head_dim = 128
+        rot = LlamaRotaryEmbedding(config=lc)
+        pos = torch.arange(1024)[None]
+        cos, sin = rot(x["rope_q"], pos)
+        q, k = apply_rotary_pos_emb(x["rope_q"], x["rope_k"], cos, sin)
+        out["rope_q"], out["rope_k"] = q, k
+        ocos, osin = O.rope_tables(pos, 128, 10000.0, dtype)
+        oq, ok_ = O.apply_rope(x["rope_q"], x["rope_k"], ocos, osin)
+        eq(oq, q, "RoPE q"); eq(ok_, k, "RoPE k")
+        out["swiglu"] = ACT2FN["silu"](x["gate"]) * x["up"]
+        out["quick_gelu"] = ACT2FN["quick_gelu"](x["act_x"])
+        eq(O.quick_gelu(x["act_x"]), out["quick_gelu"], "QuickGELU")
+        out["gelu"] = ACT2FN["gelu"](x["act_x"])
+        for isz, px, posk in ((224, "px224", "pos224"), (336, "px336", "pos336")):
+            vc = CLIPVisionConfig(hidden_size=1024, image_size=isz, patch_size=14, num_hidden_layers=1, num_attention_heads=16, intermediate_size=64)
+            emb = CLIPVisionEmbeddings(vc).to(dtype)
+            emb.patch_embedding.weight.copy_(x["patch_w"]); emb.class_embedding.copy_(x["cls"]); emb.position_embedding.weight.copy_(x[posk])
+            ln = torch.nn.LayerNorm(1024, eps=1e-5).to(dtype)
+            ln.weight.copy_(x["ln_w"]); ln.bias.copy_(x["ln_b"])
+            e = emb(x[px])
+            out[f"clip_embed_{isz}"] = e
+            out[f"clip_embed_ln_{isz}"] = ln(e)
+    save(name, dict(seed=seed, dtype=str(dtype), outputs={k: _digest(v) for k, v in out.items()}))
+
+
 # --------------------------------------------------------------------------- G11 evaluate(): ids + masks + boxes
 def gen_evaluate(name, dtype, seed):
     """UllavaForCausalLM.evaluate cannot run under transformers 5.15 (generate drops output_hidden_states), so the
@@ -602,6 +657,9 @@ if __name__ == "__main__":
         gen_full("g8_full_tiny_fp16.pt", torch.float16, 8)
     if want("samblocks"):
         gen_sam_blocks("g9_sam_blocks_bf16.pt", torch.bfloat16, 9)
+    if want("perop"):
+        gen_per_op("g6_per_op_bf16.pt", torch.bfloat16, 6)
+        gen_per_op("g6_per_op_fp16.pt", torch.float16, 6)
     if want("evaluate"):
         gen_evaluate("g11_evaluate_bf16.pt", torch.bfloat16, 8)
     if want("fullgrads"):

@@ -86,3 +86,23 @@ def run_core_fixture(name, device="cuda:0"):
         stats["greedy_equal"] = bool(torch.equal(seq.cpu(), fx["greedy_sequences"]))
         stats["greedy"] = seq[0, fx["greedy_prompt"].shape[1]:].tolist()
     return stats
+
+
+def per_op_inputs(seed, dtype):
+    """Seeded inputs / weights of the G6 ops (shared with the tests: they regenerate these, the fixture only holds outputs)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dtype)
+    return dict(rms_x=r(96, 4096, sc=1.5), rms_w=(torch.randn(4096, generator=g) * 0.1 + 1.0).to(dtype),
+                rope_q=r(1, 2, 1024, 128), rope_k=r(1, 2, 1024, 128),
+                gate=r(160, 1024, sc=2.0), up=r(160, 1024), act_x=r(160, 1024, sc=2.5),
+                px224=r(2, 3, 224, 224), px336=r(1, 3, 336, 336),
+                patch_w=r(1024, 3, 14, 14, sc=0.02), cls=r(1024, sc=0.02), pos224=r(257, 1024, sc=0.02), pos336=r(577, 1024, sc=0.02),
+                ln_w=(torch.randn(1024, generator=g) * 0.1 + 1.0).to(dtype), ln_b=r(1024, sc=0.1))
+
+
+def digest_matches(t, d):
+    """Does tensor t reproduce a gen_golden._digest record bit for bit?  (sha256 of the raw bytes)"""
+    import hashlib
+    flat = t.detach().cpu().contiguous().view(-1)
+    raw = flat.view(torch.int16 if t.element_size() == 2 else torch.int32).numpy().tobytes()
+    return tuple(t.shape) == tuple(d["shape"]) and hashlib.sha256(raw).hexdigest() == d["sha256"]

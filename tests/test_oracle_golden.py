@@ -185,3 +185,20 @@ def test_full_training_gradients_g13():
         assert float(leaves[k].grad.float().norm()) == nrm, k
     for k, rec in fx["grads"].items():
         _eq(leaves[k].grad.reshape(-1)[::rec["stride"]].contiguous(), rec["sample"])
+
+
+@pytest.mark.parametrize("name,dt", [("g6_per_op_bf16.pt", torch.bfloat16), ("g6_per_op_fp16.pt", torch.float16)])
+def test_per_op_fixture_g6_oracle_is_bit_exact(name, dt):
+    """G6: per-op outputs of the reference's own modules at BASELINE dims (RMSNorm 4096, RoPE hd 128 over positions 0..1023, SiLU * up,
+    QuickGELU, GELU): the oracle reproduces every stored byte (sha256) from the seeded inputs."""
+    import torch.nn.functional as F
+    from helpers import per_op_inputs, digest_matches
+    fx = load_fixture(name)
+    x, out = per_op_inputs(fx["seed"], dt), fx["outputs"]
+    assert digest_matches(O.rms_norm(x["rms_x"], x["rms_w"], 1e-6), out["rmsnorm"])
+    cos, sin = O.rope_tables(torch.arange(1024)[None], 128, 10000.0, dt)
+    q, k = O.apply_rope(x["rope_q"], x["rope_k"], cos, sin)
+    assert digest_matches(q, out["rope_q"]) and digest_matches(k, out["rope_k"])
+    assert digest_matches(F.silu(x["gate"]) * x["up"], out["swiglu"])
+    assert digest_matches(O.quick_gelu(x["act_x"]), out["quick_gelu"])
+    assert digest_matches(F.gelu(x["act_x"]), out["gelu"])

@@ -27,7 +27,10 @@ ULL_DEV float f16_bits_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Fl
 // f32 -> 16 bit goes through the native types so hipcc emits gfx950's v_cvt_pk_bf16_f32 / v_cvt_f16_f32 (IEEE round-to-nearest-even,
 // identical to torch's c10::BFloat16 / c10::Half conversions)
 ULL_DEV uint16_t f32_to_bf16_bits(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
-ULL_DEV uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+ULL_DEV uint16_t f32_to_f16_bits(float f) {
+    asm("" : "+v"(f));             // keep a preceding multiply out of the conversion (v_fma_mixlo_f16 would round the product once; see rnd)
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
 
 // dtype-coded access for the kernels that are compiled once and take ULL_DT_* at run time (bilinear, box losses, u8 -> CHW)
 template <int DT> ULL_DEV float load_dt(const void* p, long i) {
@@ -53,12 +56,18 @@ ULL_DEV float e2f(elem_t v) { return f16_bits_to_f32(v); }
 ULL_DEV elem_t f2e(float f) { return f32_to_f16_bits(f); }
 // The rounded value is made opaque to the optimiser: with -ffp-contract=fast LLVM folds fpext(fptrunc(a16 * b16)) + c into a
 // mixed-precision v_fma_mix_f32, which keeps the product UNROUNDED (measured: 19 % of RoPE outputs off by one fp16 ulp).
+// The INPUT is opaque too: fptrunc(a * b) otherwise becomes one v_fma_mixlo_f16 that rounds the exact product once, while torch rounds
+// the fp32 product and then the half (a tie after the first rounding goes the other way: QuickGELU's 1.702 * x at x = -2.9297, found
+// by the G6 fixture).
 ULL_DEV float rnd(float f) {
+    asm("" : "+v"(f));
     _Float16 h = (_Float16)f;
     asm("" : "+v"(h));
     return (float)h;
 }
 ULL_DEV uint32_t pack2e(float lo, float hi) {
+    asm("" : "+v"(lo));
+    asm("" : "+v"(hi));
     const elem2_native_t v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
