@@ -1173,11 +1173,12 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
         // The 4-wave form has the faster K-loop and the slower tile turn-around (one wave per SIMD: nothing overlaps the epilogue's and
         // the prologue's latencies, and the last two steps of every tile re-fetch a K-tile), so it takes the long-K launches -- the
         // LLaMA layer, SAM's lin2 -- and the 8-wave form the K = 1024 / 1280 shapes of the ViTs (measured crossover, tools/gemm_bench.py:
-        // K = 3072 +4 %, K = 2048 -2 %, K = 1280 -9 %; under two rounds of tiles the two are equal).  It addresses its DMA pieces with
+        // K = 3072 +4 %, K = 2048 -2 %, K = 1280 -9 %; with few tiles -- M = 1024-3032 tokens -- the 4-wave form is equal or up to 7 %
+        // ahead at K >= 4096: tools/gemm_smallm.py).  It addresses its DMA pieces with
         // 32-bit offsets from the tile's first row.
         // (An output whose rows are not 16-byte aligned -- lm_head, V = 32011 -- is stored element by element: latency again, 8 waves.)
         const bool c_rows_aligned = (flags & EPI_OUT_F32) ? (ldc & 3) == 0 : (ldc & 7) == 0;
-        const bool waves4 = force_waves4 || (!force_waves8 && K >= 3072 && T >= 2 * n_cu && c_rows_aligned && ldx < (1 << 21) && ldw < (1 << 21));
+        const bool waves4 = force_waves4 || (!force_waves8 && K >= 3072 && c_rows_aligned && ldx < (1 << 21) && ldw < (1 << 21));
         if (waves4) {
             if (flags & EPI_SWIGLU)
                 hipLaunchKernelGGL(big::gemm256w4_kernel<true>, dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
