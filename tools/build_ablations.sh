@@ -3,7 +3,7 @@
 # most of them; they answer "what does the K-loop cost without X").  Output: tools/probes/lib_<name>.so, loaded through ULL_LIB_PATH.
 set -e
 cd "$(dirname "$0")/../u-llava_amd/csrc"
-OTHERS=$(ls *.o | grep -v '^gemm\.o$')
+OTHERS=$(ls *.o | grep -E '^[a-z_]+(\.f16)?\.o$' | grep -v '^gemm\.o$')     # the Makefile's objects only (no -save-temps leftovers)
 for abl in "$@"; do
   # A+B = both switches; a switch with '=' is a schedule knob: BAR_A=16 -> -DULL_W4_BAR_A=16
   DEFS=$(echo $abl | tr '+' '\n' | sed -e '/=/s/^/-DULL_W4_/' -e '/^W4_/s/^/-DULL_/' -e '/^-D/!s/^/-DULL_ABL_/' | tr '\n' ' ')

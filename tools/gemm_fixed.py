@@ -18,7 +18,7 @@ def t(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 b = torch.randn(N, device=dev, generator=g).to(BF); r = torch.randn(M, N, device=dev, generator=g).to(BF)
 out = torch.empty(M, N, device=dev, dtype=BF)
-for K in (128, 1024):
+for K in (128, 256, 1024):
     x = torch.randn(M, K, device=dev, generator=g).to(BF)
     w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(BF)
     ops.register_tiled(w)

@@ -135,7 +135,12 @@ ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_
         } else {
             elem_t* cp = (elem_t*)c.p.C + (long)m * c.p.ldc + n;
             if (full && c.c_al) {
+#if defined(ULL_ABL_NOSTORE)
+                const uint4 v_ = pack8(a);
+                asm volatile("" :: "v"(v_.x), "v"(v_.y), "v"(v_.z), "v"(v_.w), "v"(cp));
+#else
                 *(uint4*)cp = pack8(a);
+#endif
             } else {
 #pragma unroll 1
                 for (int e = 0; e < 8; ++e)
@@ -237,6 +242,63 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
         const int n = ncol0 + c8 * 8;
         const bool rope_on = ROPE && n < p.rope_cols;
         const bool res_pre = has_res && r_al && n + 8 <= n_out;
+        // The common cases -- a 16-bit store of whole 16-byte groups with no activation: plain, + residual, + RoPE -- run in a loop of
+        // their own: the general tail (big_finish8) tests six run-time flags per group of 8 outputs, and those scalar branches, not the
+        // stores, were most of the 5.9 us (8 waves) / 10.7 us (4 waves) an epilogue cost without its stores (tools/gemm_fixed.py with
+        // the NOEPI / NOSTORE ablations).
+#if defined(ULL_ABL_FASTRES)
+        const bool fast = !act && !bias_late && !out_f32 && c_al && (!has_res || r_al) && ncol0 + WCOLS <= n_out;
+#else
+        const bool fast = !act && !bias_late && !out_f32 && c_al && !has_res && ncol0 + WCOLS <= n_out;
+#endif
+        if (fast) {
+            elem_t* cbase = (elem_t*)p.C + n;
+            const elem_t* rbase = p.R + n;
+#pragma unroll 1
+            for (int it0 = 0; it0 < NIT; it0 += UNR) {
+                uint4 va[UNR], vb[UNR], vc[UNR], vs[UNR], vr[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {                  // the long-latency loads first
+                    const long mc = min(mrow0 + (it0 + u) * RPI + lane / LPR, p.M - 1);
+                    if (has_res) vr[u] = *(const uint4*)(rbase + mc * p.ldr);
+                    if constexpr (ROPE) {
+                        vc[u] = *(const uint4*)(p.rope_cos + mc * 64 + c8 * 8);
+                        vs[u] = *(const uint4*)(p.rope_sin + mc * 64 + c8 * 8);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int row = (it0 + u) * RPI + lane / LPR;
+                    va[u] = *(const uint4*)(reg + row * PITCH + c8 * 16);
+                    if constexpr (ROPE) vb[u] = *(const uint4*)(reg_partner + row * PITCH + c8 * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int m = mrow0 + (it0 + u) * RPI + lane / LPR;
+                    uint4 o = va[u];
+                    if (ROPE ? rope_on : false) {
+                        float a[8], b[8], cs[8], sn[8];
+                        unpack8(va[u], a); unpack8(vb[u], b); unpack8(vc[u], cs); unpack8(vs[u], sn);
+                        const bool first_half = (n & 64) == 0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = rnd(a[e] * cs[e]) + rnd((first_half ? -b[e] : b[e]) * sn[e]);
+                        o = pack8(a);
+                    }
+                    if (has_res) {
+                        float a[8], b[8];
+                        unpack8(o, a); unpack8(vr[u], b);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
+                        o = pack8(a);
+                    }
+#if defined(ULL_ABL_NOSTORE)
+                    asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(cbase));
+#else
+                    if (m < p.M) *(uint4*)(cbase + (long)m * p.ldc) = o;
+#endif
+                }
+            }
+        } else
 #pragma unroll 1
         for (int it0 = 0; it0 < NIT; it0 += UNR) {
             uint4 va[UNR], vb[UNR], vc[UNR], vs[UNR], vr[UNR];
@@ -694,6 +756,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the dump's pieces: nothing may be in flight at exit)
 
+#if defined(ULL_ABL_NOEPI)
+    if (p.M > 0) return;
+#endif
     // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
     if (split) {
         float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
@@ -957,6 +1022,9 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
     }
     asm volatile("s_mov_b32 m0, %0\n\ts_waitcnt vmcnt(0)" :: "s"(m0_keep) : "memory");   // (the dump's pieces: nothing may be in flight at exit)
 
+#if defined(ULL_ABL_NOEPI)
+    if (p.M > 0) return;
+#endif
     // ---- epilogue: acc[h][i][j][r] = D[n = n0 + wn*128 + h*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
     if (split) {
         float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
