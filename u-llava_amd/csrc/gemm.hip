@@ -246,58 +246,63 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
         // their own: the general tail (big_finish8) tests six run-time flags per group of 8 outputs, and those scalar branches, not the
         // stores, were most of the 5.9 us (8 waves) / 10.7 us (4 waves) an epilogue cost without its stores (tools/gemm_fixed.py with
         // the NOEPI / NOSTORE ablations).
-#if defined(ULL_ABL_FASTRES)
-        const bool fast = !act && !bias_late && !out_f32 && c_al && (!has_res || r_al) && ncol0 + WCOLS <= n_out;
-#else
-        const bool fast = !act && !bias_late && !out_f32 && c_al && !has_res && ncol0 + WCOLS <= n_out;
-#endif
+        // (the residual takes this loop on the 4-wave kernel only: with groups of 2 the 8-wave kernel measured 2 us per tile round slower
+        // here than on the general path)
+        const bool fast = !act && !bias_late && !out_f32 && c_al && (!has_res || (r_al && UNR >= 4)) && ncol0 + WCOLS <= n_out;
         if (fast) {
             elem_t* cbase = (elem_t*)p.C + n;
             const elem_t* rbase = p.R + n;
+            // compiled twice (with / without the residual) so that the residual loads are unconditional statements of the load phase:
+            // under a run-time `if (has_res)` the compiler merged them with their use and every group waited out its own HBM latency
+            auto fast_loop = [&](auto with_res) {
+                constexpr bool RES = decltype(with_res)::value;
 #pragma unroll 1
-            for (int it0 = 0; it0 < NIT; it0 += UNR) {
-                uint4 va[UNR], vb[UNR], vc[UNR], vs[UNR], vr[UNR];
+                for (int it0 = 0; it0 < NIT; it0 += UNR) {
+                    uint4 va[UNR], vb[UNR], vc[UNR], vs[UNR], vr[UNR];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {                  // the long-latency loads first
-                    const long mc = min(mrow0 + (it0 + u) * RPI + lane / LPR, p.M - 1);
-                    if (has_res) vr[u] = *(const uint4*)(rbase + mc * p.ldr);
-                    if constexpr (ROPE) {
-                        vc[u] = *(const uint4*)(p.rope_cos + mc * 64 + c8 * 8);
-                        vs[u] = *(const uint4*)(p.rope_sin + mc * 64 + c8 * 8);
+                    for (int u = 0; u < UNR; ++u) {              // the long-latency loads first
+                        const long mc = min(mrow0 + (it0 + u) * RPI + lane / LPR, p.M - 1);
+                        if constexpr (RES) vr[u] = *(const uint4*)(rbase + mc * p.ldr);
+                        if constexpr (ROPE) {
+                            vc[u] = *(const uint4*)(p.rope_cos + mc * 64 + c8 * 8);
+                            vs[u] = *(const uint4*)(p.rope_sin + mc * 64 + c8 * 8);
+                        }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int row = (it0 + u) * RPI + lane / LPR;
-                    va[u] = *(const uint4*)(reg + row * PITCH + c8 * 16);
-                    if constexpr (ROPE) vb[u] = *(const uint4*)(reg_partner + row * PITCH + c8 * 16);
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int m = mrow0 + (it0 + u) * RPI + lane / LPR;
-                    uint4 o = va[u];
-                    if (ROPE ? rope_on : false) {
-                        float a[8], b[8], cs[8], sn[8];
-                        unpack8(va[u], a); unpack8(vb[u], b); unpack8(vc[u], cs); unpack8(vs[u], sn);
-                        const bool first_half = (n & 64) == 0;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) a[e] = rnd(a[e] * cs[e]) + rnd((first_half ? -b[e] : b[e]) * sn[e]);
-                        o = pack8(a);
+                    for (int u = 0; u < UNR; ++u) {
+                        const int row = (it0 + u) * RPI + lane / LPR;
+                        va[u] = *(const uint4*)(reg + row * PITCH + c8 * 16);
+                        if constexpr (ROPE) vb[u] = *(const uint4*)(reg_partner + row * PITCH + c8 * 16);
                     }
-                    if (has_res) {
-                        float a[8], b[8];
-                        unpack8(o, a); unpack8(vr[u], b);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
-                        o = pack8(a);
-                    }
+                    for (int u = 0; u < UNR; ++u) {
+                        const int m = mrow0 + (it0 + u) * RPI + lane / LPR;
+                        uint4 o = va[u];
+                        if (ROPE ? rope_on : false) {
+                            float a[8], b[8], cs[8], sn[8];
+                            unpack8(va[u], a); unpack8(vb[u], b); unpack8(vc[u], cs); unpack8(vs[u], sn);
+                            const bool first_half = (n & 64) == 0;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a[e] = rnd(a[e] * cs[e]) + rnd((first_half ? -b[e] : b[e]) * sn[e]);
+                            o = pack8(a);
+                        }
+                        if constexpr (RES) {
+                            float a[8], b[8];
+                            unpack8(o, a); unpack8(vr[u], b);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
+                            o = pack8(a);
+                        }
 #if defined(ULL_ABL_NOSTORE)
-                    asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(cbase));
+                        asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(cbase));
 #else
-                    if (m < p.M) *(uint4*)(cbase + (long)m * p.ldc) = o;
+                        if (m < p.M) *(uint4*)(cbase + (long)m * p.ldc) = o;
 #endif
+                    }
                 }
-            }
+            };
+            if (has_res) fast_loop(std::true_type{});
+            else fast_loop(std::false_type{});
         } else
 #pragma unroll 1
         for (int it0 = 0; it0 < NIT; it0 += UNR) {
