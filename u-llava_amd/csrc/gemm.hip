@@ -199,6 +199,9 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
         constexpr int WCOLS = (SWIGLU && !SW2) ? 32 : 64;  // output columns of the region
         constexpr int PITCH = WCOLS * 2 + 16;              // bytes; +16 keeps 16-byte alignment and spreads banks
         if constexpr (PHASE != 2) {
+        // (two copies: without a bias the 4 adds per accumulator -- 256 instructions per wave of the 4-wave kernel -- are not issued)
+        auto park_all = [&](auto with_bias) {
+        constexpr bool WB = decltype(with_bias)::value;
 #pragma clang loop unroll(full)
         for (int j = 0; j < JT; ++j) {
             if constexpr (SWIGLU) {
@@ -221,12 +224,20 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
 #pragma clang loop unroll(full)
                 for (int i = 0; i < 4; ++i) {
                     uint2 o;                                             // the Linear's bf16 output
-                    o.x = pack2e(acc[i][j][0] + bias_v[i][0], acc[i][j][1] + bias_v[i][1]);
-                    o.y = pack2e(acc[i][j][2] + bias_v[i][2], acc[i][j][3] + bias_v[i][3]);
+                    if constexpr (WB) {
+                        o.x = pack2e(acc[i][j][0] + bias_v[i][0], acc[i][j][1] + bias_v[i][1]);
+                        o.y = pack2e(acc[i][j][2] + bias_v[i][2], acc[i][j][3] + bias_v[i][3]);
+                    } else {
+                        o.x = pack2e(acc[i][j][0], acc[i][j][1]);
+                        o.y = pack2e(acc[i][j][2], acc[i][j][3]);
+                    }
                     *(uint2*)(reg + (j * 16 + fr) * PITCH + (i * 16 + fg * 4) * 2) = o;
                 }
             }
         }
+        };
+        if (!SWIGLU && (flags & EPI_BIAS) && !bias_late) park_all(std::true_type{});
+        else park_all(std::false_type{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own region only: no block barrier needed
         }
         if constexpr (PHASE == 1) return;
