@@ -94,7 +94,7 @@ ULL_DEV EpiCtx epi_ctx(const GemmArgs& p, bool swiglu) {
 }
 ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_pre = false, uint4 res_pre = uint4{0, 0, 0, 0}) {
         if (c.bias_late) {
-#pragma unroll 1
+#pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (n + e < c.n_out) a[e] = rnd(a[e] + e2f(c.p.bias[n + e]));
         }
@@ -117,7 +117,7 @@ ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
             } else {
-#pragma unroll 1
+#pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (n + e < c.n_out) a[e] = rnd(e2f(rp[e]) + a[e]);
             }
@@ -128,7 +128,7 @@ ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_
                 *(float4*)cp = make_float4(a[0], a[1], a[2], a[3]);
                 *(float4*)(cp + 4) = make_float4(a[4], a[5], a[6], a[7]);
             } else {
-#pragma unroll 1
+#pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (n + e < c.n_out) cp[e] = a[e];
             }
@@ -141,8 +141,22 @@ ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_
 #else
                 *(uint4*)cp = pack8(a);
 #endif
+            } else if (full) {
+                // rows that are only 2-byte aligned (lm_head: V = 32011): 4-byte stores where the address allows, two 2-byte ends otherwise
+                const uint4 pk = pack8(a);
+                if ((((long)m * c.p.ldc + n) & 1) == 0) {
+                    uint32_t* c4 = (uint32_t*)cp;
+                    c4[0] = pk.x; c4[1] = pk.y; c4[2] = pk.z; c4[3] = pk.w;
+                } else {
+                    cp[0] = (elem_t)(pk.x & 0xffff);
+                    uint32_t* c4 = (uint32_t*)(cp + 1);
+                    c4[0] = (pk.x >> 16) | (pk.y << 16);
+                    c4[1] = (pk.y >> 16) | (pk.z << 16);
+                    c4[2] = (pk.z >> 16) | (pk.w << 16);
+                    cp[7] = (elem_t)(pk.w >> 16);
+                }
             } else {
-#pragma unroll 1
+#pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (n + e < c.n_out) cp[e] = f2e(a[e]);
             }
