@@ -784,7 +784,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the dump's pieces: nothing may be in flight at exit)
+    // (the dump's pieces may still be landing: they touch nothing the epilogue uses, and s_endpgm waits for them)
 
 #if defined(ULL_ABL_NOEPI)
     if (p.M > 0) return;
@@ -1050,7 +1050,8 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
         }
         if (kt == nk - 1) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     }
-    asm volatile("s_mov_b32 m0, %0\n\ts_waitcnt vmcnt(0)" :: "s"(m0_keep) : "memory");   // (the dump's pieces: nothing may be in flight at exit)
+    asm volatile("s_mov_b32 m0, %0" :: "s"(m0_keep) : "memory");   // (the dump's pieces may still be landing: they touch nothing
+                                                                    // the epilogue uses, and s_endpgm waits for them)
 
 #if defined(ULL_ABL_NOEPI)
     if (p.M > 0) return;
