@@ -273,14 +273,17 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
         // the NOEPI / NOSTORE ablations).
         // (the residual takes this loop on the 4-wave kernel only: with groups of 2 the 8-wave kernel measured 2 us per tile round slower
         // here than on the general path)
-        const bool fast = !act && !bias_late && !out_f32 && c_al && (!has_res || (r_al && UNR >= 4)) && ncol0 + WCOLS <= n_out;
+        // An activation takes it on the 8-wave kernel (where the ViT MLPs run), without a residual (no Linear on the path has both).
+        const bool fast_act = act && UNR <= 2 && !has_res && !ROPE && !SWIGLU;
+        const bool fast = (!act || fast_act) && !bias_late && !out_f32 && c_al && (!has_res || (r_al && UNR >= 4)) && ncol0 + WCOLS <= n_out;
         if (fast) {
             elem_t* cbase = (elem_t*)p.C + n;
             const elem_t* rbase = p.R + n;
             // compiled twice (with / without the residual) so that the residual loads are unconditional statements of the load phase:
             // under a run-time `if (has_res)` the compiler merged them with their use and every group waited out its own HBM latency
-            auto fast_loop = [&](auto with_res) {
+            auto fast_loop = [&](auto with_res, auto act_kind) {
                 constexpr bool RES = decltype(with_res)::value;
+                constexpr int ACT = decltype(act_kind)::value;          // 0 none, 1 QuickGELU, 2 GELU(erf), 3 ReLU
 #pragma unroll 1
                 for (int it0 = 0; it0 < NIT; it0 += UNR) {
                     uint4 va[UNR], vb[UNR], vc[UNR], vs[UNR], vr[UNR];
@@ -311,6 +314,14 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                             for (int e = 0; e < 8; ++e) a[e] = rnd(a[e] * cs[e]) + rnd((first_half ? -b[e] : b[e]) * sn[e]);
                             o = pack8(a);
                         }
+                        if constexpr (ACT != 0) {
+                            float a[8];
+                            unpack8(o, a);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                a[e] = ACT == 1 ? act_quick_gelu_e(a[e]) : ACT == 2 ? rnd(act_gelu_erf(a[e])) : fmaxf(a[e], 0.f);
+                            o = pack8(a);
+                        }
                         if constexpr (RES) {
                             float a[8], b[8];
                             unpack8(o, a); unpack8(vr[u], b);
@@ -326,8 +337,14 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                     }
                 }
             };
-            if (has_res) fast_loop(std::true_type{});
-            else fast_loop(std::false_type{});
+            using I0 = std::integral_constant<int, 0>;
+            if (has_res) fast_loop(std::true_type{}, I0{});
+            else if constexpr (UNR <= 2 && !ROPE && !SWIGLU) {
+                if (act == 1) fast_loop(std::false_type{}, std::integral_constant<int, 1>{});
+                else if (act == 2) fast_loop(std::false_type{}, std::integral_constant<int, 2>{});
+                else if (act == 3) fast_loop(std::false_type{}, std::integral_constant<int, 3>{});
+                else fast_loop(std::false_type{}, I0{});
+            } else fast_loop(std::false_type{}, I0{});
         } else
 #pragma unroll 1
         for (int it0 = 0; it0 < NIT; it0 += UNR) {
