@@ -90,6 +90,21 @@ def test_sam_encoder_attention(side, hd, nH, NB):
                   q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side))
     # (MFMA vs sequential fp32 accumulation order may flip a bf16 rounding of a table entry, so compare with the reference)
     assert_close_bf16(att2, ref, ulps=2.0, what=f"sam attention (fused rel-pos) side={side}", outlier_frac=frac, outlier_floor=vmax)
+    if side == 14 and hd == 80:
+        # the path's own form for 14 x 14 windows: window rows padded to 16 key slots (C-ABI rel_mode 3).  Scores, softmax and P are
+        # the same numbers as in the generic kernel; only the order of the fp32 P*V sum over keys differs.
+        vtw = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd, win_kw=side)
+        assert vtw.shape[-1] == 256
+        att3 = torch.empty_like(att)
+        ops.attention(qkv, qkv[:, C:], vtw, att3, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
+                      q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side),
+                      win_padded=True)
+        assert_close_bf16(att3, ref, ulps=2.0, what="sam attention (row-padded windows)", outlier_frac=frac, outlier_floor=vmax)
+        e3 = float((att3.float().cpu() - truth).pow(2).mean().sqrt())
+        assert e3 <= 1.15 * e_ref, f"rms error vs fp32 truth: row-padded kernel {e3:.4g}, reference bf16 path {e_ref:.4g}"
+        d = (att3.float() - att2.float()).abs()
+        assert float((d > 0).float().mean()) < 0.02, "row-padded and generic window kernels differ on more than 2 % of the outputs"
+        print(f"row-padded vs generic window attention: {float((d > 0).float().mean()):.4%} of outputs differ, max {float(d.max()):.3g}")
 
 
 @pytest.mark.parametrize("Sq,Sk,hd", [(6, 4096, 16), (4096, 6, 16), (6, 6, 32), (130, 1500, 64)])

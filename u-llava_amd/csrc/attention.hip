@@ -35,6 +35,7 @@ struct AttnArgs {
     const elem_t* rel_h; const elem_t* rel_w;   // [B*H, Sq, KH] / [B*H, Sq, KW] or null
     int KH, KW;
     int rel_mode;                       // 1: rel_h/rel_w are per-query tables [B*H,Sq,KH|KW]; 2: they are the raw rel_pos_h/w parameters
+    int win16;                          // C-ABI rel_mode 3: as 2, and Vt is the row-padded image written by ull_transpose_v_win
                                         //    [2KH-1,hd] / [2KW-1,hd] and the tables are built in the kernel prologue on the MFMA
     float inv_kw;                       // 1 / KW
     float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
@@ -225,9 +226,18 @@ ULL_DEV int head_dim_of(const AttnArgs& p) {
 //   DMA'd up front, the NT V^T tiles right after the K barrier (they land during the score / softmax phases), so a block
 //   passes 2 barriers instead of 2*NT and exposes two memory round trips instead of 2*NT -- the streaming form measured
 //   46 us per block for ~10 us of work.  One block of NWV = 13 waves covers all 196 queries of a (window, head).
-template <int HDP, int NT, int FL, int NWV, bool EXACT = false>
+//   WIN16 (the SAM 14 x 14 windows, rel_mode 3): the key axis is re-indexed slot = 16 * kh + kw, i.e. every window row padded from
+//   KW = 14 to 16 slots (K rows gathered that way by the DMA, V^T written that way by ull_transpose_v_win).  A 16-key block is then
+//   one window row: kh is a compile-time constant per block and kw = 4 * (lane / 16) + r a per-lane constant for the whole
+//   kernel, so the decomposed rel-pos bias costs one LDS read per quad and two adds per score (the generic path divides j by KW
+//   and reads two table entries per score: 28 VALU instructions per score against 10), padding is a per-lane constant, the
+//   two all-padding blocks of the fourth tile are not computed, and the row maximum is taken while the scores are produced.
+template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false>
 __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!WIN16 || (EXACT && FL == FL_SAM_ENC && NT == 4), "WIN16 is the 14 x 14 window form of the exact kernel");
+    constexpr int WKH = 14, WKW = 14;     // WIN16 window shape (checked by the dispatcher)
+    constexpr int NBLK = WIN16 ? WKH : 4 * NT;       // 16-key blocks that hold any key
     constexpr int BQ = 16 * NWV;
     constexpr int CPR = HDP / 8;          // 16-byte chunks per K-tile row
     constexpr int KROW = HDP * 2;         // K-tile row bytes
@@ -271,10 +281,14 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 #pragma unroll
             for (int i0 = 0; i0 < CPR; i0 += NWV) {
                 const int i = i0 + wave;                        // one 1-KiB piece = 64/CPR rows
-                if (i < CPR) {
+                if (i < CPR && (!WIN16 || kt * KT + i * (64 / CPR) < NBLK * 16)) {
                     const int row = i * (64 / CPR) + lane / CPR;
                     const int c = (lane % CPR) ^ swz<CPR>(row);
-                    const int key = min(kt * KT + row, p.Sk - 1);
+                    int key = min(kt * KT + row, p.Sk - 1);
+                    if constexpr (WIN16) {           // slot 16 * kh + kw <- key kh * KW + kw (padding slots read a real key and are masked)
+                        const int slot = kt * KT + row;
+                        key = min(slot >> 4, WKH - 1) * WKW + min(slot & 15, WKW - 1);
+                    }
                     const elem_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
                     glds16(src, dst + i * 1024);
                 }
@@ -309,6 +323,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             const int d = ks * 32 + fg * 8;
             qf[ks] = (qi < p.Sq && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
         }
+        if constexpr (!WIN16)
         for (int j = tid; j < nkt * KT; j += NWV * 64) {
             unsigned char m = 2;
             if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
@@ -327,6 +342,12 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = scale_q8(qf[ks], p.q_scale);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float wv[4] = {0.f, 0.f, 0.f, 0.f};   // WIN16: rel_w of this lane's four window columns kw = 4 * fg + r (same for every block)
+    float mrow = -INFINITY;               // WIN16: running maximum of this lane's scores
+    if constexpr (WIN16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[r] = e2f(brow[bw_off - min(fg * 4 + r, WKW - 1)]);
+    }
 
     uint32_t sp[NT][8];                   // [tile][2*ns + half]: bf16 pairs for keys kt*64 + ns*16 + 4*fg + {0,1 | 2,3}
     if constexpr (EXACT) {
@@ -350,6 +371,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                 const char* tb = smem + (EXACT ? kt : (kt & 1)) * TILE;
 #pragma unroll
                 for (int ns = 0; ns < 4; ++ns) {
+                    if (WIN16 && kt * 4 + ns >= NBLK) continue;   // blocks past the last window row hold no key
                     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
                     const int row = ns * 16 + fr;
 #pragma unroll
@@ -358,6 +380,19 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                             const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
                             acc = mfma16(kf, qf[ks], acc);
                         }
+                    }
+                    if constexpr (WIN16) {
+                        // block = window row kh = 4 * kt + ns; this lane's keys are columns kw = 4 * fg + r
+                        const float hb = e2f(brow[bh_off - (kt * 4 + ns)]);
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = rnd(rnd(rnd(acc[r]) + hb) + wv[r]);
+                        if (fg == 3) o[2] = o[3] = -INFINITY;             // kw = 14, 15: padding slots
+                        mrow = fmaxf(mrow, fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])));
+                        sp[kt][ns * 2] = pack2e(o[0], o[1]);
+                        sp[kt][ns * 2 + 1] = pack2e(o[2], o[3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
                     }
                     const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
                     const int j0 = kt * KT + ns * 16 + fg * 4;
@@ -376,7 +411,8 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 
     // ---- phase 2: exact fp32 row softmax over the bf16 scores, P = bf16(softmax) (registers only) --------
     {
-        float m = -INFINITY;
+        float m = mrow;
+        if constexpr (!WIN16)
 #pragma clang loop unroll(full)
         for (int kt = 0; kt < NT; ++kt)
             if (kt < nkt_w) {
@@ -389,11 +425,29 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float sum = 0.f;
+        if constexpr (WIN16) {
+            // 56 scores per lane: the exponentials fit in registers, so each is evaluated once (the generic form evaluates it for
+            // the sum and again for P because a long row does not fit)
+            float e[NBLK * 4];
+#pragma unroll
+            for (int i = 0; i < NBLK * 2; ++i) {
+                e[2 * i] = __expf(pk_lo(sp[i / 8][i % 8]) - m);
+                e[2 * i + 1] = __expf(pk_hi(sp[i / 8][i % 8]) - m);
+                sum += e[2 * i];
+                sum += e[2 * i + 1];
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int i = 0; i < NBLK * 2; ++i) sp[i / 8][i % 8] = pack2e(e[2 * i] * inv, e[2 * i + 1] * inv);
+        } else {
 #pragma clang loop unroll(full)
         for (int kt = 0; kt < NT; ++kt)
             if (kt < nkt_w) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
+                    if (kt * 4 + i / 2 >= NBLK) continue;
                     sum += __expf(pk_lo(sp[kt][i]) - m);
                     sum += __expf(pk_hi(sp[kt][i]) - m);
                 }
@@ -407,12 +461,14 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             if (kt < nkt_w) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
+                    if (kt * 4 + i / 2 >= NBLK) continue;
                     const float lo = __expf(pk_lo(sp[kt][i]) - m) * inv;
                     const float hi = __expf(pk_hi(sp[kt][i]) - m) * inv;
                     sp[kt][i] = pack2e(lo, hi);
                 }
                 if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
+        }
     }
 
     // ---- phase 3: O^T = V^T P^T; P feeds the MFMA B operand straight from registers ---------------------
@@ -437,6 +493,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                 const char* tb = smem + (EXACT ? NT + kt : ((nkt + kt) & 1)) * TILE;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
+                    if (2 * (kt * 2 + kk) >= NBLK) continue;
                     const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
 #pragma unroll
                     for (int ds = 0; ds < NDS; ++ds) {
@@ -1179,8 +1236,10 @@ __global__ __launch_bounds__(256) void rope_append_kernel(elem_t* __restrict__ q
 // Inside every 32-key block the keys are stored permuted: slot 8g + 4a + r holds key 16a + 4g + r (a<2, g<4, r<4),
 // which is the (lane group g, element j = 4a + r) <-> key map that the attention kernel's probability registers
 // have after the swapped QK^T MFMA -- so P*V needs no cross-lane movement.  64(s) x 64(d) tiles through LDS.
+// win_kw > 0 (ull_transpose_v_win): the key axis of Vt is slot = 16 * (key / win_kw) + key % win_kw -- every window row padded to 16
+// slots (zeros in the padding) -- which is the key order of the WIN16 attention kernel.
 __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restrict__ v, long v_bs, long v_ss, elem_t* __restrict__ vt, int S,
-                                                          int H, int hd, int pitch) {
+                                                          int H, int hd, int pitch, int win_kw) {
     __shared__ __attribute__((aligned(16))) elem_t t[64][68];            // [d][key]; 136-byte rows keep the 8-byte reads aligned
     const int b = blockIdx.z / H, h = blockIdx.z % H;
     const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
@@ -1191,7 +1250,9 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restri
         const int c = threadIdx.x + 256 * k;
         const int sl = c >> 3, dc = (c & 7) * 8;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (s0 + sl < S && d0 + dc < hd) val = *(const uint4*)(vp + (long)(s0 + sl) * v_ss + d0 + dc);
+        int key = s0 + sl;
+        if (win_kw > 0) key = (key & 15) < win_kw ? (key >> 4) * win_kw + (key & 15) : S;
+        if (key < S && d0 + dc < hd) val = *(const uint4*)(vp + (long)key * v_ss + d0 + dc);
         const uint32_t w[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1212,7 +1273,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restri
     }
 }
 
-template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false>
+template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false, bool WIN16 = false>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
     const int lds = (EXACT ? 2 * NT : 2) * TILE + NT * KT +
@@ -1220,11 +1281,11 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     if (lds > 160 * 1024) return ULL_ERR_LDS;
     static UllOncePerDevice once;
     if (lds > 64 * 1024 && once.first())
-        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT>), grid, dim3(NWV * 64), lds, st, a);
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16>), grid, dim3(NWV * 64), lds, st, a);
     return ull_check_launch();
 }
 
@@ -1303,6 +1364,10 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     if constexpr (HDP == 128) {
         if (fl == FL_LLAMA && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4>(a, st);
         if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
+        if (a.win16) {                                                                   // 14 x 14 windows, row-padded key slots
+            if (fl != FL_SAM_ENC || a.KH != 14 || a.KW != 14 || a.Sk != 196 || a.Sq > 208 || a.key_mask || a.vt_len < 256) return ULL_ERR_SHAPE;
+            return launch_attn<128, 4, FL_SAM_ENC, 13, true, true>(a, st);
+        }
         if (fl == FL_SAM_ENC && nt == 4 && a.Sq <= 208) return launch_attn<128, 4, FL_SAM_ENC, 13, true>(a, st);   // 14 x 14 windows
         if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
         if (fl == FL_SAM_ENC && nt > 16) {
@@ -1352,11 +1417,13 @@ extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs,
     a.zeros = (const elem_t*)zeros;
     a.rel_h = (const elem_t*)rel_h; a.rel_w = (const elem_t*)rel_w; a.KH = (int)rel_kh; a.KW = (int)rel_kw; a.q_scale = q_scale;
     a.inv_kw = rel_kw > 0 ? 1.0f / (float)rel_kw : 0.f;
-    a.rel_mode = rel_h ? rel_mode : 0;
-    if (rel_h && rel_mode != 1 && rel_mode != 2) return ULL_ERR_ARG;
+    a.rel_mode = rel_h ? (rel_mode == 3 ? 2 : rel_mode) : 0;
+    a.win16 = rel_h && rel_mode == 3;
+    if (rel_h && (rel_mode < 1 || rel_mode > 3)) return ULL_ERR_ARG;
     if ((rel_h == nullptr) != (rel_w == nullptr)) return ULL_ERR_ARG;
     if (rel_h && (rel_kh <= 0 || rel_kw <= 0 || rel_kh + rel_kw > 256 || rel_kh * rel_kw < Sk)) return ULL_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (a.win16 && hd != 80) return ULL_ERR_SHAPE;
     if (hd <= 32) return dispatch_nt<32>(a, st);
     if (hd <= 64) return dispatch_nt<64>(a, st);
     return dispatch_nt<128>(a, st);
@@ -1413,6 +1480,17 @@ extern "C" int ULL_FN(ull_transpose_v_)(const void* v, int64_t v_bs, int64_t v_s
     if (pitch < S || (pitch & 63)) return ULL_ERR_SHAPE;
     const dim3 grid((unsigned)((pitch + 63) / 64), (unsigned)((hd + 63) / 64), (unsigned)(B * H));
     hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const elem_t*)v, v_bs, v_ss, (elem_t*)vt, (int)S, (int)H,
-                       (int)hd, (int)pitch);
+                       (int)hd, (int)pitch, 0);
+    return ull_check_launch();
+}
+
+// The same for window attention with rel_mode 3: window rows of kw <= 16 keys padded to 16 slots each (S = kh * kw keys -> 16 * kh slots).
+extern "C" int ULL_FN(ull_transpose_v_win_)(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd,
+                                        int64_t pitch, int64_t kw, void* stream) {
+    if (!v || !vt || B <= 0 || S <= 0) return ULL_ERR_ARG;
+    if (kw <= 0 || kw > 16 || S % kw || pitch < (S / kw) * 16 || (pitch & 63)) return ULL_ERR_SHAPE;
+    const dim3 grid((unsigned)((pitch + 63) / 64), (unsigned)((hd + 63) / 64), (unsigned)(B * H));
+    hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const elem_t*)v, v_bs, v_ss, (elem_t*)vt, (int)S, (int)H,
+                       (int)hd, (int)pitch, (int)kw);
     return ull_check_launch();
 }

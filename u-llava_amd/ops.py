@@ -289,15 +289,16 @@ def clip_embed_ln(patch: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, w: 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Sq: int, Sk: int, hd: int,
               q_strides, k_strides, o_strides, key_mask: Optional[torch.Tensor] = None, causal: bool = False, scale_mode: int = 1,
               scale: float = 1.0, q_scale: float = 1.0, rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None,
-              rel_pos_hw: Optional[tuple] = None):
+              rel_pos_hw: Optional[tuple] = None, win_padded: bool = False):
     """rel_h/rel_w: either per-query bias tables [B*H, Sq, KH|KW] (from sam_relpos), or -- with rel_pos_hw=(KH, KW) -- the raw
-    rel_pos_h / rel_pos_w parameters [2KH-1, hd] / [2KW-1, hd], in which case the kernel builds the tables itself."""
+    rel_pos_h / rel_pos_w parameters [2KH-1, hd] / [2KW-1, hd], in which case the kernel builds the tables itself.
+    win_padded: vt comes from transpose_v(..., win_kw=KW) (14 x 14 windows: rows padded to 16 key slots, C-ABI rel_mode 3)."""
     _chk(q, "q"); _chk(k, "k", q.dtype); _chk(vt, "vt", q.dtype); _chk(out, "out", q.dtype)
     rel_mode, kh, kw = 0, 0, 0
     if rel_h is not None:
         _chk(rel_h, "rel_h", q.dtype); _chk(rel_w, "rel_w", q.dtype)
         if rel_pos_hw is not None:
-            rel_mode, (kh, kw) = 2, rel_pos_hw
+            rel_mode, (kh, kw) = (3 if win_padded else 2), rel_pos_hw
             if rel_h.shape[0] != 2 * kh - 1 or rel_w.shape[0] != 2 * kw - 1 or rel_h.shape[1] != hd:
                 raise NotImplementedError("rel_pos interpolation (image_encoder.py:336-343) is not needed for 1024x1024 SAM inputs")
         else:
@@ -326,11 +327,16 @@ def rope_append(qkv: torch.Tensor, row_stride: int, positions: torch.Tensor, inv
 
 
 def transpose_v(v: torch.Tensor, v_bs: int, v_ss: int, B: int, S: int, H: int, hd: int, pitch: Optional[int] = None,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, win_kw: int = 0) -> torch.Tensor:
+    """win_kw > 0: the window form (rows of win_kw keys padded to 16 slots) that attention(..., win_padded=True) reads."""
     _chk(v, "v")
-    pitch = pitch or ((S + 63) // 64) * 64
+    slots = (S // win_kw) * 16 if win_kw else S
+    pitch = pitch or ((slots + 63) // 64) * 64
     vt = out if out is not None else torch.empty(B, H, hd, pitch, device=v.device, dtype=v.dtype)
-    _lib.call("ull_transpose_v_" + _SFX[v.dtype], _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, _stream())
+    if win_kw:
+        _lib.call("ull_transpose_v_win_" + _SFX[v.dtype], _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, win_kw, _stream())
+    else:
+        _lib.call("ull_transpose_v_" + _SFX[v.dtype], _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, _stream())
     return vt
 
 
