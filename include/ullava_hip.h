@@ -179,9 +179,14 @@ int ull_window_unpartition_add_bf16(const void* win, const void* shortcut, void*
                                     void* stream);
 
 /* image_encoder.py:321-392 get_rel_pos + einsum("bhwc,hkc->bhwk") / ("bhwc,wkc->bhwk"): q [NB,nH,KH*KW,hd] by strides ->
- * out_h [NB*nH, KH*KW, KH], out_w [NB*nH, KH*KW, KW].  rel_pos_h [2*KH-1, hd], rel_pos_w [2*KW-1, hd] (no interpolation case). */
+ * out_h [NB*nH, KH*KW, KH], out_w [NB*nH, KH*KW, KW].  rel_pos_h [2*KH-1, hd], rel_pos_w [2*KW-1, hd] (tables of another length go
+ * through ull_interp_rows_linear_bf16 first). */
 int ull_sam_relpos_bf16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w, void* out_h,
                         void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
+
+/* image_encoder.py:336-343: the linear resize get_rel_pos applies to a rel-pos table whose length differs from 2*size-1:
+ * x [L, C] -> y [M, C] = F.interpolate(x as [1, C, L], size = M, mode = "linear") with ATen's CPU rounding (weights rounded to the element type). */
+int ull_interp_rows_linear_bf16(const void* x, void* y, int64_t L, int64_t M, int64_t C, void* stream);
 
 /* common.py:31-43 LayerNorm2d on channels-last rows [rows, C] with the reference's bf16 op chain; gelu != 0 fuses the
  * nn.GELU that follows it in mask_decoder.py:53-64 output_upscaling. */
@@ -383,6 +388,7 @@ int ull_add_rows_f16(const void* a, const void* b, void* out, int64_t rows, int6
 int ull_window_partition_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
 int ull_window_unpartition_add_f16(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
 int ull_sam_relpos_f16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w, void* out_h, void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
+int ull_interp_rows_linear_f16(const void* x, void* y, int64_t L, int64_t M, int64_t C, void* stream);
 int ull_layernorm2d_cl_f16(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu, void* stream);
 int ull_im2col3x3_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 int ull_mask_matmul_f16(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);

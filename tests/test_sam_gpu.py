@@ -57,6 +57,42 @@ def test_relpos_tables(side, hd, nH, NB):
     assert_close_bf16(ow.view(rel_w.shape), rel_w, ulps=1.0, what="rel_w")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("L,size", [(27, 64), (127, 14), (27, 20), (63, 64), (27, 14)])
+def test_rel_pos_interpolation_is_bit_exact(L, size, dtype):
+    """get_rel_pos's resize of a table of another length (image_encoder.py:336-343), against the oracle's F.interpolate."""
+    ops = pkg("ops")
+    g = torch.Generator().manual_seed(L * 100 + size)
+    tab = torch.randn(L, 80, generator=g).to(dtype)
+    ref = O.get_rel_pos(size, size, tab)                       # [size, size, C] gather of the resized table
+    got = ops.fit_rel_pos(tab.to(DEV), size).cpu()
+    assert got.shape == (2 * size - 1, 80)
+    idx = (torch.arange(size)[:, None] - torch.arange(size)[None, :]) + (size - 1)
+    assert torch.equal(got[idx], ref)
+
+
+def test_sam_attention_with_tables_of_another_length():
+    """A SAM block whose rel_pos tables were trained at another window size: the attention path resizes them like the reference."""
+    ops = pkg("ops")
+    side, hd, nH, NB = 14, 80, 2, 2
+    S, C = side * side, nH * hd
+    x = _rand(NB, side, side, C, seed=16)
+    sd = {"qkv.weight": _rand(3 * C, C, seed=17, scale=C ** -0.5), "qkv.bias": _rand(3 * C, seed=18, scale=0.1),
+          "proj.weight": torch.eye(C).to(BF), "proj.bias": torch.zeros(C).to(BF),
+          "rel_pos_h": _rand(39, hd, seed=19, scale=0.3), "rel_pos_w": _rand(39, hd, seed=20, scale=0.3)}
+    ref = O.sam_attention(sd, "", x, nH).reshape(NB * S, C)
+    qkv = F.linear(x.reshape(-1, C), sd["qkv.weight"], sd["qkv.bias"]).to(DEV)
+    strides = (S * 3 * C, hd, 3 * C)
+    vmax = float(qkv[:, 2 * C:].float().abs().max())
+    for win in (False, True):
+        vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd, win_kw=side if win else 0)
+        att = torch.empty(NB * S, C, device=DEV, dtype=BF)
+        ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
+                      q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side),
+                      win_padded=win)
+        assert_close_bf16(att, ref, ulps=2.0, what=f"sam attention, resized tables, row-padded={win}", outlier_frac=2e-3, outlier_floor=vmax)
+
+
 @pytest.mark.parametrize("side,hd,nH,NB", [(14, 80, 2, 3), (64, 80, 2, 1), (64, 32, 2, 1)])
 def test_sam_encoder_attention(side, hd, nH, NB):
     """windowed (196 keys, register kernel + bias) and global (4096 keys, single-pass streaming kernel + bias) SAM attention.

@@ -211,6 +211,32 @@ extern "C" int ULL_FN(ull_window_unpartition_add_)(const void* win, const void* 
     return ull_check_launch();
 }
 
+// image_encoder.py:336-343: F.interpolate(rel_pos[L, C] as [1, C, L], size = M, mode = "linear") -> [M, C], the resize get_rel_pos applies to
+// a table whose length is not 2 * size - 1 (a checkpoint trained at another input size).  Rounding as ATen's CPU kernel, which the
+// oracle runs: source index in fp32 (half-pixel centres, clamped at 0), the weight lambda rounded to the element type, 1 - lambda
+// rounded again, products and sum in fp32, one rounding of the result.
+namespace {
+__global__ __launch_bounds__(256) void interp_rows_linear_kernel(const elem_t* __restrict__ x, elem_t* __restrict__ y, int L, int M, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)M * C) return;
+    const int m = (int)(i / C), c = (int)(i % C);
+    const float scale = (float)L / (float)M;
+    float src = __fsub_rn(__fmul_rn(scale, (float)m + 0.5f), 0.5f);
+    if (src < 0.f) src = 0.f;
+    const int i0 = min((int)src, L - 1), i1 = min(i0 + 1, L - 1);
+    const float l1 = rnd(__fsub_rn(src, (float)i0));
+    const float l0 = rnd(__fsub_rn(1.0f, l1));
+    y[i] = f2e(__fadd_rn(__fmul_rn(l0, e2f(x[(long)i0 * C + c])), __fmul_rn(l1, e2f(x[(long)i1 * C + c]))));
+}
+}  // namespace
+
+extern "C" int ULL_FN(ull_interp_rows_linear_)(const void* x, void* y, int64_t L, int64_t M, int64_t C, void* stream) {
+    if (!x || !y || L <= 0 || M <= 0 || C <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(interp_rows_linear_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x,
+                       (elem_t*)y, (int)L, (int)M, (int)C);
+    return ull_check_launch();
+}
+
 extern "C" int ULL_FN(ull_sam_relpos_)(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w,
                                    void* out_h, void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream) {
     if (!q || !rel_pos_h || !rel_pos_w || !out_h || !out_w || NB <= 0) return ULL_ERR_ARG;

@@ -286,6 +286,27 @@ def clip_embed_ln(patch: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, w: 
     return out
 
 
+_REL_POS_CACHE: dict = {}
+
+
+def fit_rel_pos(rel_pos: torch.Tensor, size: int) -> torch.Tensor:
+    """get_rel_pos's resize (image_encoder.py:333-345): a table whose length is not 2 * size - 1 is linearly interpolated to that length.
+    The resized copy is kept per (storage, version, size): the tables are weights."""
+    n = 2 * size - 1
+    if rel_pos.shape[0] == n:
+        return rel_pos
+    _chk(rel_pos, "rel_pos")
+    key = (rel_pos.data_ptr(), rel_pos._version, tuple(rel_pos.shape), rel_pos.dtype, n)
+    hit = _REL_POS_CACHE.get(key)
+    if hit is None:
+        if len(_REL_POS_CACHE) > 256:
+            _REL_POS_CACHE.clear()
+        hit = torch.empty(n, rel_pos.shape[1], device=rel_pos.device, dtype=rel_pos.dtype)
+        _lib.call("ull_interp_rows_linear_" + _SFX[rel_pos.dtype], _p(rel_pos.contiguous()), _p(hit), rel_pos.shape[0], n, rel_pos.shape[1], _stream())
+        _REL_POS_CACHE[key] = hit
+    return hit
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Sq: int, Sk: int, hd: int,
               q_strides, k_strides, o_strides, key_mask: Optional[torch.Tensor] = None, causal: bool = False, scale_mode: int = 1,
               scale: float = 1.0, q_scale: float = 1.0, rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None,
@@ -299,8 +320,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
         _chk(rel_h, "rel_h", q.dtype); _chk(rel_w, "rel_w", q.dtype)
         if rel_pos_hw is not None:
             rel_mode, (kh, kw) = (3 if win_padded else 2), rel_pos_hw
-            if rel_h.shape[0] != 2 * kh - 1 or rel_w.shape[0] != 2 * kw - 1 or rel_h.shape[1] != hd:
-                raise NotImplementedError("rel_pos interpolation (image_encoder.py:336-343) is not needed for 1024x1024 SAM inputs")
+            rel_h, rel_w = fit_rel_pos(rel_h, kh), fit_rel_pos(rel_w, kw)
+            if rel_h.shape[1] != hd or rel_w.shape[1] != hd:
+                raise ValueError(f"rel_pos tables of width {rel_h.shape[1]} / {rel_w.shape[1]} for head_dim {hd}")
         else:
             rel_mode, kh, kw = 1, rel_h.shape[-1], rel_w.shape[-1]
     if key_mask is not None:
@@ -452,8 +474,7 @@ def window_unpartition_add(win: torch.Tensor, shortcut: torch.Tensor, B: int, H:
 
 def sam_relpos(q: torch.Tensor, q_strides, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, NB: int, nH: int, KH: int, KW: int, hd: int):
     _chk(q, "q"); _chk(rel_pos_h, "rel_pos_h", q.dtype); _chk(rel_pos_w, "rel_pos_w", q.dtype)
-    if rel_pos_h.shape[0] != 2 * KH - 1 or rel_pos_w.shape[0] != 2 * KW - 1:
-        raise NotImplementedError("rel_pos interpolation (image_encoder.py:336-343) is not needed for 1024x1024 SAM inputs")
+    rel_pos_h, rel_pos_w = fit_rel_pos(rel_pos_h, KH), fit_rel_pos(rel_pos_w, KW)
     oh = torch.empty(NB * nH, KH * KW, KH, device=q.device, dtype=q.dtype)
     ow = torch.empty(NB * nH, KH * KW, KW, device=q.device, dtype=q.dtype)
     _lib.call("ull_sam_relpos_" + _SFX[q.dtype], _p(q), *q_strides, _p(rel_pos_h), _p(rel_pos_w), _p(oh), _p(ow), NB, nH, KH, KW, hd, _stream())
