@@ -157,28 +157,27 @@ ULL_DEV f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
 
 // ---- activations (computed in fp32 on a 16-bit-rounded input, like torch's bf16 / fp16 CPU and GPU kernels)
 // GELU(erf) = 0.5 x (1 + erf(x / sqrt 2)), the formula torch evaluates in fp32 (ATen GeluKernel).  erf through the complementary
-// function of |z| in the Chebyshev form of Numerical Recipes' erfcc (fractional error < 1.2e-7 everywhere): branch-free, one rcp
-// (+ a Newton step), nine FMAs and one exp -- the library erff is two divergent branches and ~3x the instructions, which made the
+// function of |z| in the Chebyshev form of Numerical Recipes' erfcc (fractional error < 1.2e-7 everywhere): branch-free, one rcp,
+// nine FMAs and one exp -- the library erff is two divergent branches and ~3x the instructions, which made the
 // SAM MLP epilogue longer than its K-loop.  The inputs are 16-bit values, so the test is exhaustive: over all 51 022 normal bf16
 // inputs this differs from torch's CPU bf16 GELU in ~24 results, all in the tail x in [-5.4, -3.1] where |GELU| < 3e-3 and the
 // reference's own 1 + erf has lost its digits (torch's fp32 formula differs from torch's bf16 kernel in 27): tests/test_kernels_gpu.py.
 ULL_DEV float act_gelu_erf(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float a = fabsf(z);
-    const float d = fmaf(0.5f, a, 1.0f);
-    float t = __builtin_amdgcn_rcpf(d);
-    t = fmaf(fmaf(-d, t, 1.0f), t, t);                   // 1 / (1 + |z| / 2) to half an ulp
-    float p = 0.17087277f;
-    p = fmaf(t, p, -0.82215223f);
-    p = fmaf(t, p, 1.48851587f);
-    p = fmaf(t, p, -1.13520398f);
-    p = fmaf(t, p, 0.27886807f);
-    p = fmaf(t, p, -0.18628806f);
-    p = fmaf(t, p, 0.09678418f);
-    p = fmaf(t, p, 0.37409196f);
-    p = fmaf(t, p, 1.00002368f);
-    const float ec = t * __expf(fmaf(-a, a, fmaf(t, p, -1.26551223f)));   // erfc(|z|)
-    const float erf = z >= 0.0f ? 1.0f - ec : ec - 1.0f;
+    // a = |z| sqrt(log2 e) with z = x / sqrt 2, and every polynomial coefficient times log2 e: the exponential is then a bare v_exp_f32
+    const float a = fabsf(x) * 0.8493218002880191f;
+    const float d = fmaf(0.41627730557884884f, a, 1.0f);
+    const float t = __builtin_amdgcn_rcpf(d);            // 1 / (1 + |z| / 2): the 1-ulp reciprocal is enough (a Newton step changes no result)
+    float p = 0.24651729790196045f;
+    p = fmaf(t, p, -1.1861149450768025f);
+    p = fmaf(t, p, 2.147474463933521f);
+    p = fmaf(t, p, -1.637753152343414f);
+    p = fmaf(t, p, 0.40232158165127635f);
+    p = fmaf(t, p, -0.2687568603388257f);
+    p = fmaf(t, p, 0.1396300565225048f);
+    p = fmaf(t, p, 0.5397006155284324f);
+    p = fmaf(t, p, 1.4427292039075317f);
+    const float ec = t * __builtin_amdgcn_exp2f(fmaf(-a, a, fmaf(t, p, -1.825748218405333f)));   // erfc(|z|)
+    const float erf = __builtin_copysignf(1.0f - ec, x);  // 1 - ec >= 0: one v_bfi instead of compare + two subtractions + select
     return 0.5f * x * (1.0f + erf);
 }
 ULL_DEV float act_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
