@@ -184,6 +184,14 @@ int ull_window_unpartition_add_bf16(const void* win, const void* shortcut, void*
 int ull_sam_relpos_bf16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w, void* out_h,
                         void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
 
+/* image_encoder.py:176-190 (Block.forward between norm1 and proj) for the 14 x 14 windows, on tokens that stay in IMAGE order:
+ * window_partition with its zero padding + Attention with the decomposed rel-pos bias + window_unpartition.  qkv [B*H*W, ld] rows
+ * q|k|v of 3*nH*hd, out [B*H*W, ldo]; pad_row = the q|k|v row of a padded token = the qkv bias (the reference pads the normalised
+ * activations with zeros); rel_pos_h / rel_pos_w [27, hd]; vt_scratch: B*ceil(H/14)*ceil(W/14)*nH*hd*256 elements.  ws = 14, hd = 80. */
+int ull_sam_window_attention_bf16(const void* qkv, int64_t ld, const void* pad_row, const void* rel_pos_h, const void* rel_pos_w, void* out,
+                                  int64_t ldo, void* vt_scratch, int64_t B, int64_t H, int64_t W, int64_t nH, int64_t hd, int64_t ws,
+                                  float q_scale, const void* zeros, void* stream);
+
 /* image_encoder.py:336-343: the linear resize get_rel_pos applies to a rel-pos table whose length differs from 2*size-1:
  * x [L, C] -> y [M, C] = F.interpolate(x as [1, C, L], size = M, mode = "linear") with ATen's CPU rounding (weights rounded to the element type). */
 int ull_interp_rows_linear_bf16(const void* x, void* y, int64_t L, int64_t M, int64_t C, void* stream);
@@ -388,6 +396,7 @@ int ull_add_rows_f16(const void* a, const void* b, void* out, int64_t rows, int6
 int ull_window_partition_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
 int ull_window_unpartition_add_f16(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
 int ull_sam_relpos_f16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w, void* out_h, void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
+int ull_sam_window_attention_f16(const void* qkv, int64_t ld, const void* pad_row, const void* rel_pos_h, const void* rel_pos_w, void* out, int64_t ldo, void* vt_scratch, int64_t B, int64_t H, int64_t W, int64_t nH, int64_t hd, int64_t ws, float q_scale, const void* zeros, void* stream);
 int ull_interp_rows_linear_f16(const void* x, void* y, int64_t L, int64_t M, int64_t C, void* stream);
 int ull_layernorm2d_cl_f16(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu, void* stream);
 int ull_im2col3x3_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);

@@ -93,6 +93,40 @@ def test_sam_attention_with_tables_of_another_length():
         assert_close_bf16(att, ref, ulps=2.0, what=f"sam attention, resized tables, row-padded={win}", outlier_frac=2e-3, outlier_floor=vmax)
 
 
+@pytest.mark.parametrize("H,W", [(20, 20), (28, 14), (31, 17)])
+def test_window_attention_on_image_order_tokens(H, W):
+    """ull_sam_window_attention (tokens stay in image order; the kernel does the window addressing and reads the zero-padded positions'
+    q|k|v from the qkv bias) against window_partition -> qkv Linear -> attention -> window_unpartition: identical bits, and against
+    the oracle's Block-level arithmetic."""
+    ops = pkg("ops")
+    B, nH, hd, ws = 2, 2, 80, 14
+    C = nH * hd
+    y = _rand(B, H, W, C, seed=31).to(DEV)                      # norm1 output
+    w, b = _rand(3 * C, C, seed=32, scale=C ** -0.5).to(DEV), _rand(3 * C, seed=33, scale=0.3).to(DEV)
+    rph, rpw = _rand(27, hd, seed=34, scale=0.3).to(DEV), _rand(27, hd, seed=35, scale=0.3).to(DEV)
+    # the window-major chain
+    yw = ops.window_partition(y.view(-1, C), B, H, W, ws)
+    NB, S = yw.shape[0] // (ws * ws), ws * ws
+    qkv_w = ops.linear(yw, w, b)
+    strides = (S * 3 * C, hd, 3 * C)
+    vt = ops.transpose_v(qkv_w[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd, win_kw=ws)
+    att_w = torch.empty(NB * S, C, device=DEV, dtype=BF)
+    ops.attention(qkv_w, qkv_w[:, C:], vt, att_w, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
+                  q_scale=hd ** -0.5, rel_h=rph, rel_w=rpw, rel_pos_hw=(ws, ws), win_padded=True)
+    ref = ops.window_unpartition_add(att_w, torch.zeros(B * H * W, C, device=DEV, dtype=BF), B, H, W, ws)
+    # image order
+    qkv = ops.linear(y.view(-1, C), w, b)
+    got = ops.sam_window_attention(qkv, b, rph, rpw, B, H, W, nH, hd, ws)
+    assert torch.equal(got, ref)
+    # and the oracle (proj = identity)
+    sd = {"qkv.weight": w.cpu(), "qkv.bias": b.cpu(), "proj.weight": torch.eye(C).to(BF), "proj.bias": torch.zeros(C).to(BF),
+          "rel_pos_h": rph.cpu(), "rel_pos_w": rpw.cpu()}
+    xw, pad_hw = O.window_partition(y.cpu(), ws)
+    o = O.window_unpartition(O.sam_attention(sd, "", xw, nH), ws, pad_hw, (H, W)).reshape(B * H * W, C)
+    vmax = float(qkv[:, 2 * C:].float().abs().max())
+    assert_close_bf16(got, o, ulps=2.0, what="window attention on image-order tokens", outlier_frac=2e-3, outlier_floor=vmax)
+
+
 @pytest.mark.parametrize("side,hd,nH,NB", [(14, 80, 2, 3), (64, 80, 2, 1), (64, 32, 2, 1)])
 def test_sam_encoder_attention(side, hd, nH, NB):
     """windowed (196 keys, register kernel + bias) and global (4096 keys, single-pass streaming kernel + bias) SAM attention.

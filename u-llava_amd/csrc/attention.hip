@@ -39,7 +39,19 @@ struct AttnArgs {
                                         //    [2KH-1,hd] / [2KW-1,hd] and the tables are built in the kernel prologue on the MFMA
     float inv_kw;                       // 1 / KW
     float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
+    // WIN16 on image-order tokens (ull_sam_window_attention): Q / K / O rows are tokens of [img, img_h, img_w] grids, "batch" b is
+    // window (img, wy, wx) of the 14 x 14 partition, and window positions outside the grid are the reference's zero padding
+    // (image_encoder.py:262-289 pads AFTER norm1, so a padded token's q|k|v is the qkv bias): K rows of such keys come from k_pad.
+    int img_h, img_w, nwy, nwx;         // img_w == 0: window-major tokens as everywhere else
+    const elem_t* k_pad;                // K part of the pad token's row (+ h * k_hs)
 };
+
+// token index (in image order) of position (ly, lx) of window b, or -1 for a padding position
+ULL_DEV long win_token(const AttnArgs& p, int b, int ly, int lx, int ws) {
+    const int wx = b % p.nwx, wy = (b / p.nwx) % p.nwy, img = b / (p.nwx * p.nwy);
+    const int iy = wy * ws + ly, ix = wx * ws + lx;
+    return (iy < p.img_h && ix < p.img_w) ? ((long)img * p.img_h + iy) * p.img_w + ix : -1;
+}
 
 // Compile-time "flavors" of the score epilogue.  The runtime-flag version (FL_RUNTIME) costs ~6 wave-uniform branches per
 // score element, which fragments the schedule (measured: SAM global attention 12 ms -> see profiles/); the hot callers
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     const int nkt = EXACT ? NT : (kend + KT - 1) / KT;          // tiles this block streams
     int kend_w = p.Sk;
     if (p.causal) kend_w = min(p.Sk, q0 + wave * 16 + 16 + koff);
-    const int nkt_w = EXACT ? NT : (q0 + wave * 16 < p.Sq) ? max(1, (kend_w + KT - 1) / KT) : 0;   // tiles this wave computes on
+    int nkt_w = EXACT ? NT : (q0 + wave * 16 < p.Sq) ? max(1, (kend_w + KT - 1) / KT) : 0;   // tiles this wave computes on
 
     const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
     const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
@@ -285,11 +297,18 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                     const int row = i * (64 / CPR) + lane / CPR;
                     const int c = (lane % CPR) ^ swz<CPR>(row);
                     int key = min(kt * KT + row, p.Sk - 1);
+                    const elem_t* krow = nullptr;
                     if constexpr (WIN16) {           // slot 16 * kh + kw <- key kh * KW + kw (padding slots read a real key and are masked)
                         const int slot = kt * KT + row;
-                        key = min(slot >> 4, WKH - 1) * WKW + min(slot & 15, WKW - 1);
+                        const int kh = min(slot >> 4, WKH - 1), kw = min(slot & 15, WKW - 1);
+                        key = kh * WKW + kw;
+                        if (p.img_w > 0) {
+                            const long tok = win_token(p, b, kh, kw, WKW);
+                            krow = tok >= 0 ? p.K + tok * p.k_ss + (long)h * p.k_hs : p.k_pad + (long)h * p.k_hs;
+                        }
                     }
-                    const elem_t* src = (c * 8 < hd) ? kbase + (long)key * p.k_ss + c * 8 : p.zeros;
+                    if (krow == nullptr) krow = kbase + (long)key * p.k_ss;
+                    const elem_t* src = (c * 8 < hd) ? krow + c * 8 : p.zeros;
                     glds16(src, dst + i * 1024);
                 }
             }
@@ -316,12 +335,20 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     // ---- Q fragments + key-mask bytes (ordinary loads; drained before any DMA is issued) ---------------
     uint4 qf[NKS];
     const int qi = q0 + wave * 16 + fr;
+    long q_tok = 0;                       // WIN16 on image-order tokens: this lane's query token, -1 = a padding position
+    if constexpr (WIN16) {
+        if (p.img_w > 0) {
+            q_tok = qi < p.Sq ? win_token(p, b, qi / WKW, qi % WKW, WKW) : -1;
+            if (__builtin_amdgcn_ballot_w64(q_tok >= 0) == 0) nkt_w = 0;     // 16 padding positions: barriers and DMA only
+        }
+    }
     {
         const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
+        if (WIN16 && p.img_w > 0) qp = p.Q + max(q_tok, 0L) * p.q_ss + (long)h * p.q_hs;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
-            qf[ks] = (qi < p.Sq && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+            qf[ks] = (qi < p.Sq && q_tok >= 0 && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
         }
         if constexpr (!WIN16)
         for (int j = tid; j < nkt * KT; j += NWV * 64) {
@@ -426,6 +453,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float sum = 0.f;
         if constexpr (WIN16) {
+            if (nkt_w > 0) {
             // 56 scores per lane: the exponentials fit in registers, so each is evaluated once (the generic form evaluates it for
             // the sum and again for P because a long row does not fit)
             float e[NBLK * 4];
@@ -441,6 +469,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int i = 0; i < NBLK * 2; ++i) sp[i / 8][i % 8] = pack2e(e[2 * i] * inv, e[2 * i + 1] * inv);
+            }
         } else {
 #pragma clang loop unroll(full)
         for (int kt = 0; kt < NT; ++kt)
@@ -508,8 +537,9 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             }
         }
     }
-    if (qi < p.Sq) {
+    if (qi < p.Sq && q_tok >= 0) {
         elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
+        if (WIN16 && p.img_w > 0) op = p.O + q_tok * p.o_ss + (long)h * p.o_hs;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
             if (ds * 16 < hd) {
@@ -1238,8 +1268,11 @@ __global__ __launch_bounds__(256) void rope_append_kernel(elem_t* __restrict__ q
 // have after the swapped QK^T MFMA -- so P*V needs no cross-lane movement.  64(s) x 64(d) tiles through LDS.
 // win_kw > 0 (ull_transpose_v_win): the key axis of Vt is slot = 16 * (key / win_kw) + key % win_kw -- every window row padded to 16
 // slots (zeros in the padding) -- which is the key order of the WIN16 attention kernel.
+// img.w > 0 (ull_sam_window_attention): v rows are image-order tokens, block b is window (img, wy, wx) and a window position outside
+// the grid reads the pad token's v (img.pad).
+struct WinImage { int h, w, nwy, nwx; const elem_t* pad; };
 __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restrict__ v, long v_bs, long v_ss, elem_t* __restrict__ vt, int S,
-                                                          int H, int hd, int pitch, int win_kw) {
+                                                          int H, int hd, int pitch, int win_kw, WinImage img) {
     __shared__ __attribute__((aligned(16))) elem_t t[64][68];            // [d][key]; 136-byte rows keep the 8-byte reads aligned
     const int b = blockIdx.z / H, h = blockIdx.z % H;
     const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
@@ -1252,6 +1285,14 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restri
         uint4 val = make_uint4(0, 0, 0, 0);
         int key = s0 + sl;
         if (win_kw > 0) key = (key & 15) < win_kw ? (key >> 4) * win_kw + (key & 15) : S;
+        if (img.w > 0) {
+            if (key < S && d0 + dc < hd) {
+                const int wx = b % img.nwx, wy = (b / img.nwx) % img.nwy, im = b / (img.nwx * img.nwy);
+                const int iy = wy * win_kw + key / win_kw, ix = wx * win_kw + key % win_kw;
+                const elem_t* src = (iy < img.h && ix < img.w) ? v + (((long)im * img.h + iy) * img.w + ix) * v_ss : img.pad;
+                val = *(const uint4*)(src + (long)h * hd + d0 + dc);
+            }
+        } else
         if (key < S && d0 + dc < hd) val = *(const uint4*)(vp + (long)key * v_ss + d0 + dc);
         const uint32_t w[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
@@ -1419,6 +1460,7 @@ extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs,
     a.inv_kw = rel_kw > 0 ? 1.0f / (float)rel_kw : 0.f;
     a.rel_mode = rel_h ? (rel_mode == 3 ? 2 : rel_mode) : 0;
     a.win16 = rel_h && rel_mode == 3;
+    a.img_h = a.img_w = a.nwy = a.nwx = 0; a.k_pad = nullptr;
     if (rel_h && (rel_mode < 1 || rel_mode > 3)) return ULL_ERR_ARG;
     if ((rel_h == nullptr) != (rel_w == nullptr)) return ULL_ERR_ARG;
     if (rel_h && (rel_kh <= 0 || rel_kw <= 0 || rel_kh + rel_kw > 256 || rel_kh * rel_kw < Sk)) return ULL_ERR_SHAPE;
@@ -1480,7 +1522,7 @@ extern "C" int ULL_FN(ull_transpose_v_)(const void* v, int64_t v_bs, int64_t v_s
     if (pitch < S || (pitch & 63)) return ULL_ERR_SHAPE;
     const dim3 grid((unsigned)((pitch + 63) / 64), (unsigned)((hd + 63) / 64), (unsigned)(B * H));
     hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const elem_t*)v, v_bs, v_ss, (elem_t*)vt, (int)S, (int)H,
-                       (int)hd, (int)pitch, 0);
+                       (int)hd, (int)pitch, 0, WinImage{0, 0, 0, 0, nullptr});
     return ull_check_launch();
 }
 
@@ -1491,6 +1533,42 @@ extern "C" int ULL_FN(ull_transpose_v_win_)(const void* v, int64_t v_bs, int64_t
     if (kw <= 0 || kw > 16 || S % kw || pitch < (S / kw) * 16 || (pitch & 63)) return ULL_ERR_SHAPE;
     const dim3 grid((unsigned)((pitch + 63) / 64), (unsigned)((hd + 63) / 64), (unsigned)(B * H));
     hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const elem_t*)v, v_bs, v_ss, (elem_t*)vt, (int)S, (int)H,
-                       (int)hd, (int)pitch, (int)kw);
+                       (int)hd, (int)pitch, (int)kw, WinImage{0, 0, 0, 0, nullptr});
     return ull_check_launch();
+}
+
+// image_encoder.py Block.forward :176-190 between norm1 and the projection, for the 14 x 14 windows: window_partition (zero padding
+// included) + Attention (decomposed rel-pos) + window_unpartition, on tokens that stay in IMAGE order.  qkv [B*H*W, 3*nH*hd] rows
+// q|k|v (ld elements apart), out [B*H*W, nH*hd]; pad_row = the q|k|v row of a padded token = the qkv bias (the reference pads the
+// normalised activations with zeros, so Linear gives exactly its bias there); rel_pos_h / rel_pos_w [27, hd]; vt_scratch
+// [B * ceil(H/14) * ceil(W/14) * nH * hd * 256] elements.  The GEMMs either side then run on H*W rows per image instead of the
+// padded 25 * 196 (+19.6 % at 64 x 64), and the two re-ordering passes disappear.
+extern "C" int ULL_FN(ull_sam_window_attention_)(const void* qkv, int64_t ld, const void* pad_row, const void* rel_pos_h, const void* rel_pos_w,
+                                             void* out, int64_t ldo, void* vt_scratch, int64_t B, int64_t Hh, int64_t Ww, int64_t nH, int64_t hd,
+                                             int64_t ws, float q_scale, const void* zeros, void* stream) {
+    if (!qkv || !pad_row || !rel_pos_h || !rel_pos_w || !out || !vt_scratch || !zeros || B <= 0 || Hh <= 0 || Ww <= 0 || nH <= 0) return ULL_ERR_ARG;
+    if (ws != 14 || hd != 80 || (ld & 7) || (ldo & 3) || ld < 3 * nH * hd || ldo < nH * hd) return ULL_ERR_SHAPE;
+    const int nwy = (int)((Hh + ws - 1) / ws), nwx = (int)((Ww + ws - 1) / ws);
+    const long NB = B * nwy * nwx;
+    const int C = (int)(nH * hd), S = (int)(ws * ws), pitch = 256;
+    const elem_t* base = (const elem_t*)qkv;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(pitch / 64), (unsigned)((hd + 63) / 64), (unsigned)(NB * nH));
+    hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, st, base + 2 * C, 0L, (long)ld, (elem_t*)vt_scratch, S, (int)nH, (int)hd, pitch,
+                       (int)ws, WinImage{(int)Hh, (int)Ww, nwy, nwx, (const elem_t*)pad_row + 2 * C});
+    AttnArgs a;
+    a.Q = base; a.K = base + C; a.Vt = (const elem_t*)vt_scratch; a.O = (elem_t*)out;
+    a.key_mask = nullptr;
+    a.q_bs = 0; a.q_hs = hd; a.q_ss = ld; a.k_bs = 0; a.k_hs = hd; a.k_ss = ld;
+    a.vt_bs = nH * hd * pitch; a.vt_hs = hd * pitch; a.vt_ds = pitch; a.o_bs = 0; a.o_hs = hd; a.o_ss = ldo;
+    a.B = (int)NB; a.H = (int)nH; a.Sq = S; a.Sk = S; a.hd = (int)hd; a.vt_len = pitch;
+    a.causal = 0; a.scale_mode = 0; a.scale = 1.0f;
+    a.zeros = (const elem_t*)zeros;
+    a.rel_h = (const elem_t*)rel_pos_h; a.rel_w = (const elem_t*)rel_pos_w; a.KH = (int)ws; a.KW = (int)ws; a.q_scale = q_scale;
+    a.inv_kw = 1.0f / (float)ws;
+    a.rel_mode = 2; a.win16 = 1;
+    a.img_h = (int)Hh; a.img_w = (int)Ww; a.nwy = nwy; a.nwx = nwx; a.k_pad = (const elem_t*)pad_row + C;
+    const int rc = ull_check_launch();
+    if (rc != ULL_OK) return rc;
+    return dispatch_nt<128>(a, st);
 }

@@ -334,6 +334,23 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     return out
 
 
+def sam_window_attention(qkv: torch.Tensor, pad_row: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, B: int, H: int, W: int,
+                         nH: int, hd: int, ws: int) -> torch.Tensor:
+    """Block.forward's window_partition + Attention + window_unpartition (image_encoder.py:176-190) on image-order tokens:
+    qkv [B*H*W, 3*nH*hd] -> [B*H*W, nH*hd].  pad_row: the qkv bias (= the q|k|v of a zero-padded token)."""
+    _chk(qkv, "qkv"); _chk(pad_row, "pad_row", qkv.dtype); _chk(rel_pos_h, "rel_pos_h", qkv.dtype); _chk(rel_pos_w, "rel_pos_w", qkv.dtype)
+    rel_pos_h, rel_pos_w = fit_rel_pos(rel_pos_h, ws), fit_rel_pos(rel_pos_w, ws)
+    C = nH * hd
+    if qkv.shape != (B * H * W, 3 * C) or pad_row.numel() != 3 * C:
+        raise ValueError(f"qkv {tuple(qkv.shape)} / pad_row {tuple(pad_row.shape)} for B={B} H={H} W={W} C={C}")
+    nw = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
+    vt = torch.empty(B * nw * nH * hd * 256, device=qkv.device, dtype=qkv.dtype)
+    out = torch.empty(B * H * W, C, device=qkv.device, dtype=qkv.dtype)
+    _lib.call("ull_sam_window_attention_" + _SFX[qkv.dtype], _p(qkv), 3 * C, _p(pad_row), _p(rel_pos_h), _p(rel_pos_w), _p(out), C, _p(vt),
+              B, H, W, nH, hd, ws, float(hd ** -0.5), _zeros(qkv.device).data_ptr(), _stream())
+    return out
+
+
 def rope_inplace(x: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_freq: torch.Tensor, tokens: int, n_heads: int, hd: int):
     _chk(x, "x"); _chk(positions, "positions", torch.int64); _chk(inv_freq, "inv_freq", torch.float32)
     _lib.call("ull_rope_inplace_" + _SFX[x.dtype], _p(x), row_stride, _p(positions), _p(inv_freq), tokens, n_heads, hd, _stream())
