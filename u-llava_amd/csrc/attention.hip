@@ -67,7 +67,7 @@ constexpr int FL_SAM_DEC = 3;    // S / sqrt(hd)                                
 //   brow   = this query's bias row in LDS, rel_h(kh) = brow[bh_off - kh], rel_w(kw) = brow[bw_off - kw]; or null
 template <int FL>
 ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t mk, int qi, int koff, const elem_t* brow, int bh_off,
-                        int bw_off, uint32_t& lo, uint32_t& hi) {
+                        int bw_off, uint32_t& lo, uint32_t& hi, float* row_max = nullptr) {
     const bool do_mul = FL == FL_RUNTIME ? p.scale_mode == 1 : (FL == FL_LLAMA || FL == FL_CLIP);
     const bool do_div = FL == FL_RUNTIME ? p.scale_mode == 2 : (FL == FL_SAM_DEC);
     const bool do_bias = FL == FL_RUNTIME ? brow != nullptr : (FL == FL_SAM_ENC);
@@ -88,6 +88,7 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
         const bool allowed = (mb == 1) && (!do_causal || j <= qi + koff);
         o[r] = (mb == 2) ? -INFINITY : (allowed ? sv : ELEM_MIN_F);   // -inf / finfo(bf16).min, exact in bf16
     }
+    if (row_max) *row_max = fmaxf(fmaxf(*row_max, fmaxf(o[0], o[1])), fmaxf(o[2], o[3]));   // values are already 16-bit exact
     lo = pack2e(o[0], o[1]);
     hi = pack2e(o[2], o[3]);
 }
@@ -95,7 +96,7 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
 // The same for a quad whose four keys are all attendable for every lane of the wave (no padding, below the causal diagonal, no
 // bias): only the scale + the two roundings remain.  ~85 % of the LLaMA / CLIP score quads take this path.
 template <int FL>
-ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& lo, uint32_t& hi) {
+ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& lo, uint32_t& hi, float* row_max = nullptr) {
     const bool do_mul = FL == FL_RUNTIME ? p.scale_mode == 1 : (FL == FL_LLAMA || FL == FL_CLIP);
     const bool do_div = FL == FL_RUNTIME ? p.scale_mode == 2 : (FL == FL_SAM_DEC);
     float o[4];
@@ -106,6 +107,7 @@ ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& l
         if (do_div) sv = rnd(sv / p.scale);
         o[r] = sv;
     }
+    if (row_max) *row_max = fmaxf(fmaxf(*row_max, fmaxf(o[0], o[1])), fmaxf(o[2], o[3]));
     lo = pack2e(o[0], o[1]);
     hi = pack2e(o[2], o[3]);
 }
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float wv[4] = {0.f, 0.f, 0.f, 0.f};   // WIN16: rel_w of this lane's four window columns kw = 4 * fg + r (same for every block)
-    float mrow = -INFINITY;               // WIN16: running maximum of this lane's scores
+    float mrow = -INFINITY;               // running maximum of this lane's scores
     if constexpr (WIN16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) wv[r] = e2f(brow[bw_off - min(fg * 4 + r, WKW - 1)]);
@@ -428,8 +430,9 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                         const bool dirty = mk != 0x01010101u || (FL == FL_LLAMA && j0 + 3 > qi + koff);
                         fast = __builtin_amdgcn_ballot_w64(dirty) == 0;     // wave-uniform
                     }
-                    if (fast) score_quad_clean<FL>(p, acc, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
-                    else score_quad<FL>(p, acc, j0, mk, qi, koff, brow, bh_off, bw_off, sp[kt][ns * 2], sp[kt][ns * 2 + 1]);
+                    // the row maximum is taken here, on the fp32 copies of the 16-bit scores (phase 2 would unpack them again)
+                    if (fast) score_quad_clean<FL>(p, acc, sp[kt][ns * 2], sp[kt][ns * 2 + 1], &mrow);
+                    else score_quad<FL>(p, acc, j0, mk, qi, koff, brow, bh_off, bw_off, sp[kt][ns * 2], sp[kt][ns * 2 + 1], &mrow);
                     if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -439,16 +442,6 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     // ---- phase 2: exact fp32 row softmax over the bf16 scores, P = bf16(softmax) (registers only) --------
     {
         float m = mrow;
-        if constexpr (!WIN16)
-#pragma clang loop unroll(full)
-        for (int kt = 0; kt < NT; ++kt)
-            if (kt < nkt_w) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    m = fmaxf(m, pk_lo(sp[kt][i]));
-                    m = fmaxf(m, pk_hi(sp[kt][i]));
-                }
-            }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float sum = 0.f;
