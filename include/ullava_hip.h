@@ -109,9 +109,8 @@ int ull_clip_embed_ln_bf16(const void* patch, int64_t ldp, const void* cls, cons
  * multiplies after the matmul like both.  SAM encoder (image_encoder.py:235-260,354-392): q_scale = hd^-0.5 applied to Q
  * as a bf16 tensor op, scale_mode 0, and the decomposed rel-pos bias added to the bf16 scores (rel_h then rel_w): rel_mode 1 =
  * rel_h [B*H,Sq,rel_kh] / rel_w [B*H,Sq,rel_kw] precomputed (ull_sam_relpos_bf16); rel_mode 2 = rel_h/rel_w are the module's raw
- * rel_pos_h [2*rel_kh-1,hd] / rel_pos_w [2*rel_kw-1,hd] parameters and the kernel builds the tables itself on the MFMA; rel_mode 3 =
- * as 2 for the 14 x 14 windows (rel_kh = rel_kw = 14, Sk = 196, hd = 80, no key_mask) with Vt written by ull_transpose_v_win_bf16
- * (window rows padded to 16 key slots: the bias indices become per-lane constants).  SAM decoder (transformer.py:220-242): scale_mode 2 divides by sqrt(hd).
+ * rel_pos_h [2*rel_kh-1,hd] / rel_pos_w [2*rel_kw-1,hd] parameters and the kernel builds the tables itself on the MFMA (the 14 x 14
+ * windows have their own entry, ull_sam_window_attention_bf16).  SAM decoder (transformer.py:220-242): scale_mode 2 divides by sqrt(hd).
  * Q/K: [B,H,S,hd] by strides, hd contiguous.  Vt: [B,H,hd,vt_len] as written by ull_transpose_v_bf16 (vt_len % 64 == 0).
  * key_mask: int32 [B,Sk] (nonzero = attend) or NULL.  zeros: >= 16 readable zero bytes (head-dim padding source). */
 int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs, int64_t k_ss,
@@ -135,11 +134,6 @@ int ull_rope_append_bf16(void* qkv, int64_t row_stride, const void* positions, c
  * (slot 8g+4a+r <- key 16a+4g+r): the K-contiguous A-operand layout of P*V matching the P register layout. */
 int ull_transpose_v_bf16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch,
                          void* stream);
-
-/* The same for ull_attention_bf16's rel_mode 3: S = kh*kw keys of a window, key kh*kw_+c stored at slot 16*kh+c (kw <= 16, zeros in the
- * padding slots, pitch >= 16*S/kw), then the same 32-slot permutation. */
-int ull_transpose_v_win_bf16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch,
-                             int64_t kw, void* stream);
 
 /* Patch extraction for conv(kernel = stride = ps): out[(img,py,px)][(c*ps+ky)*ps+kx], zero padded to Kp columns.
  * hf: CLIPVisionEmbeddings.patch_embedding; segment_anything/modeling/image_encoder.py:395-426 (PatchEmbed). */
@@ -185,12 +179,12 @@ int ull_sam_relpos_bf16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss,
                         void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
 
 /* image_encoder.py:176-190 (Block.forward between norm1 and proj) for the 14 x 14 windows, on tokens that stay in IMAGE order:
- * window_partition with its zero padding + Attention with the decomposed rel-pos bias + window_unpartition.  qkv [B*H*W, ld] rows
- * q|k|v of 3*nH*hd, out [B*H*W, ldo]; pad_row = the q|k|v row of a padded token = the qkv bias (the reference pads the normalised
- * activations with zeros); rel_pos_h / rel_pos_w [27, hd]; vt_scratch: B*ceil(H/14)*ceil(W/14)*nH*hd*256 elements.  ws = 14, hd = 80. */
+ * window_partition with its zero padding + Attention with the decomposed rel-pos bias + window_unpartition, one launch.  qkv
+ * [B*H*W, ld] rows q|k|v of 3*nH*hd, out [B*H*W, ldo]; pad_row = the q|k|v row of a padded token = the qkv bias (the reference pads
+ * the normalised activations with zeros); rel_pos_h / rel_pos_w [27, hd].  ws = 14, hd = 80; no V^T image is needed. */
 int ull_sam_window_attention_bf16(const void* qkv, int64_t ld, const void* pad_row, const void* rel_pos_h, const void* rel_pos_w, void* out,
-                                  int64_t ldo, void* vt_scratch, int64_t B, int64_t H, int64_t W, int64_t nH, int64_t hd, int64_t ws,
-                                  float q_scale, const void* zeros, void* stream);
+                                  int64_t ldo, int64_t B, int64_t H, int64_t W, int64_t nH, int64_t hd, int64_t ws, float q_scale,
+                                  const void* zeros, void* stream);
 
 /* image_encoder.py:336-343: the linear resize get_rel_pos applies to a rel-pos table whose length differs from 2*size-1:
  * x [L, C] -> y [M, C] = F.interpolate(x as [1, C, L], size = M, mode = "linear") with ATen's CPU rounding (weights rounded to the element type). */
@@ -387,7 +381,6 @@ int ull_attention_f16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, c
 int ull_rope_inplace_f16(void* x, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads, int64_t hd, void* stream);
 int ull_rope_append_f16(void* qkv, int64_t row_stride, const void* positions, const void* inv_freq, int64_t B, int64_t S, int64_t H, int64_t hd, void* k_cache, void* vt_cache, int64_t smax, int64_t past, void* stream);
 int ull_transpose_v_f16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch, void* stream);
-int ull_transpose_v_win_f16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch, int64_t kw, void* stream);
 int ull_im2col_f16(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp, void* stream);
 int ull_embed_splice_f16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
 int ull_video_pool_f16(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch, int64_t tok_off, void* stream);
@@ -396,7 +389,7 @@ int ull_add_rows_f16(const void* a, const void* b, void* out, int64_t rows, int6
 int ull_window_partition_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
 int ull_window_unpartition_add_f16(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
 int ull_sam_relpos_f16(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w, void* out_h, void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
-int ull_sam_window_attention_f16(const void* qkv, int64_t ld, const void* pad_row, const void* rel_pos_h, const void* rel_pos_w, void* out, int64_t ldo, void* vt_scratch, int64_t B, int64_t H, int64_t W, int64_t nH, int64_t hd, int64_t ws, float q_scale, const void* zeros, void* stream);
+int ull_sam_window_attention_f16(const void* qkv, int64_t ld, const void* pad_row, const void* rel_pos_h, const void* rel_pos_w, void* out, int64_t ldo, int64_t B, int64_t H, int64_t W, int64_t nH, int64_t hd, int64_t ws, float q_scale, const void* zeros, void* stream);
 int ull_interp_rows_linear_f16(const void* x, void* y, int64_t L, int64_t M, int64_t C, void* stream);
 int ull_layernorm2d_cl_f16(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu, void* stream);
 int ull_im2col3x3_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);

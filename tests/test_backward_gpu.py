@@ -309,3 +309,35 @@ def test_transpose2d_is_exact(R, C, pad, dt):
     y = ops.transpose2d(x)
     assert y.shape == (C, R) and y.is_contiguous()
     assert torch.equal(y.cpu(), x.cpu().t().contiguous())
+
+
+def test_weight_caches_are_keyed_by_tensor_object_not_address():
+    """The kept W^T copies (Linear backward) and resized rel-pos tables are looked up by tensor object: a freed temporary's storage is
+    handed to the next tensor of that size by the allocator, and an address-keyed cache then answers with the previous contents."""
+    A, ops, M_ = pkg("autograd_ops"), pkg("ops"), pkg("modeling_core")
+    g = torch.Generator().manual_seed(5)
+    seen = set()
+    for i in range(6):
+        w = torch.randn(256, 128, generator=g).to(torch.bfloat16).to(DEV)      # frozen temporaries, one after the other
+        seen.add(w.data_ptr())
+        assert torch.equal(A._t_frozen(w), w.t().contiguous()), f"stale transposed copy on temporary {i}"
+        tab = torch.randn(39, 80, generator=g).to(torch.bfloat16).to(DEV)
+        fit = ops.fit_rel_pos(tab, 14).cpu()
+        ref = torch.nn.functional.interpolate(tab.cpu().reshape(1, 39, -1).permute(0, 2, 1), size=27, mode="linear")
+        assert torch.equal(fit, ref.reshape(-1, 27).permute(1, 0)), f"stale resized table on temporary {i}"
+        del w, tab
+    assert len(seen) < 6, "the allocator did not reuse an address: the test did not exercise the hazard"
+    # a persistent weight hits, and an in-place update rebuilds
+    p = torch.randn(64, 32, generator=g).to(torch.bfloat16).to(DEV)
+    t0 = A._t_frozen(p)
+    assert A._t_frozen(p) is t0
+    p.mul_(2)
+    assert torch.equal(A._t_frozen(p), p.t().contiguous())
+    # frozen packs of the training path: built once per parameter set, rebuilt after an update
+    a_, b_ = torch.nn.Parameter(p.clone(), requires_grad=False), torch.nn.Parameter(p.clone() + 1, requires_grad=False)
+    k0 = M_._frozen_pack("t", (a_, b_), lambda: torch.cat((a_, b_), dim=0))
+    assert M_._frozen_pack("t", (a_, b_), lambda: torch.cat((a_, b_), dim=0)) is k0
+    with torch.no_grad():
+        a_.add_(1)
+    k1 = M_._frozen_pack("t", (a_, b_), lambda: torch.cat((a_, b_), dim=0))
+    assert k1 is not k0 and torch.equal(k1, torch.cat((a_, b_), dim=0))

@@ -84,40 +84,45 @@ def test_sam_attention_with_tables_of_another_length():
     qkv = F.linear(x.reshape(-1, C), sd["qkv.weight"], sd["qkv.bias"]).to(DEV)
     strides = (S * 3 * C, hd, 3 * C)
     vmax = float(qkv[:, 2 * C:].float().abs().max())
-    for win in (False, True):
-        vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd, win_kw=side if win else 0)
-        att = torch.empty(NB * S, C, device=DEV, dtype=BF)
-        ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
-                      q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side),
-                      win_padded=win)
-        assert_close_bf16(att, ref, ulps=2.0, what=f"sam attention, resized tables, row-padded={win}", outlier_frac=2e-3, outlier_floor=vmax)
+    vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
+    att = torch.empty(NB * S, C, device=DEV, dtype=BF)
+    ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
+                  q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side))
+    assert_close_bf16(att, ref, ulps=2.0, what="sam attention, resized tables", outlier_frac=2e-3, outlier_floor=vmax)
+    # the image-order entry resizes them too (one window, no padding: the same tokens)
+    att2 = ops.sam_window_attention(qkv[:S], sd["qkv.bias"].to(DEV), sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), 1, side, side, nH, hd, side)
+    assert_close_bf16(att2, ref[:S], ulps=2.0, what="window attention entry, resized tables", outlier_frac=2e-3, outlier_floor=vmax)
 
 
 @pytest.mark.parametrize("H,W", [(20, 20), (28, 14), (31, 17)])
 def test_window_attention_on_image_order_tokens(H, W):
-    """ull_sam_window_attention (tokens stay in image order; the kernel does the window addressing and reads the zero-padded positions'
-    q|k|v from the qkv bias) against window_partition -> qkv Linear -> attention -> window_unpartition: identical bits, and against
-    the oracle's Block-level arithmetic."""
+    """ull_sam_window_attention (tokens stay in image order; the kernel does the window addressing, reads the zero-padded positions'
+    q|k|v from the qkv bias and V through the transposing LDS load) against window_partition -> qkv Linear -> V^T pass -> attention ->
+    window_unpartition with the generic kernels, and against the oracle's Block-level arithmetic."""
     ops = pkg("ops")
     B, nH, hd, ws = 2, 2, 80, 14
     C = nH * hd
     y = _rand(B, H, W, C, seed=31).to(DEV)                      # norm1 output
     w, b = _rand(3 * C, C, seed=32, scale=C ** -0.5).to(DEV), _rand(3 * C, seed=33, scale=0.3).to(DEV)
     rph, rpw = _rand(27, hd, seed=34, scale=0.3).to(DEV), _rand(27, hd, seed=35, scale=0.3).to(DEV)
-    # the window-major chain
+    # the window-major chain with the generic kernels
     yw = ops.window_partition(y.view(-1, C), B, H, W, ws)
     NB, S = yw.shape[0] // (ws * ws), ws * ws
     qkv_w = ops.linear(yw, w, b)
     strides = (S * 3 * C, hd, 3 * C)
-    vt = ops.transpose_v(qkv_w[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd, win_kw=ws)
+    vt = ops.transpose_v(qkv_w[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
     att_w = torch.empty(NB * S, C, device=DEV, dtype=BF)
     ops.attention(qkv_w, qkv_w[:, C:], vt, att_w, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
-                  q_scale=hd ** -0.5, rel_h=rph, rel_w=rpw, rel_pos_hw=(ws, ws), win_padded=True)
+                  q_scale=hd ** -0.5, rel_h=rph, rel_w=rpw, rel_pos_hw=(ws, ws))
     ref = ops.window_unpartition_add(att_w, torch.zeros(B * H * W, C, device=DEV, dtype=BF), B, H, W, ws)
     # image order
     qkv = ops.linear(y.view(-1, C), w, b)
     got = ops.sam_window_attention(qkv, b, rph, rpw, B, H, W, nH, hd, ws)
-    assert torch.equal(got, ref)
+    # scores, softmax and P are the same numbers in both kernels; the fp32 P*V sum runs over the keys in another order
+    d = (got.float() - ref.float()).abs()
+    nd = float((d > 0).float().mean())
+    print(f"image-order vs window-major chain {H}x{W}: {nd:.4%} of outputs differ, max {float(d.max()):.3g}")
+    assert nd < 0.01 and float(d.max()) <= 2.0 ** -7 * float(ref.float().abs().max())
     # and the oracle (proj = identity)
     sd = {"qkv.weight": w.cpu(), "qkv.bias": b.cpu(), "proj.weight": torch.eye(C).to(BF), "proj.bias": torch.zeros(C).to(BF),
           "rel_pos_h": rph.cpu(), "rel_pos_w": rpw.cpu()}
@@ -161,20 +166,14 @@ def test_sam_encoder_attention(side, hd, nH, NB):
     # (MFMA vs sequential fp32 accumulation order may flip a bf16 rounding of a table entry, so compare with the reference)
     assert_close_bf16(att2, ref, ulps=2.0, what=f"sam attention (fused rel-pos) side={side}", outlier_frac=frac, outlier_floor=vmax)
     if side == 14 and hd == 80:
-        # the path's own form for 14 x 14 windows: window rows padded to 16 key slots (C-ABI rel_mode 3).  Scores, softmax and P are
-        # the same numbers as in the generic kernel; only the order of the fp32 P*V sum over keys differs.
-        vtw = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd, win_kw=side)
-        assert vtw.shape[-1] == 256
-        att3 = torch.empty_like(att)
-        ops.attention(qkv, qkv[:, C:], vtw, att3, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
-                      q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side),
-                      win_padded=True)
-        assert_close_bf16(att3, ref, ulps=2.0, what="sam attention (row-padded windows)", outlier_frac=frac, outlier_floor=vmax)
+        # the path's own entry for 14 x 14 windows (here: whole windows, no padding) gives the same numbers up to the P*V sum order
+        att3 = ops.sam_window_attention(qkv, sd["qkv.bias"].to(DEV), sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), NB, side, side, nH, hd,
+                                        side)
+        assert_close_bf16(att3, ref, ulps=2.0, what="sam window attention entry", outlier_frac=frac, outlier_floor=vmax)
         e3 = float((att3.float().cpu() - truth).pow(2).mean().sqrt())
-        assert e3 <= 1.15 * e_ref, f"rms error vs fp32 truth: row-padded kernel {e3:.4g}, reference bf16 path {e_ref:.4g}"
+        assert e3 <= 1.15 * e_ref, f"rms error vs fp32 truth: window entry {e3:.4g}, reference bf16 path {e_ref:.4g}"
         d = (att3.float() - att2.float()).abs()
-        assert float((d > 0).float().mean()) < 0.02, "row-padded and generic window kernels differ on more than 2 % of the outputs"
-        print(f"row-padded vs generic window attention: {float((d > 0).float().mean()):.4%} of outputs differ, max {float(d.max()):.3g}")
+        assert float((d > 0).float().mean()) < 0.02, "window entry and generic window kernel differ on more than 2 % of the outputs"
 
 
 @pytest.mark.parametrize("Sq,Sk,hd", [(6, 4096, 16), (4096, 6, 16), (6, 6, 32), (130, 1500, 64)])

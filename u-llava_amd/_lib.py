@@ -56,9 +56,8 @@ SIGNATURES = {
     "ull_rope_inplace_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "ull_rope_append_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr],
     "ull_transpose_v_bf16": [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
-    "ull_sam_window_attention_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _ptr, _ptr],
+    "ull_sam_window_attention_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _ptr, _ptr],
     "ull_interp_rows_linear_bf16": [_ptr, _ptr, _i64, _i64, _i64, _ptr],
-    "ull_transpose_v_win_bf16": [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_im2col_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_mm_spans": [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     "ull_embed_splice_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],

@@ -8,6 +8,8 @@ HIP kernel from csrc/backward.hip or the forward GEMM on transposed operands.  t
 """
 from typing import Optional
 
+import weakref
+
 import torch
 
 from . import ops
@@ -20,21 +22,25 @@ def _t(x: torch.Tensor) -> torch.Tensor:
     return ops.transpose2d(x)
 
 
-_T_CACHE: dict = {}
+_T_CACHE: dict = {}           # id(weight) -> (weakref(weight), version, W^T): only the very same tensor object may hit
 
 
 def _t_frozen(w: torch.Tensor) -> torch.Tensor:
     """Transposed copy of a FROZEN weight (dX = dY @ W needs W^T as the GEMM's row-major operand), kept across steps: the reference's
     stage-2 recipe freezes every LLaMA Linear but the LoRA targets, so the 13 GB of transposes are paid once, not per backward.
-    Keyed by storage pointer / shape / version counter (an in-place update of the weight rebuilds the copy)."""
+    Kept per tensor OBJECT (weak reference + version counter), never per address: the allocator hands a freed temporary's storage
+    to the next one, so an address says nothing about the contents.  Callers therefore pass persistent tensors (parameters, or the
+    frozen packs of modeling_core._frozen_pack)."""
     if w.requires_grad or w.grad_fn is not None:
         return _t(w)
-    key = (w.data_ptr(), tuple(w.shape), w.dtype)
-    hit = _T_CACHE.get(key)
-    if hit is None or hit[0] != w._version:
-        hit = (w._version, _t(w))
-        _T_CACHE[key] = hit
-    return hit[1]
+    hit = _T_CACHE.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    wt = _t(w)
+    for k in [k for k, v in _T_CACHE.items() if v[0]() is None]:
+        del _T_CACHE[k]
+    _T_CACHE[id(w)] = (weakref.ref(w), w._version, wt)
+    return wt
 
 
 def clear_transpose_cache():

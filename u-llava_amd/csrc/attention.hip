@@ -35,15 +35,16 @@ struct AttnArgs {
     const elem_t* rel_h; const elem_t* rel_w;   // [B*H, Sq, KH] / [B*H, Sq, KW] or null
     int KH, KW;
     int rel_mode;                       // 1: rel_h/rel_w are per-query tables [B*H,Sq,KH|KW]; 2: they are the raw rel_pos_h/w parameters
-    int win16;                          // C-ABI rel_mode 3: as 2, and Vt is the row-padded image written by ull_transpose_v_win
+    int win16;                          // ull_sam_window_attention: the WIN16 form of the exact kernel, see below
                                         //    [2KH-1,hd] / [2KW-1,hd] and the tables are built in the kernel prologue on the MFMA
     float inv_kw;                       // 1 / KW
     float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
-    // WIN16 on image-order tokens (ull_sam_window_attention): Q / K / O rows are tokens of [img, img_h, img_w] grids, "batch" b is
-    // window (img, wy, wx) of the 14 x 14 partition, and window positions outside the grid are the reference's zero padding
-    // (image_encoder.py:262-289 pads AFTER norm1, so a padded token's q|k|v is the qkv bias): K rows of such keys come from k_pad.
-    int img_h, img_w, nwy, nwx;         // img_w == 0: window-major tokens as everywhere else
-    const elem_t* k_pad;                // K part of the pad token's row (+ h * k_hs)
+    // WIN16 (ull_sam_window_attention): Q / K / V / O rows are tokens of [img, img_h, img_w] grids in image order, "batch" b is
+    // window (img, wy, wx) of the 14 x 14 partition, Vt points at the V part of the rows (same strides as K), and window positions
+    // outside the grid are the reference's zero padding (image_encoder.py:262-289 pads AFTER norm1, so a padded token's q|k|v is
+    // the qkv bias): K / V rows of such keys come from k_pad / v_pad.
+    int img_h, img_w, nwy, nwx;
+    const elem_t* k_pad; const elem_t* v_pad;   // K / V part of the pad token's row (+ h * k_hs)
 };
 
 // token index (in image order) of position (ly, lx) of window b, or -1 for a padding position
@@ -240,12 +241,32 @@ ULL_DEV int head_dim_of(const AttnArgs& p) {
 //   DMA'd up front, the NT V^T tiles right after the K barrier (they land during the score / softmax phases), so a block
 //   passes 2 barriers instead of 2*NT and exposes two memory round trips instead of 2*NT -- the streaming form measured
 //   46 us per block for ~10 us of work.  One block of NWV = 13 waves covers all 196 queries of a (window, head).
-//   WIN16 (the SAM 14 x 14 windows, rel_mode 3): the key axis is re-indexed slot = 16 * kh + kw, i.e. every window row padded from
-//   KW = 14 to 16 slots (K rows gathered that way by the DMA, V^T written that way by ull_transpose_v_win).  A 16-key block is then
+//   WIN16 (the SAM 14 x 14 windows on image-order tokens): the key axis is re-indexed slot = 16 * kh + kw, i.e. every window row padded
+//   from KW = 14 to 16 slots; K AND V rows are gathered that way by the DMA straight from the q|k|v rows (window addressing, the pad
+//   token's row for positions outside the grid), and the V^T operand of P*V comes out of the row-major V tile through
+//   ds_read_b64_tr_b16 -- there is no V^T pass and no window partition pass for these blocks.  A 16-key block is then
 //   one window row: kh is a compile-time constant per block and kw = 4 * (lane / 16) + r a per-lane constant for the whole
 //   kernel, so the decomposed rel-pos bias costs one LDS read per quad and two adds per score (the generic path divides j by KW
 //   and reads two table entries per score: 28 VALU instructions per score against 10), padding is a per-lane constant, the
 //   two all-padding blocks of the fourth tile are not computed, and the row maximum is taken while the scores are produced.
+// gfx950's transposing LDS read: within each group of 16 lanes, lane i passes the address of 4 consecutive 16-bit elements -- row i / 4,
+// columns 4 * (i % 4) .. +3 of a 4 x 16 block -- and receives column i of the block (rows 0..3).  (Probed: tools/debug/tr_read_probe.hip.)
+// The compiler does not know this is an LDS load: lds_tr_wait() below must sit between the reads and their first use.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFF>
+ULL_DEV u32x2_t lds_tr_b64(uint32_t addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+ULL_DEV void lds_tr_wait(u32x2_t (&a)[N], u32x2_t (&b)[N]) {      // ties the values to the wait so that no use can move above it
+    static_assert(N == 5, "five head-dim blocks (hd = 80)");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4])
+                 :: "memory");
+}
+
 template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false>
 __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -300,18 +321,32 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                     const int c = (lane % CPR) ^ swz<CPR>(row);
                     int key = min(kt * KT + row, p.Sk - 1);
                     const elem_t* krow = nullptr;
-                    if constexpr (WIN16) {           // slot 16 * kh + kw <- key kh * KW + kw (padding slots read a real key and are masked)
+                    if constexpr (WIN16) {           // slot 16 * kh + kw <- window position (kh, kw); padding slots read a real key and are masked
                         const int slot = kt * KT + row;
-                        const int kh = min(slot >> 4, WKH - 1), kw = min(slot & 15, WKW - 1);
-                        key = kh * WKW + kw;
-                        if (p.img_w > 0) {
-                            const long tok = win_token(p, b, kh, kw, WKW);
-                            krow = tok >= 0 ? p.K + tok * p.k_ss + (long)h * p.k_hs : p.k_pad + (long)h * p.k_hs;
-                        }
+                        const long tok = win_token(p, b, min(slot >> 4, WKH - 1), min(slot & 15, WKW - 1), WKW);
+                        krow = tok >= 0 ? p.K + tok * p.k_ss + (long)h * p.k_hs : p.k_pad + (long)h * p.k_hs;
+                    } else {
+                        krow = kbase + (long)key * p.k_ss;
                     }
-                    if (krow == nullptr) krow = kbase + (long)key * p.k_ss;
                     const elem_t* src = (c * 8 < hd) ? krow + c * 8 : p.zeros;
                     glds16(src, dst + i * 1024);
+                }
+            }
+        } else if constexpr (WIN16) {
+            // V tile kt, ROW-major like the K tile: [64 slots][256 B].  The 32-byte pair of chunks (16 head dims) is XOR-swizzled with
+            // the row so that the 16 rows one transposing read touches spread over all banks (2 passes for 512 B: the minimum).
+            const int kt = s - nkt;
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += NWV) {
+                const int i = i0 + wave;                        // one 1-KiB piece = 4 slots
+                if (i < 16 && kt * KT + i * 4 < NBLK * 16) {
+                    const int row = i * 4 + (lane >> 4);
+                    const int cpos = lane & 15;                 // chunk position in the LDS row
+                    const int c = ((((cpos >> 1) ^ (row & 7)) << 1) | (cpos & 1));   // head-dim chunk stored there
+                    const int slot = kt * KT + row;
+                    const long tok = win_token(p, b, min(slot >> 4, WKH - 1), min(slot & 15, WKW - 1), WKW);
+                    const elem_t* vrow = tok >= 0 ? p.Vt + tok * p.k_ss + (long)h * p.k_hs : p.v_pad + (long)h * p.k_hs;
+                    glds16((c * 8 < hd) ? vrow + c * 8 : p.zeros, dst + i * 1024);
                 }
             }
         } else {
@@ -337,16 +372,14 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     // ---- Q fragments + key-mask bytes (ordinary loads; drained before any DMA is issued) ---------------
     uint4 qf[NKS];
     const int qi = q0 + wave * 16 + fr;
-    long q_tok = 0;                       // WIN16 on image-order tokens: this lane's query token, -1 = a padding position
+    long q_tok = 0;                       // WIN16: this lane's query token, -1 = a padding position
     if constexpr (WIN16) {
-        if (p.img_w > 0) {
-            q_tok = qi < p.Sq ? win_token(p, b, qi / WKW, qi % WKW, WKW) : -1;
-            if (__builtin_amdgcn_ballot_w64(q_tok >= 0) == 0) nkt_w = 0;     // 16 padding positions: barriers and DMA only
-        }
+        q_tok = qi < p.Sq ? win_token(p, b, qi / WKW, qi % WKW, WKW) : -1;
+        if (__builtin_amdgcn_ballot_w64(q_tok >= 0) == 0) nkt_w = 0;         // 16 padding positions: barriers and DMA only
     }
     {
         const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
-        if (WIN16 && p.img_w > 0) qp = p.Q + max(q_tok, 0L) * p.q_ss + (long)h * p.q_hs;
+        if constexpr (WIN16) qp = p.Q + max(q_tok, 0L) * p.q_ss + (long)h * p.q_hs;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
@@ -511,6 +544,32 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                 __builtin_amdgcn_s_barrier();
                 if (kt + 1 < nkt) issue(nkt + kt + 1);
             }
+            if constexpr (WIN16) {
+                if (kt < nkt_w) {
+                    // row-major V tile: lane (fr, fg) asks for slots 4 * fg + fr / 4 (and 16 below), head dims 16 * ds + 4 * (fr % 4) .. +3,
+                    // and receives head dim 16 * ds + fr of slots 4 * fg .. +3: the A operand that matches the P registers.
+                    static_assert(NDS >= 5, "hd = 80");
+                    const int swr = 4 * (fg & 1) + (fr >> 2);                  // (slot & 7) of both reads
+                    const uint32_t vb = lds_base + (NT + kt) * TILE + (4 * fg + (fr >> 2)) * 256 + ((fr & 2) << 3) + ((fr & 1) << 3);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        if (2 * (kt * 2 + kk) >= NBLK) continue;
+                        const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
+                        u32x2_t va[5], vc[5];
+#pragma unroll
+                        for (int ds = 0; ds < 5; ++ds) {
+                            const uint32_t ad = vb + ((ds ^ swr) << 5);
+                            if (kk == 0) { va[ds] = lds_tr_b64<0>(ad); vc[ds] = lds_tr_b64<16 * 256>(ad); }
+                            else { va[ds] = lds_tr_b64<32 * 256>(ad); vc[ds] = lds_tr_b64<48 * 256>(ad); }
+                        }
+                        lds_tr_wait(va, vc);
+#pragma unroll
+                        for (int ds = 0; ds < 5; ++ds)
+                            oacc[ds] = mfma16(make_uint4(va[ds].x, va[ds].y, vc[ds].x, vc[ds].y), pf, oacc[ds]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else
             if (kt < nkt_w) {
                 const char* tb = smem + (EXACT ? NT + kt : ((nkt + kt) & 1)) * TILE;
 #pragma unroll
@@ -532,7 +591,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     }
     if (qi < p.Sq && q_tok >= 0) {
         elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
-        if (WIN16 && p.img_w > 0) op = p.O + q_tok * p.o_ss + (long)h * p.o_hs;
+        if constexpr (WIN16) op = p.O + q_tok * p.o_ss + (long)h * p.o_hs;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
             if (ds * 16 < hd) {
@@ -1259,13 +1318,8 @@ __global__ __launch_bounds__(256) void rope_append_kernel(elem_t* __restrict__ q
 // Inside every 32-key block the keys are stored permuted: slot 8g + 4a + r holds key 16a + 4g + r (a<2, g<4, r<4),
 // which is the (lane group g, element j = 4a + r) <-> key map that the attention kernel's probability registers
 // have after the swapped QK^T MFMA -- so P*V needs no cross-lane movement.  64(s) x 64(d) tiles through LDS.
-// win_kw > 0 (ull_transpose_v_win): the key axis of Vt is slot = 16 * (key / win_kw) + key % win_kw -- every window row padded to 16
-// slots (zeros in the padding) -- which is the key order of the WIN16 attention kernel.
-// img.w > 0 (ull_sam_window_attention): v rows are image-order tokens, block b is window (img, wy, wx) and a window position outside
-// the grid reads the pad token's v (img.pad).
-struct WinImage { int h, w, nwy, nwx; const elem_t* pad; };
 __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restrict__ v, long v_bs, long v_ss, elem_t* __restrict__ vt, int S,
-                                                          int H, int hd, int pitch, int win_kw, WinImage img) {
+                                                          int H, int hd, int pitch) {
     __shared__ __attribute__((aligned(16))) elem_t t[64][68];            // [d][key]; 136-byte rows keep the 8-byte reads aligned
     const int b = blockIdx.z / H, h = blockIdx.z % H;
     const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
@@ -1276,17 +1330,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restri
         const int c = threadIdx.x + 256 * k;
         const int sl = c >> 3, dc = (c & 7) * 8;
         uint4 val = make_uint4(0, 0, 0, 0);
-        int key = s0 + sl;
-        if (win_kw > 0) key = (key & 15) < win_kw ? (key >> 4) * win_kw + (key & 15) : S;
-        if (img.w > 0) {
-            if (key < S && d0 + dc < hd) {
-                const int wx = b % img.nwx, wy = (b / img.nwx) % img.nwy, im = b / (img.nwx * img.nwy);
-                const int iy = wy * win_kw + key / win_kw, ix = wx * win_kw + key % win_kw;
-                const elem_t* src = (iy < img.h && ix < img.w) ? v + (((long)im * img.h + iy) * img.w + ix) * v_ss : img.pad;
-                val = *(const uint4*)(src + (long)h * hd + d0 + dc);
-            }
-        } else
-        if (key < S && d0 + dc < hd) val = *(const uint4*)(vp + (long)key * v_ss + d0 + dc);
+        if (s0 + sl < S && d0 + dc < hd) val = *(const uint4*)(vp + (long)(s0 + sl) * v_ss + d0 + dc);
         const uint32_t w[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1398,8 +1442,8 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     if constexpr (HDP == 128) {
         if (fl == FL_LLAMA && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4>(a, st);
         if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
-        if (a.win16) {                                                                   // 14 x 14 windows, row-padded key slots
-            if (fl != FL_SAM_ENC || a.KH != 14 || a.KW != 14 || a.Sk != 196 || a.Sq > 208 || a.key_mask || a.vt_len < 256) return ULL_ERR_SHAPE;
+        if (a.win16) {                                                                   // 14 x 14 windows on image-order tokens
+            if (fl != FL_SAM_ENC || a.KH != 14 || a.KW != 14 || a.Sk != 196 || a.Sq != 196 || a.key_mask) return ULL_ERR_SHAPE;
             return launch_attn<128, 4, FL_SAM_ENC, 13, true, true>(a, st);
         }
         if (fl == FL_SAM_ENC && nt == 4 && a.Sq <= 208) return launch_attn<128, 4, FL_SAM_ENC, 13, true>(a, st);   // 14 x 14 windows
@@ -1451,14 +1495,13 @@ extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs,
     a.zeros = (const elem_t*)zeros;
     a.rel_h = (const elem_t*)rel_h; a.rel_w = (const elem_t*)rel_w; a.KH = (int)rel_kh; a.KW = (int)rel_kw; a.q_scale = q_scale;
     a.inv_kw = rel_kw > 0 ? 1.0f / (float)rel_kw : 0.f;
-    a.rel_mode = rel_h ? (rel_mode == 3 ? 2 : rel_mode) : 0;
-    a.win16 = rel_h && rel_mode == 3;
-    a.img_h = a.img_w = a.nwy = a.nwx = 0; a.k_pad = nullptr;
-    if (rel_h && (rel_mode < 1 || rel_mode > 3)) return ULL_ERR_ARG;
+    a.rel_mode = rel_h ? rel_mode : 0;
+    a.win16 = 0;
+    a.img_h = a.img_w = a.nwy = a.nwx = 0; a.k_pad = a.v_pad = nullptr;
+    if (rel_h && rel_mode != 1 && rel_mode != 2) return ULL_ERR_ARG;
     if ((rel_h == nullptr) != (rel_w == nullptr)) return ULL_ERR_ARG;
     if (rel_h && (rel_kh <= 0 || rel_kw <= 0 || rel_kh + rel_kw > 256 || rel_kh * rel_kw < Sk)) return ULL_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (a.win16 && hd != 80) return ULL_ERR_SHAPE;
     if (hd <= 32) return dispatch_nt<32>(a, st);
     if (hd <= 64) return dispatch_nt<64>(a, st);
     return dispatch_nt<128>(a, st);
@@ -1515,53 +1558,36 @@ extern "C" int ULL_FN(ull_transpose_v_)(const void* v, int64_t v_bs, int64_t v_s
     if (pitch < S || (pitch & 63)) return ULL_ERR_SHAPE;
     const dim3 grid((unsigned)((pitch + 63) / 64), (unsigned)((hd + 63) / 64), (unsigned)(B * H));
     hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const elem_t*)v, v_bs, v_ss, (elem_t*)vt, (int)S, (int)H,
-                       (int)hd, (int)pitch, 0, WinImage{0, 0, 0, 0, nullptr});
-    return ull_check_launch();
-}
-
-// The same for window attention with rel_mode 3: window rows of kw <= 16 keys padded to 16 slots each (S = kh * kw keys -> 16 * kh slots).
-extern "C" int ULL_FN(ull_transpose_v_win_)(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd,
-                                        int64_t pitch, int64_t kw, void* stream) {
-    if (!v || !vt || B <= 0 || S <= 0) return ULL_ERR_ARG;
-    if (kw <= 0 || kw > 16 || S % kw || pitch < (S / kw) * 16 || (pitch & 63)) return ULL_ERR_SHAPE;
-    const dim3 grid((unsigned)((pitch + 63) / 64), (unsigned)((hd + 63) / 64), (unsigned)(B * H));
-    hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const elem_t*)v, v_bs, v_ss, (elem_t*)vt, (int)S, (int)H,
-                       (int)hd, (int)pitch, (int)kw, WinImage{0, 0, 0, 0, nullptr});
+                       (int)hd, (int)pitch);
     return ull_check_launch();
 }
 
 // image_encoder.py Block.forward :176-190 between norm1 and the projection, for the 14 x 14 windows: window_partition (zero padding
 // included) + Attention (decomposed rel-pos) + window_unpartition, on tokens that stay in IMAGE order.  qkv [B*H*W, 3*nH*hd] rows
 // q|k|v (ld elements apart), out [B*H*W, nH*hd]; pad_row = the q|k|v row of a padded token = the qkv bias (the reference pads the
-// normalised activations with zeros, so Linear gives exactly its bias there); rel_pos_h / rel_pos_w [27, hd]; vt_scratch
-// [B * ceil(H/14) * ceil(W/14) * nH * hd * 256] elements.  The GEMMs either side then run on H*W rows per image instead of the
-// padded 25 * 196 (+19.6 % at 64 x 64), and the two re-ordering passes disappear.
+// normalised activations with zeros, so Linear gives exactly its bias there); rel_pos_h / rel_pos_w [27, hd].  The GEMMs either
+// side then run on H*W rows per image instead of the padded 25 * 196 (+19.6 % at 64 x 64); the two re-ordering passes and the V^T
+// pass do not exist (one launch).
 extern "C" int ULL_FN(ull_sam_window_attention_)(const void* qkv, int64_t ld, const void* pad_row, const void* rel_pos_h, const void* rel_pos_w,
-                                             void* out, int64_t ldo, void* vt_scratch, int64_t B, int64_t Hh, int64_t Ww, int64_t nH, int64_t hd,
-                                             int64_t ws, float q_scale, const void* zeros, void* stream) {
-    if (!qkv || !pad_row || !rel_pos_h || !rel_pos_w || !out || !vt_scratch || !zeros || B <= 0 || Hh <= 0 || Ww <= 0 || nH <= 0) return ULL_ERR_ARG;
+                                             void* out, int64_t ldo, int64_t B, int64_t Hh, int64_t Ww, int64_t nH, int64_t hd, int64_t ws,
+                                             float q_scale, const void* zeros, void* stream) {
+    if (!qkv || !pad_row || !rel_pos_h || !rel_pos_w || !out || !zeros || B <= 0 || Hh <= 0 || Ww <= 0 || nH <= 0) return ULL_ERR_ARG;
     if (ws != 14 || hd != 80 || (ld & 7) || (ldo & 3) || ld < 3 * nH * hd || ldo < nH * hd) return ULL_ERR_SHAPE;
     const int nwy = (int)((Hh + ws - 1) / ws), nwx = (int)((Ww + ws - 1) / ws);
-    const long NB = B * nwy * nwx;
-    const int C = (int)(nH * hd), S = (int)(ws * ws), pitch = 256;
+    const int C = (int)(nH * hd), S = (int)(ws * ws);
     const elem_t* base = (const elem_t*)qkv;
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(pitch / 64), (unsigned)((hd + 63) / 64), (unsigned)(NB * nH));
-    hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, st, base + 2 * C, 0L, (long)ld, (elem_t*)vt_scratch, S, (int)nH, (int)hd, pitch,
-                       (int)ws, WinImage{(int)Hh, (int)Ww, nwy, nwx, (const elem_t*)pad_row + 2 * C});
     AttnArgs a;
-    a.Q = base; a.K = base + C; a.Vt = (const elem_t*)vt_scratch; a.O = (elem_t*)out;
+    a.Q = base; a.K = base + C; a.Vt = base + 2 * C; a.O = (elem_t*)out;
     a.key_mask = nullptr;
     a.q_bs = 0; a.q_hs = hd; a.q_ss = ld; a.k_bs = 0; a.k_hs = hd; a.k_ss = ld;
-    a.vt_bs = nH * hd * pitch; a.vt_hs = hd * pitch; a.vt_ds = pitch; a.o_bs = 0; a.o_hs = hd; a.o_ss = ldo;
-    a.B = (int)NB; a.H = (int)nH; a.Sq = S; a.Sk = S; a.hd = (int)hd; a.vt_len = pitch;
+    a.vt_bs = 0; a.vt_hs = 0; a.vt_ds = 0; a.o_bs = 0; a.o_hs = hd; a.o_ss = ldo;
+    a.B = (int)(B * nwy * nwx); a.H = (int)nH; a.Sq = S; a.Sk = S; a.hd = (int)hd; a.vt_len = 0;
     a.causal = 0; a.scale_mode = 0; a.scale = 1.0f;
     a.zeros = (const elem_t*)zeros;
     a.rel_h = (const elem_t*)rel_pos_h; a.rel_w = (const elem_t*)rel_pos_w; a.KH = (int)ws; a.KW = (int)ws; a.q_scale = q_scale;
     a.inv_kw = 1.0f / (float)ws;
     a.rel_mode = 2; a.win16 = 1;
-    a.img_h = (int)Hh; a.img_w = (int)Ww; a.nwy = nwy; a.nwx = nwx; a.k_pad = (const elem_t*)pad_row + C;
-    const int rc = ull_check_launch();
-    if (rc != ULL_OK) return rc;
-    return dispatch_nt<128>(a, st);
+    a.img_h = (int)Hh; a.img_w = (int)Ww; a.nwy = nwy; a.nwx = nwx;
+    a.k_pad = (const elem_t*)pad_row + C; a.v_pad = (const elem_t*)pad_row + 2 * C;
+    return dispatch_nt<128>(a, (hipStream_t)stream);
 }

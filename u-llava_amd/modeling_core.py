@@ -15,6 +15,8 @@ MI355X-specific host design:
 """
 from typing import List, Optional
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -33,9 +35,29 @@ def _param(*shape, device=None, dtype=BF16):
 
 
 
+_FROZEN_PACKS: dict = {}      # (kind, id(src0), ...) -> (weakrefs, versions, packed): re-layouts of FROZEN weights for the training path
+
+
 def _clear_transposes():
     from .autograd_ops import clear_transpose_cache
     clear_transpose_cache()
+    _FROZEN_PACKS.clear()
+
+
+def _frozen_pack(kind: str, srcs, build):
+    """The training path re-packs weights under autograd (fused q|k|v, interleaved gate|up) so that gradients reach the parameters.
+    Where every source is frozen there is no gradient to route, and the pack -- and its transposed copy for dX, cached per tensor
+    object by autograd_ops._t_frozen -- is built once and kept, keyed by the parameter objects and their version counters."""
+    if any(t.requires_grad for t in srcs):
+        return build()
+    key = (kind,) + tuple(id(t) for t in srcs)
+    hit = _FROZEN_PACKS.get(key)
+    if hit is not None and all(r() is t for r, t in zip(hit[0], srcs)) and hit[1] == tuple(t._version for t in srcs):
+        return hit[2]
+    with torch.no_grad():
+        packed = build()
+    _FROZEN_PACKS[key] = (tuple(weakref.ref(t) for t in srcs), tuple(t._version for t in srcs), packed)
+    return packed
 
 
 class Linear(nn.Module):
@@ -423,13 +445,15 @@ class UllavaCoreForCausalLM(nn.Module):
             if output_hidden_states:
                 all_h.append(x.view(B, S, D))
             a, m = l.self_attn, l.mlp
-            w_qkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)
+            qkv_w = (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
+            w_qkv = _frozen_pack("qkv", qkv_w, lambda: torch.cat(qkv_w, dim=0))
             h = A.rmsnorm(x, l.input_layernorm.weight, cfg.rms_norm_eps)
             qkv = A.rope(A.linear(h, w_qkv), pos, inv_freq, 2 * H, hd)
             att = A.self_attention(qkv, key_mask, B, S, H, hd, True)
             x = A.linear(att, a.o_proj.weight, residual=x)
             h = A.rmsnorm(x, l.post_attention_layernorm.weight, cfg.rms_norm_eps)
-            gu = A.linear(h, interleave_gate_up(m.gate_proj.weight, m.up_proj.weight))
+            gu_w = (m.gate_proj.weight, m.up_proj.weight)
+            gu = A.linear(h, _frozen_pack("gate_up", gu_w, lambda: interleave_gate_up(*gu_w)))
             x = A.linear(A.swiglu(gu), m.down_proj.weight, residual=x)
         x = A.rmsnorm(x, self.model.norm.weight, cfg.rms_norm_eps)
         last = x.view(B, S, D)

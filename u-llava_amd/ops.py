@@ -4,6 +4,7 @@ torch is used for device memory and streams only; every arithmetic op on the pat
 libullava_hip.so.  Activations are 16-bit (bf16 or fp16: every kernel exists in both builds, picked by the dtype of the op's first
 operand; the other operands must match), row-major, last dim contiguous.
 """
+import weakref
 from typing import Optional
 
 import torch
@@ -286,40 +287,40 @@ def clip_embed_ln(patch: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, w: 
     return out
 
 
-_REL_POS_CACHE: dict = {}
+_REL_POS_CACHE: dict = {}          # id(table) -> (weakref(table), version, n, resized): only the very same tensor object may hit
 
 
 def fit_rel_pos(rel_pos: torch.Tensor, size: int) -> torch.Tensor:
     """get_rel_pos's resize (image_encoder.py:333-345): a table whose length is not 2 * size - 1 is linearly interpolated to that length.
-    The resized copy is kept per (storage, version, size): the tables are weights."""
+    The resized copy is kept for the tensor OBJECT it was made from (a module parameter), never by address: a temporary's storage
+    is reused by the allocator."""
     n = 2 * size - 1
     if rel_pos.shape[0] == n:
         return rel_pos
     _chk(rel_pos, "rel_pos")
-    key = (rel_pos.data_ptr(), rel_pos._version, tuple(rel_pos.shape), rel_pos.dtype, n)
-    hit = _REL_POS_CACHE.get(key)
-    if hit is None:
-        if len(_REL_POS_CACHE) > 256:
-            _REL_POS_CACHE.clear()
-        hit = torch.empty(n, rel_pos.shape[1], device=rel_pos.device, dtype=rel_pos.dtype)
-        _lib.call("ull_interp_rows_linear_" + _SFX[rel_pos.dtype], _p(rel_pos.contiguous()), _p(hit), rel_pos.shape[0], n, rel_pos.shape[1], _stream())
-        _REL_POS_CACHE[key] = hit
-    return hit
+    hit = _REL_POS_CACHE.get(id(rel_pos))
+    if hit is not None and hit[0]() is rel_pos and hit[1] == rel_pos._version and hit[2] == n:
+        return hit[3]
+    out = torch.empty(n, rel_pos.shape[1], device=rel_pos.device, dtype=rel_pos.dtype)
+    _lib.call("ull_interp_rows_linear_" + _SFX[rel_pos.dtype], _p(rel_pos.contiguous()), _p(out), rel_pos.shape[0], n, rel_pos.shape[1], _stream())
+    for k in [k for k, v in _REL_POS_CACHE.items() if v[0]() is None]:
+        del _REL_POS_CACHE[k]
+    _REL_POS_CACHE[id(rel_pos)] = (weakref.ref(rel_pos), rel_pos._version, n, out)
+    return out
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Sq: int, Sk: int, hd: int,
               q_strides, k_strides, o_strides, key_mask: Optional[torch.Tensor] = None, causal: bool = False, scale_mode: int = 1,
               scale: float = 1.0, q_scale: float = 1.0, rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None,
-              rel_pos_hw: Optional[tuple] = None, win_padded: bool = False):
+              rel_pos_hw: Optional[tuple] = None):
     """rel_h/rel_w: either per-query bias tables [B*H, Sq, KH|KW] (from sam_relpos), or -- with rel_pos_hw=(KH, KW) -- the raw
-    rel_pos_h / rel_pos_w parameters [2KH-1, hd] / [2KW-1, hd], in which case the kernel builds the tables itself.
-    win_padded: vt comes from transpose_v(..., win_kw=KW) (14 x 14 windows: rows padded to 16 key slots, C-ABI rel_mode 3)."""
+    rel_pos_h / rel_pos_w parameters [2KH-1, hd] / [2KW-1, hd], in which case the kernel builds the tables itself."""
     _chk(q, "q"); _chk(k, "k", q.dtype); _chk(vt, "vt", q.dtype); _chk(out, "out", q.dtype)
     rel_mode, kh, kw = 0, 0, 0
     if rel_h is not None:
         _chk(rel_h, "rel_h", q.dtype); _chk(rel_w, "rel_w", q.dtype)
         if rel_pos_hw is not None:
-            rel_mode, (kh, kw) = (3 if win_padded else 2), rel_pos_hw
+            rel_mode, (kh, kw) = 2, rel_pos_hw
             rel_h, rel_w = fit_rel_pos(rel_h, kh), fit_rel_pos(rel_w, kw)
             if rel_h.shape[1] != hd or rel_w.shape[1] != hd:
                 raise ValueError(f"rel_pos tables of width {rel_h.shape[1]} / {rel_w.shape[1]} for head_dim {hd}")
@@ -343,10 +344,8 @@ def sam_window_attention(qkv: torch.Tensor, pad_row: torch.Tensor, rel_pos_h: to
     C = nH * hd
     if qkv.shape != (B * H * W, 3 * C) or pad_row.numel() != 3 * C:
         raise ValueError(f"qkv {tuple(qkv.shape)} / pad_row {tuple(pad_row.shape)} for B={B} H={H} W={W} C={C}")
-    nw = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
-    vt = torch.empty(B * nw * nH * hd * 256, device=qkv.device, dtype=qkv.dtype)
     out = torch.empty(B * H * W, C, device=qkv.device, dtype=qkv.dtype)
-    _lib.call("ull_sam_window_attention_" + _SFX[qkv.dtype], _p(qkv), 3 * C, _p(pad_row), _p(rel_pos_h), _p(rel_pos_w), _p(out), C, _p(vt),
+    _lib.call("ull_sam_window_attention_" + _SFX[qkv.dtype], _p(qkv), 3 * C, _p(pad_row), _p(rel_pos_h), _p(rel_pos_w), _p(out), C,
               B, H, W, nH, hd, ws, float(hd ** -0.5), _zeros(qkv.device).data_ptr(), _stream())
     return out
 
@@ -366,16 +365,11 @@ def rope_append(qkv: torch.Tensor, row_stride: int, positions: torch.Tensor, inv
 
 
 def transpose_v(v: torch.Tensor, v_bs: int, v_ss: int, B: int, S: int, H: int, hd: int, pitch: Optional[int] = None,
-                out: Optional[torch.Tensor] = None, win_kw: int = 0) -> torch.Tensor:
-    """win_kw > 0: the window form (rows of win_kw keys padded to 16 slots) that attention(..., win_padded=True) reads."""
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(v, "v")
-    slots = (S // win_kw) * 16 if win_kw else S
-    pitch = pitch or ((slots + 63) // 64) * 64
+    pitch = pitch or ((S + 63) // 64) * 64
     vt = out if out is not None else torch.empty(B, H, hd, pitch, device=v.device, dtype=v.dtype)
-    if win_kw:
-        _lib.call("ull_transpose_v_win_" + _SFX[v.dtype], _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, win_kw, _stream())
-    else:
-        _lib.call("ull_transpose_v_" + _SFX[v.dtype], _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, _stream())
+    _lib.call("ull_transpose_v_" + _SFX[v.dtype], _p(v), v_bs, v_ss, _p(vt), B, S, H, hd, pitch, _stream())
     return vt
 
 

@@ -173,7 +173,8 @@ class SamEngine:
             if ws == 14 and hd == 80 and blk.attn.qkv.bias is not None:
                 # the path's own window shape: the tokens stay in image order, the attention kernel does the window addressing and
                 # takes the q|k|v of the reference's zero-padded positions from the qkv bias -- no partition / unpartition passes
-                # and no GEMM rows for the padding (25 windows x 196 = 4900 positions for 4096 tokens)
+                # and no GEMM rows for the padding (25 windows x 196 = 4900 positions for 4096 tokens), and reads V through the
+                # transposing LDS load, so there is no V^T pass either
                 qkv = ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)
                 att = ops.sam_window_attention(qkv, blk.attn.qkv.bias, blk.attn.rel_pos_h, blk.attn.rel_pos_w, B, g, g, nH, hd, ws)
                 x = ops.linear(att, blk.attn.proj.weight, blk.attn.proj.bias, residual=x)
@@ -187,8 +188,7 @@ class SamEngine:
                 S = side * side
                 qkv = ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)          # [NB*S, 3C]: q | k | v, heads contiguous
                 strides = (S * 3 * C, hd, 3 * C)
-                win14 = ws == 14 and hd == 80          # the path's own window shape has a kernel of its own (row-padded key slots)
-                vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd, win_kw=ws if win14 else 0)
+                vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
                 att = torch.empty(NB * S, C, device=x.device, dtype=x.dtype)
                 if glob and side != 64:
                     # other grid sizes: per-query bias tables from their own kernel, looked up by the attention kernel
@@ -200,7 +200,7 @@ class SamEngine:
                     # product on the MFMA): 14x14 windows in the register kernel, the 64x64 global grid in the streaming kernel
                     ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
                                   scale_mode=0, q_scale=hd ** -0.5, rel_h=blk.attn.rel_pos_h, rel_w=blk.attn.rel_pos_w,
-                                  rel_pos_hw=(side, side), win_padded=bool(ws) and win14)
+                                  rel_pos_hw=(side, side))
                 if ws:
                     o = ops.linear(att, blk.attn.proj.weight, blk.attn.proj.bias)
                     x = ops.window_unpartition_add(o, x, B, g, g, ws)
