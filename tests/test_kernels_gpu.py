@@ -243,6 +243,33 @@ def test_attention(B, H, S, hd, causal, masked):
     assert_close_bf16(got, ref, ulps=2.0, what=f"attention S={S} hd={hd}", outlier_frac=1e-3, outlier_floor=float(v.float().abs().max()))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,S,hd,causal,masked", [(2, 3, 643, 128, True, True), (1, 2, 1000, 128, True, False), (2, 2, 130, 128, True, False),
+                                                    (2, 3, 577, 64, False, False), (3, 2, 257, 64, False, False), (1, 2, 50, 64, False, False),
+                                                    (1, 2, 1500, 128, True, False), (1, 2, 196, 80, False, False), (2, 4, 11, 16, True, True)])
+def test_attention_takes_v_as_rows(B, H, S, hd, causal, masked, dt):
+    """V handed over as rows of the fused q|k|v buffer (C-ABI vt_len = 0): the LLaMA / CLIP prefill kernels read it through the
+    transposing LDS load -- same operands in the same MFMA slots as with the V^T image, so the result is identical to the last bit;
+    shapes without such a kernel (long rows, other head dims, few queries) get their V^T image made by the wrapper."""
+    ops = pkg("ops")
+    D = H * hd
+    g = torch.Generator().manual_seed(S * 3 + hd)
+    qkv = torch.randn(B * S, 3 * D, generator=g).to(dt).to(DEV)
+    km = None
+    if masked:
+        km = torch.ones(B, S, dtype=torch.int32)
+        km[-1, S - S // 3:] = 0
+        km = km.to(DEV)
+    st = (S * 3 * D, hd, 3 * D)
+    vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
+    a = torch.empty(B * S, D, device=DEV, dtype=dt)
+    b = torch.full((B * S, D), float("nan"), device=DEV, dtype=dt)
+    ops.attention(qkv, qkv[:, D:], vt, a, B, H, S, S, hd, st, st, (S * D, hd, D), km, causal=causal, scale_mode=1, scale=hd ** -0.5)
+    ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], b, B, H, S, S, hd, st, st, (S * D, hd, D), km, causal=causal, scale_mode=1, scale=hd ** -0.5,
+                  v_strides=st)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("Sq,Sk,left_pad", [(1, 70, 0), (1, 700, 13), (3, 1024, 0), (2, 2000, 100), (16, 4096, 0)])
 def test_attention_decode_step_shapes(Sq, Sk, left_pad):
     """<= 16 new queries against a longer key cache (KV-cached generation incl. left-padded prompts; few-query split-key kernel up to

@@ -36,6 +36,7 @@ struct AttnArgs {
     int KH, KW;
     int rel_mode;                       // 1: rel_h/rel_w are per-query tables [B*H,Sq,KH|KW]; 2: they are the raw rel_pos_h/w parameters
     int win16;                          // ull_sam_window_attention: the WIN16 form of the exact kernel, see below
+    int v_rows;                         // Vt is V itself, [B,H,S,hd] by (vt_bs, vt_hs, vt_ds = token stride): kernels with a VROW form
                                         //    [2KH-1,hd] / [2KW-1,hd] and the tables are built in the kernel prologue on the MFMA
     float inv_kw;                       // 1 / KW
     float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
@@ -259,18 +260,31 @@ ULL_DEV u32x2_t lds_tr_b64(uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
-template <int N>
+template <int N, int LEFT = 0>     // LEFT: LDS operations issued AFTER these reads that may still be in flight
 ULL_DEV void lds_tr_wait(u32x2_t (&a)[N], u32x2_t (&b)[N]) {      // ties the values to the wait so that no use can move above it
-    static_assert(N == 5, "five head-dim blocks (hd = 80)");
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4])
-                 :: "memory");
+    static_assert(N == 4 || N == 5 || N == 8, "head-dim blocks of hd = 64 / 80 / 128");
+    if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                     : "n"(LEFT) : "memory");
+    else if constexpr (N == 5)
+        asm volatile("s_waitcnt lgkmcnt(%10)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4])
+                     : "n"(LEFT) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%16)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]),
+                       "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+                     : "n"(LEFT) : "memory");
 }
 
-template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false>
+//   VROW (LLaMA / CLIP prefill): the V tiles are DMA'd ROW-major from V itself ([64 keys][head dim], like the K tiles) and the V^T
+//   operand of P*V comes out of them through ds_read_b64_tr_b16: no V^T pass in front of the attention.
+template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false, bool VROW = false>
 __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!WIN16 || (EXACT && FL == FL_SAM_ENC && NT == 4), "WIN16 is the 14 x 14 window form of the exact kernel");
+    static_assert(!VROW || (!WIN16 && (FL == FL_LLAMA || FL == FL_CLIP) && HDP >= 64), "VROW: flavors that pin hd = HDP");
+    constexpr int PM = HDP / 16 >= 8 ? 7 : HDP / 16 - 1;      // VROW: XOR mask of the 32-byte pair index (pairs per row - 1, at most 7)
     constexpr int WKH = 14, WKW = 14;     // WIN16 window shape (checked by the dispatcher)
     constexpr int NBLK = WIN16 ? WKH : 4 * NT;       // 16-key blocks that hold any key
     constexpr int BQ = 16 * NWV;
@@ -347,6 +361,20 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                     const long tok = win_token(p, b, min(slot >> 4, WKH - 1), min(slot & 15, WKW - 1), WKW);
                     const elem_t* vrow = tok >= 0 ? p.Vt + tok * p.k_ss + (long)h * p.k_hs : p.v_pad + (long)h * p.k_hs;
                     glds16((c * 8 < hd) ? vrow + c * 8 : p.zeros, dst + i * 1024);
+                }
+            }
+        } else if constexpr (VROW) {
+            // V tile kt, row-major: [64 keys][KROW bytes]; 32-byte pairs of chunks XOR-swizzled with the row (see WIN16 above)
+            const int kt = s - nkt;
+#pragma unroll
+            for (int i0 = 0; i0 < CPR; i0 += NWV) {
+                const int i = i0 + wave;
+                if (i < CPR) {
+                    const int row = i * (64 / CPR) + lane / CPR;
+                    const int cpos = lane % CPR;
+                    const int c = ((((cpos >> 1) ^ (row & PM)) << 1) | (cpos & 1));
+                    const int key = min(kt * KT + row, p.Sk - 1);          // rows past the last key: P is exactly 0 there
+                    glds16(vbase + (long)key * p.vt_ds + c * 8, dst + i * 1024);
                 }
             }
         } else {
@@ -567,6 +595,31 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                         for (int ds = 0; ds < 5; ++ds)
                             oacc[ds] = mfma16(make_uint4(va[ds].x, va[ds].y, vc[ds].x, vc[ds].y), pf, oacc[ds]);
                         __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if constexpr (VROW) {
+                if (kt < nkt_w) {
+                    const int swr = (4 * (fg & 1) + (fr >> 2)) & PM;
+                    const uint32_t vb = lds_base + (EXACT ? NT + kt : ((nkt + kt) & 1)) * TILE + (4 * fg + (fr >> 2)) * KROW + ((fr & 2) << 3) +
+                                        ((fr & 1) << 3);
+                    // four head-dim blocks at a time (8 reads in flight, 16 registers): more would cost the third wave per SIMD
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
+#pragma unroll
+                        for (int d0 = 0; d0 < NDS; d0 += 4) {
+                            u32x2_t va[4], vc[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t ad = vb + (((d0 + j) ^ swr) << 5);
+                                if (kk == 0) { va[j] = lds_tr_b64<0>(ad); vc[j] = lds_tr_b64<16 * KROW>(ad); }
+                                else { va[j] = lds_tr_b64<32 * KROW>(ad); vc[j] = lds_tr_b64<48 * KROW>(ad); }
+                            }
+                            lds_tr_wait<4>(va, vc);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                oacc[d0 + j] = mfma16(make_uint4(va[j].x, va[j].y, vc[j].x, vc[j].y), pf, oacc[d0 + j]);
+                        }
                     }
                 }
             } else
@@ -1351,7 +1404,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restri
     }
 }
 
-template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false, bool WIN16 = false>
+template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false, bool WIN16 = false, bool VROW = false>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
     const int lds = (EXACT ? 2 * NT : 2) * TILE + NT * KT +
@@ -1359,11 +1412,11 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     if (lds > 160 * 1024) return ULL_ERR_LDS;
     static UllOncePerDevice once;
     if (lds > 64 * 1024 && once.first())
-        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16, VROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16>), grid, dim3(NWV * 64), lds, st, a);
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16, VROW>), grid, dim3(NWV * 64), lds, st, a);
     return ull_check_launch();
 }
 
@@ -1428,6 +1481,17 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     // the flavored kernels take the head dim as a compile-time constant (head_dim_of)
     if ((fl == FL_LLAMA || fl == FL_CLIP) && a.hd != HDP) fl = FL_RUNTIME;
     if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
+    if (a.v_rows) {                      // V handed over row-major: the kernels that transpose on the fly (see the C entry)
+        if constexpr (HDP == 128) {
+            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4, false, false, true>(a, st);
+            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, false, true>(a, st);
+        }
+        if constexpr (HDP == 64) {
+            if (fl == FL_CLIP && a.Sq > 16 && nt <= 5) return launch_attn<64, 5, FL_CLIP, 8, false, false, true>(a, st);
+            if (fl == FL_CLIP && a.Sq > 16 && nt <= 11) return launch_attn<64, 11, FL_CLIP, 4, false, false, true>(a, st);
+        }
+        return ULL_ERR_SHAPE;
+    }
     // <= 16 queries (decode steps, mask-decoder tokens): split the keys over the waves of one block per head
     if (a.Sq <= 16 && !a.rel_h && nt >= 2 && nt <= 64) {
         if constexpr (HDP == 128) {
@@ -1481,7 +1545,8 @@ extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs,
                                   int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, float q_scale, const void* rel_h,
                                   const void* rel_w, int64_t rel_kh, int64_t rel_kw, int rel_mode, const void* zeros, void* stream) {
     if (!Q || !K || !Vt || !O || !zeros || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return ULL_ERR_ARG;
-    if (hd <= 0 || hd > 128 || (hd & 15) || (vt_len & 63) || vt_len < ((Sk + 63) & ~63)) return ULL_ERR_SHAPE;
+    if (hd <= 0 || hd > 128 || (hd & 15)) return ULL_ERR_SHAPE;
+    if (vt_len != 0 && ((vt_len & 63) || vt_len < ((Sk + 63) & ~63))) return ULL_ERR_SHAPE;
     if ((q_ss & 7) || (k_ss & 7) || (vt_ds & 7) || (q_hs & 7) || (k_hs & 7) || (q_bs & 7) || (k_bs & 7) || (vt_hs & 7) || (vt_bs & 7) ||
         (o_ss & 3) || (o_hs & 3) || (o_bs & 3))
         return ULL_ERR_SHAPE;
@@ -1497,6 +1562,7 @@ extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs,
     a.inv_kw = rel_kw > 0 ? 1.0f / (float)rel_kw : 0.f;
     a.rel_mode = rel_h ? rel_mode : 0;
     a.win16 = 0;
+    a.v_rows = vt_len == 0;
     a.img_h = a.img_w = a.nwy = a.nwx = 0; a.k_pad = a.v_pad = nullptr;
     if (rel_h && rel_mode != 1 && rel_mode != 2) return ULL_ERR_ARG;
     if ((rel_h == nullptr) != (rel_w == nullptr)) return ULL_ERR_ARG;
@@ -1586,7 +1652,7 @@ extern "C" int ULL_FN(ull_sam_window_attention_)(const void* qkv, int64_t ld, co
     a.zeros = (const elem_t*)zeros;
     a.rel_h = (const elem_t*)rel_pos_h; a.rel_w = (const elem_t*)rel_pos_w; a.KH = (int)ws; a.KW = (int)ws; a.q_scale = q_scale;
     a.inv_kw = 1.0f / (float)ws;
-    a.rel_mode = 2; a.win16 = 1;
+    a.rel_mode = 2; a.win16 = 1; a.v_rows = 0;
     a.img_h = (int)Hh; a.img_w = (int)Ww; a.nwy = nwy; a.nwx = nwx;
     a.k_pad = (const elem_t*)pad_row + C; a.v_pad = (const elem_t*)pad_row + 2 * C;
     return dispatch_nt<128>(a, (hipStream_t)stream);

@@ -372,10 +372,10 @@ class UllavaCoreForCausalLM(nn.Module):
             w = pk["clip"][li]
             y = ops.layernorm(h, w["ln1"].weight, w["ln1"].bias, vc.layer_norm_eps)
             qkv = ops.linear(y, w["w_qkv"], w["b_qkv"])
-            vt = ops.transpose_v(qkv[:, 2 * Dv:], S * 3 * Dv, 3 * Dv, n, S, H, hd)
             att = torch.empty(n * S, Dv, device=h.device, dtype=h.dtype)
-            ops.attention(qkv, qkv[:, Dv:], vt, att, n, H, S, S, hd, (S * 3 * Dv, hd, 3 * Dv), (S * 3 * Dv, hd, 3 * Dv),
-                          (S * Dv, hd, Dv), None, causal=False, scale_mode=1, scale=hd ** -0.5)
+            st = (S * 3 * Dv, hd, 3 * Dv)                       # V goes in as rows of the fused q|k|v buffer: no V^T pass
+            ops.attention(qkv, qkv[:, Dv:], qkv[:, 2 * Dv:], att, n, H, S, S, hd, st, st, (S * Dv, hd, Dv), None, causal=False, scale_mode=1,
+                          scale=hd ** -0.5, v_strides=st)
             h = ops.linear(att, w["w_out"], w["b_out"], residual=h)
             y = ops.layernorm(h, w["ln2"].weight, w["ln2"].bias, vc.layer_norm_eps)
             f = ops.linear(y, w["fc1"].weight, w["fc1"].bias, act="quick_gelu")
@@ -550,14 +550,16 @@ class UllavaCoreForCausalLM(nn.Module):
             else:
                 if not fuse_rope:
                     ops.rope_inplace(qkv, 3 * D, pos, inv_freq, T, 2 * H, hd)
-                if cache is None:
-                    vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
-                else:                                            # prefill that also fills the cache
+                st = (S * 3 * D, hd, 3 * D)
+                if cache is None:                                # V goes in as rows of the fused q|k|v buffer: no V^T pass
+                    ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], att, B, H, S, S, hd, st, st, (S * D, hd, D), key_mask, causal=True,
+                                  scale_mode=1, scale=hd ** -0.5, v_strides=st)
+                else:                                            # prefill that also fills the cache (K rows, V^T image)
                     kc, vt = cache.k[li], cache.vt[li]
                     kc[:, :, :S].copy_(qkv.view(B, S, 3, H, hd)[:, :, 1].permute(0, 2, 1, 3))
                     ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd, pitch=cache.smax, out=vt)
-                ops.attention(qkv, qkv[:, D:], vt, att, B, H, S, S, hd, (S * 3 * D, hd, 3 * D), (S * 3 * D, hd, 3 * D), (S * D, hd, D),
-                              key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
+                    ops.attention(qkv, qkv[:, D:], vt, att, B, H, S, S, hd, st, st, (S * D, hd, D), key_mask, causal=True, scale_mode=1,
+                                  scale=hd ** -0.5)
             x = ops.linear(att, w["w_o"], residual=x)
             a = ops.linear(x, w["w_gu"], swiglu=True, rms_w=w["ln2"], rms_eps=cfg.rms_norm_eps)  # post_attention_layernorm -> gate|up
             x = ops.linear(a, w["w_down"], residual=x)

@@ -312,9 +312,11 @@ def fit_rel_pos(rel_pos: torch.Tensor, size: int) -> torch.Tensor:
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int, Sq: int, Sk: int, hd: int,
               q_strides, k_strides, o_strides, key_mask: Optional[torch.Tensor] = None, causal: bool = False, scale_mode: int = 1,
               scale: float = 1.0, q_scale: float = 1.0, rel_h: Optional[torch.Tensor] = None, rel_w: Optional[torch.Tensor] = None,
-              rel_pos_hw: Optional[tuple] = None):
+              rel_pos_hw: Optional[tuple] = None, v_strides=None):
     """rel_h/rel_w: either per-query bias tables [B*H, Sq, KH|KW] (from sam_relpos), or -- with rel_pos_hw=(KH, KW) -- the raw
-    rel_pos_h / rel_pos_w parameters [2KH-1, hd] / [2KW-1, hd], in which case the kernel builds the tables itself."""
+    rel_pos_h / rel_pos_w parameters [2KH-1, hd] / [2KW-1, hd], in which case the kernel builds the tables itself.
+    v_strides = (batch, head, token) strides: `vt` is V ITSELF ([B,H,Sk,hd] by strides), not its transposed image; the kernels that
+    transpose on the fly (LLaMA / CLIP prefill) take it directly, for any other shape the V^T image is made here first."""
     _chk(q, "q"); _chk(k, "k", q.dtype); _chk(vt, "vt", q.dtype); _chk(out, "out", q.dtype)
     rel_mode, kh, kw = 0, 0, 0
     if rel_h is not None:
@@ -328,10 +330,20 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
             rel_mode, kh, kw = 1, rel_h.shape[-1], rel_w.shape[-1]
     if key_mask is not None:
         _chk(key_mask, "key_mask", torch.int32)
+    name = "ull_attention_" + _SFX[q.dtype]
+    tail = (_p(out), *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), float(q_scale), _p(rel_h), _p(rel_w),
+            kh, kw, rel_mode, _zeros(q.device).data_ptr(), _stream())
+    if v_strides is not None:
+        rc = _lib.query(name, _p(q), *q_strides, _p(k), *k_strides, _p(vt), *v_strides, 0, *tail)
+        if rc == 0:
+            return out
+        if rc != -2:                               # anything but "no kernel of that form for this shape"
+            raise RuntimeError(f"u-llava_amd: {name} failed: {_lib.ERRORS.get(rc, rc)}")
+        if v_strides[1] != hd:
+            raise ValueError("V rows must have their heads contiguous (head stride == head_dim) to be transposed here")
+        vt = transpose_v(vt, v_strides[0], v_strides[2], B, Sk, H, hd)
     pitch = vt.shape[-1]
-    _lib.call("ull_attention_" + _SFX[q.dtype], _p(q), *q_strides, _p(k), *k_strides, _p(vt), H * hd * pitch, hd * pitch, pitch, pitch, _p(out),
-              *o_strides, _p(key_mask), B, H, Sq, Sk, hd, int(causal), scale_mode, float(scale), float(q_scale), _p(rel_h), _p(rel_w),
-              kh, kw, rel_mode, _zeros(q.device).data_ptr(), _stream())
+    _lib.call(name, _p(q), *q_strides, _p(k), *k_strides, _p(vt), H * hd * pitch, hd * pitch, pitch, pitch, *tail)
     return out
 
 
