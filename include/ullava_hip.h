@@ -113,7 +113,8 @@ int ull_clip_embed_ln_bf16(const void* patch, int64_t ldp, const void* cls, cons
  * windows have their own entry, ull_sam_window_attention_bf16).  SAM decoder (transformer.py:220-242): scale_mode 2 divides by sqrt(hd).
  * Q/K: [B,H,S,hd] by strides, hd contiguous.  Vt: [B,H,hd,vt_len] as written by ull_transpose_v_bf16 (vt_len % 64 == 0); or, with
  * vt_len = 0, V itself [B,H,S,hd] by (vt_bs, vt_hs, vt_ds = token stride): the LLaMA (hd 128, Sk <= 1024) and CLIP (hd 64, Sk <= 704)
- * prefill kernels transpose it on the fly through the LDS (ULL_ERR_SHAPE where no such kernel exists: Sq <= 16, other flavors).
+ * prefill kernels and the SAM global-attention kernel (64 x 64 grid, rel_mode 2) transpose it on the fly through the LDS
+ * (ULL_ERR_SHAPE where no such kernel exists: Sq <= 16, other flavors).
  * key_mask: int32 [B,Sk] (nonzero = attend) or NULL.  zeros: >= 16 readable zero bytes (head-dim padding source). */
 int ull_attention_bf16(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs, int64_t k_ss,
                        const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O, int64_t o_bs, int64_t o_hs,

@@ -165,6 +165,12 @@ def test_sam_encoder_attention(side, hd, nH, NB):
                   q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side))
     # (MFMA vs sequential fp32 accumulation order may flip a bf16 rounding of a table entry, so compare with the reference)
     assert_close_bf16(att2, ref, ulps=2.0, what=f"sam attention (fused rel-pos) side={side}", outlier_frac=frac, outlier_floor=vmax)
+    # V handed over as rows of the q|k|v buffer: the 64 x 64 global kernel reads it through the transposing LDS load (other shapes
+    # get their V^T image made by the wrapper) -- the same operands in the same MFMA slots, identical bits
+    att4 = torch.full_like(att, float("nan"))
+    ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], att4, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
+                  q_scale=hd ** -0.5, rel_h=sd["rel_pos_h"].to(DEV), rel_w=sd["rel_pos_w"].to(DEV), rel_pos_hw=(side, side), v_strides=strides)
+    assert torch.equal(att4, att2)
     if side == 14 and hd == 80:
         # the path's own entry for 14 x 14 windows (here: whole windows, no padding) gives the same numbers up to the P*V sum order
         att3 = ops.sam_window_attention(qkv, sd["qkv.bias"].to(DEV), sd["rel_pos_h"].to(DEV), sd["rel_pos_w"].to(DEV), NB, side, side, nH, hd,

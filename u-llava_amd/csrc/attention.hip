@@ -262,8 +262,10 @@ ULL_DEV u32x2_t lds_tr_b64(uint32_t addr) {
 }
 template <int N, int LEFT = 0>     // LEFT: LDS operations issued AFTER these reads that may still be in flight
 ULL_DEV void lds_tr_wait(u32x2_t (&a)[N], u32x2_t (&b)[N]) {      // ties the values to the wait so that no use can move above it
-    static_assert(N == 4 || N == 5 || N == 8, "head-dim blocks of hd = 64 / 80 / 128");
-    if constexpr (N == 4)
+    static_assert(N == 1 || N == 4 || N == 5 || N == 8, "head-dim blocks of hd = 64 / 80 / 128");
+    if constexpr (N == 1)
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(LEFT) : "memory");
+    else if constexpr (N == 4)
         asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
                      : "n"(LEFT) : "memory");
     else if constexpr (N == 5)
@@ -858,7 +860,9 @@ __global__ __launch_bounds__(512) void attn_long_kernel(AttnArgs p) {
 //   is one grid row, so rel_h is ONE value per (query, tile) and the 16 rel_w values of a lane are the same for every tile:
 //   they live in registers and the per-score table lookups / index arithmetic / LDS bias rows disappear; without the mask
 //   bytes and bias rows a block needs 64 KiB of LDS and two blocks share a CU.
-template <int HDP, int FL, int HOIST>
+//   VROW: V is handed over as rows (AttnArgs::v_rows); the V tile is DMA'd row-major and read through ds_read_b64_tr_b16 (see
+//   attn_reg_kernel): the global SAM blocks then run without a V^T pass as well.
+template <int HDP, int FL, int HOIST, bool VROW = false>
 __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NWV = 8, BQ = 16 * NWV;
@@ -988,6 +992,20 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                 glds16(src, dst + i * 1024);
             }
         }
+        if constexpr (VROW) {
+            static_assert(HDP == 128, "row-major V tiles: 256-byte rows");
+#pragma unroll
+            for (int i0 = 0; i0 < CPR; i0 += NWV) {
+                const int i = i0 + wave;
+                if (i < CPR) {
+                    const int row = i * (64 / CPR) + lane / CPR;
+                    const int cpos = lane % CPR;
+                    const int c = ((((cpos >> 1) ^ (row & 7)) << 1) | (cpos & 1));      // 32-byte pairs XOR-swizzled with the row
+                    const int key = min(kt * KT + row, p.Sk - 1);
+                    glds16((c * 8 < hd) ? vbase + (long)key * p.vt_ds + c * 8 : p.zeros, dst + TILE + i * 1024);
+                }
+            }
+        } else {
         const int npieces = hd >> 3;
 #pragma unroll
         for (int i0 = 0; i0 < HDP / 8; i0 += NWV) {
@@ -997,6 +1015,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                 const int c = (lane & 7) ^ (row & 7);
                 glds16(vbase + (long)row * p.vt_ds + kt * KT + c * 8, dst + TILE + i * 1024);
             }
+        }
         }
     };
 
@@ -1056,6 +1075,32 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             // the sum runs over the ROUNDED probabilities, so that O / l is a true weighted mean of V rows
             l += pk_lo(pk[i]) + pk_hi(pk[i]);
         }
+        if constexpr (VROW) {
+            static_assert(FL == FL_SAM_ENC, "hd = 80: five head-dim blocks");
+            const int swr = 4 * (fg & 1) + (fr >> 2);
+            const uint32_t vb = lds_base + (kt & 1) * (2 * TILE) + TILE + (4 * fg + (fr >> 2)) * KROW + ((fr & 2) << 3) + ((fr & 1) << 3);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const uint4 pf = make_uint4(pk[4 * kk], pk[4 * kk + 1], pk[4 * kk + 2], pk[4 * kk + 3]);
+                u32x2_t va[4], vc[4], wa[1], wc[1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t ad = vb + ((j ^ swr) << 5);
+                    if (kk == 0) { va[j] = lds_tr_b64<0>(ad); vc[j] = lds_tr_b64<16 * KROW>(ad); }
+                    else { va[j] = lds_tr_b64<32 * KROW>(ad); vc[j] = lds_tr_b64<48 * KROW>(ad); }
+                }
+                {
+                    const uint32_t ad = vb + ((4 ^ swr) << 5);
+                    if (kk == 0) { wa[0] = lds_tr_b64<0>(ad); wc[0] = lds_tr_b64<16 * KROW>(ad); }
+                    else { wa[0] = lds_tr_b64<32 * KROW>(ad); wc[0] = lds_tr_b64<48 * KROW>(ad); }
+                }
+                lds_tr_wait<4, 2>(va, vc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) oacc[j] = mfma16(make_uint4(va[j].x, va[j].y, vc[j].x, vc[j].y), pf, oacc[j]);
+                lds_tr_wait<1, 0>(wa, wc);
+                oacc[4] = mfma16(make_uint4(wa[0].x, wa[0].y, wc[0].x, wc[0].y), pf, oacc[4]);
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const uint4 pf = make_uint4(pk[4 * kk], pk[4 * kk + 1], pk[4 * kk + 2], pk[4 * kk + 3]);
@@ -1067,6 +1112,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                     oacc[ds] = mfma16(vf, pf, oacc[ds]);
                 }
             }
+        }
         }
     };
     issue(0);
@@ -1434,18 +1480,19 @@ int launch_long(const AttnArgs& a, hipStream_t st) {
     return ull_check_launch();
 }
 
-template <int HDP, int FL, int HOIST>
+template <int HDP, int FL, int HOIST, bool VROW = false>
 int launch_stream(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2;
+    static_assert(!VROW || HOIST == 2, "row-major V: the SAM global-attention form");
     const int nt = (a.Sk + KT - 1) / KT;
     int lds = 4 * TILE;
     if (HOIST == 0) lds += ((nt * KT + 15) & ~15) + (a.rel_h ? 8 * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     if (lds > 160 * 1024) return ULL_ERR_LDS;
     static UllOncePerDevice once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)attn_stream_kernel<HDP, FL, HOIST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (once.first()) (void)hipFuncSetAttribute((const void*)attn_stream_kernel<HDP, FL, HOIST, VROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nq = (a.Sq + 127) / 128;
     const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_stream_kernel<HDP, FL, HOIST>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((attn_stream_kernel<HDP, FL, HOIST, VROW>), grid, dim3(512), lds, st, a);
     return ull_check_launch();
 }
 
@@ -1485,6 +1532,8 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
         if constexpr (HDP == 128) {
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4, false, false, true>(a, st);
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, false, true>(a, st);
+            if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16)
+                return launch_stream<128, FL_SAM_ENC, 2, true>(a, st);
         }
         if constexpr (HDP == 64) {
             if (fl == FL_CLIP && a.Sq > 16 && nt <= 5) return launch_attn<64, 5, FL_CLIP, 8, false, false, true>(a, st);

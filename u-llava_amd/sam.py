@@ -188,19 +188,19 @@ class SamEngine:
                 S = side * side
                 qkv = ops.linear(y, blk.attn.qkv.weight, blk.attn.qkv.bias)          # [NB*S, 3C]: q | k | v, heads contiguous
                 strides = (S * 3 * C, hd, 3 * C)
-                vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
                 att = torch.empty(NB * S, C, device=x.device, dtype=x.dtype)
                 if glob and side != 64:
                     # other grid sizes: per-query bias tables from their own kernel, looked up by the attention kernel
                     rel_h, rel_w = ops.sam_relpos(qkv, strides, blk.attn.rel_pos_h, blk.attn.rel_pos_w, NB, nH, side, side, hd)
-                    ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
-                                  scale_mode=0, q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
+                    ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
+                                  scale_mode=0, q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w, v_strides=strides)
                 else:
                     # the attention kernels build the rel-pos bias themselves from the raw rel_pos_h / rel_pos_w parameters (Toeplitz
-                    # product on the MFMA): 14x14 windows in the register kernel, the 64x64 global grid in the streaming kernel
-                    ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
+                    # product on the MFMA); V goes in as rows of the q|k|v buffer (the 64 x 64 global kernel reads it through the
+                    # transposing LDS load, other shapes get their V^T image made by the wrapper)
+                    ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False,
                                   scale_mode=0, q_scale=hd ** -0.5, rel_h=blk.attn.rel_pos_h, rel_w=blk.attn.rel_pos_w,
-                                  rel_pos_hw=(side, side))
+                                  rel_pos_hw=(side, side), v_strides=strides)
                 if ws:
                     o = ops.linear(att, blk.attn.proj.weight, blk.attn.proj.bias)
                     x = ops.window_unpartition_add(o, x, B, g, g, ws)
