@@ -180,8 +180,15 @@ ULL_DEV float act_gelu_erf(float x) {
     const float erf = __builtin_copysignf(1.0f - ec, x);  // 1 - ec >= 0: one v_bfi instead of compare + two subtractions + select
     return 0.5f * x * (1.0f + erf);
 }
-ULL_DEV float act_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
-ULL_DEV float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+// 1 / d for d in [1, inf): the hardware reciprocal (1 ulp) plus one Newton step, three instructions where the IEEE division sequence
+// (v_div_scale / v_rcp / 4 FMAs / v_div_fmas / v_div_fixup) is ten -- the SwiGLU and QuickGELU epilogues are VALU-bound.  The results
+// go through a 16-bit rounding right away; the fixtures and the exhaustive activation tests pin that they do not move.
+ULL_DEV float rcp_newton(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+ULL_DEV float act_sigmoid(float x) { return rcp_newton(1.0f + __expf(-x)); }
+ULL_DEV float act_silu(float x) { return x * rcp_newton(1.0f + __expf(-x)); }
 // transformers QuickGELUActivation on a 16-bit tensor: input * sigmoid(1.702 * input) has THREE roundings
 // (the scaled input, the sigmoid, the product).
 ULL_DEV float act_quick_gelu_e(float t) {
