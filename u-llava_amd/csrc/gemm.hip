@@ -103,7 +103,10 @@ ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_
             for (int e = 0; e < 8; ++e) a[e] = act_quick_gelu_e(a[e]);
         } else if (c.act == 2) {
 #pragma unroll                                           // (rolled, the dynamic index into a[] cost 32 us per tile: 3x the erf itself)
-            for (int e = 0; e < 8; ++e) a[e] = rnd(act_gelu_erf(a[e]));
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2_t r = act_gelu_erf2(f32x2_t{a[e], a[e + 1]});        // packed fp32 math, same results
+                a[e] = rnd(r.x); a[e + 1] = rnd(r.y);
+            }
         } else if (c.act == 3) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], 0.f);
@@ -317,9 +320,16 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                         if constexpr (ACT != 0) {
                             float a[8];
                             unpack8(o, a);
+                            if constexpr (ACT == 2) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                a[e] = ACT == 1 ? act_quick_gelu_e(a[e]) : ACT == 2 ? rnd(act_gelu_erf(a[e])) : fmaxf(a[e], 0.f);
+                                for (int e = 0; e < 8; e += 2) {
+                                    const f32x2_t r = act_gelu_erf2(f32x2_t{a[e], a[e + 1]});
+                                    a[e] = r.x; a[e + 1] = r.y;          // (pack8 rounds)
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) a[e] = ACT == 1 ? act_quick_gelu_e(a[e]) : fmaxf(a[e], 0.f);
+                            }
                             o = pack8(a);
                         }
                         if constexpr (RES) {

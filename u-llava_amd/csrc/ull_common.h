@@ -180,6 +180,27 @@ ULL_DEV float act_gelu_erf(float x) {
     const float erf = __builtin_copysignf(1.0f - ec, x);  // 1 - ec >= 0: one v_bfi instead of compare + two subtractions + select
     return 0.5f * x * (1.0f + erf);
 }
+// The same on two values at a time, written on 2-vectors so that the multiplies, adds and FMAs become packed fp32 instructions
+// (v_pk_mul / v_pk_add / v_pk_fma_f32: two lanes of work per issue slot); the reciprocal, the exponential and the sign transfer
+// stay scalar.  Same operations in the same order as act_gelu_erf on each element: identical results.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+ULL_DEV f32x2_t act_gelu_erf2(f32x2_t x) {
+    const f32x2_t ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2_t a = ax * 0.8493218002880191f;
+    const f32x2_t d = __builtin_elementwise_fma(f32x2_t{0.41627730557884884f, 0.41627730557884884f}, a, f32x2_t{1.0f, 1.0f});
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2_t p = {0.24651729790196045f, 0.24651729790196045f};
+#define ULL_H2(c) p = __builtin_elementwise_fma(t, p, f32x2_t{c, c})
+    ULL_H2(-1.1861149450768025f); ULL_H2(2.147474463933521f); ULL_H2(-1.637753152343414f); ULL_H2(0.40232158165127635f);
+    ULL_H2(-0.2687568603388257f); ULL_H2(0.1396300565225048f); ULL_H2(0.5397006155284324f); ULL_H2(1.4427292039075317f);
+#undef ULL_H2
+    const f32x2_t g = __builtin_elementwise_fma(-a, a, __builtin_elementwise_fma(t, p, f32x2_t{-1.825748218405333f, -1.825748218405333f}));
+    const f32x2_t ec = t * f32x2_t{__builtin_amdgcn_exp2f(g.x), __builtin_amdgcn_exp2f(g.y)};
+    const f32x2_t om = f32x2_t{1.0f, 1.0f} - ec;
+    const f32x2_t erf = {__builtin_copysignf(om.x, x.x), __builtin_copysignf(om.y, x.y)};
+    return (x * 0.5f) * (f32x2_t{1.0f, 1.0f} + erf);
+}
+
 // 1 / d for d in [1, inf): the hardware reciprocal (1 ulp) plus one Newton step, three instructions where the IEEE division sequence
 // (v_div_scale / v_rcp / 4 FMAs / v_div_fmas / v_div_fixup) is ten -- the SwiGLU and QuickGELU epilogues are VALU-bound.  The results
 // go through a 16-bit rounding right away; the fixtures and the exhaustive activation tests pin that they do not move.
