@@ -1368,26 +1368,30 @@ __global__ __launch_bounds__(256) void rope_table_kernel(const int64_t* __restri
 // (was rope + two strided copies per layer).  qkv rows = tokens (b, s) of a step, [q | k | v] heads contiguous; the token at
 // step position s goes to cache slot past + s: K cache [B, H, smax, hd] row past + s, V^T cache [B, H, hd, smax] column
 // vt_slot(past + s) (the key-permuted layout of transpose_v_kernel).  One block per token.
-__global__ __launch_bounds__(256) void rope_append_kernel(elem_t* __restrict__ qkv, long row_stride, const int64_t* __restrict__ pos,
-                                                          const float* __restrict__ inv_freq, int S, int H, int hd, elem_t* __restrict__ kc,
-                                                          elem_t* __restrict__ vtc, int smax, int past) {
+__global__ __launch_bounds__(64) void rope_append_kernel(elem_t* __restrict__ qkv, long row_stride, const int64_t* __restrict__ pos,
+                                                         const float* __restrict__ inv_freq, int S, int H, int hd, elem_t* __restrict__ kc,
+                                                         elem_t* __restrict__ vtc, int smax, int past) {
+    // one 64-lane block per (token, head): a decode step is ONE token, and a single block walking all 2H heads and scattering
+    // H * hd cache columns was a 10-us latency chain per layer; H blocks do it in a third of that
     const long tok = blockIdx.x;
+    const int h = blockIdx.y;
     const int b = (int)(tok / S), s = (int)(tok % S);
     const int half = hd >> 1;
-    const int cpr = half >> 3;
-    const int c = threadIdx.x % cpr;
-    const float pf = (float)pos[tok];
-    float cs[8], sn[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float a = pf * inv_freq[c * 8 + j];
-        cs[j] = rnd(cosf(a));
-        sn[j] = rnd(sinf(a));
-    }
+    const int cpr = half >> 3;                                   // 16-byte chunks per half head
     elem_t* xr = qkv + tok * row_stride;
     const int slot_k = past + s;
-    for (int hh = threadIdx.x / cpr; hh < 2 * H; hh += blockDim.x / cpr) {
-        elem_t* p1 = xr + hh * hd + c * 8;
+    if ((int)threadIdx.x < 2 * cpr) {                            // lanes [0, cpr): q head h; [cpr, 2 cpr): k head h
+        const int c = threadIdx.x % cpr;
+        const bool is_k = (int)threadIdx.x >= cpr;
+        const float pf = (float)pos[tok];
+        float cs[8], sn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = pf * inv_freq[c * 8 + j];
+            cs[j] = rnd(cosf(a));
+            sn[j] = rnd(sinf(a));
+        }
+        elem_t* p1 = xr + ((is_k ? H : 0) + h) * hd + c * 8;
         elem_t* p2 = p1 + half;
         float a[8], bb[8], o1[8], o2[8];
         unpack8(*(const uint4*)p1, a);
@@ -1398,19 +1402,19 @@ __global__ __launch_bounds__(256) void rope_append_kernel(elem_t* __restrict__ q
             o2[j] = rnd(bb[j] * cs[j]) + rnd(a[j] * sn[j]);
         }
         const uint4 r1 = pack8(o1), r2 = pack8(o2);
-        if (hh < H) {
+        if (!is_k) {
             *(uint4*)p1 = r1;
             *(uint4*)p2 = r2;
         } else {
-            elem_t* kp = kc + (((long)b * H + (hh - H)) * smax + slot_k) * hd + c * 8;
+            elem_t* kp = kc + (((long)b * H + h) * smax + slot_k) * hd + c * 8;
             *(uint4*)kp = r1;
             *(uint4*)(kp + half) = r2;
         }
     }
     const int w = slot_k & 31;
     const int slot_v = (slot_k & ~31) + 8 * ((w >> 2) & 3) + 4 * (w >> 4) + (w & 3);
-    const elem_t* vr = xr + 2 * H * hd;
-    for (int i = threadIdx.x; i < H * hd; i += blockDim.x) vtc[((long)b * H * hd + i) * smax + slot_v] = vr[i];
+    const elem_t* vr = xr + 2 * H * hd + h * hd;
+    for (int i = threadIdx.x; i < hd; i += 64) vtc[(((long)b * H + h) * hd + i) * smax + slot_v] = vr[i];
 }
 
 // V [B, S, H, hd] (token stride v_ss, heads contiguous) -> Vt [B, H, hd, pitch], zero-filled for keys >= S.
@@ -1661,7 +1665,7 @@ extern "C" int ULL_FN(ull_rope_append_)(void* qkv, int64_t row_stride, const voi
     if (!qkv || !positions || !inv_freq || !k_cache || !vt_cache || B <= 0 || S <= 0) return ULL_ERR_ARG;
     const int64_t cpr = hd >> 4;
     if ((hd & 15) || hd > 256 || (cpr & (cpr - 1)) || (row_stride & 7) || past + S > smax) return ULL_ERR_SHAPE;
-    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, (elem_t*)qkv, row_stride,
+    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)(B * S), (unsigned)H), dim3(64), 0, (hipStream_t)stream, (elem_t*)qkv, row_stride,
                        (const int64_t*)positions, (const float*)inv_freq, (int)S, (int)H, (int)hd, (elem_t*)k_cache, (elem_t*)vt_cache,
                        (int)smax, (int)past);
     return ull_check_launch();
