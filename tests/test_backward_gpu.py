@@ -56,6 +56,18 @@ def test_rmsnorm_swiglu_rope_backward():
     xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
     A.rmsnorm(xd, wd, 1e-6).backward(dy.to(DEV))
     assert rel_l2(xd.grad, xs.grad) < 6e-3 and rel_l2(wd.grad, ws.grad) < 6e-3
+    # ragged / wide / strided rows and the frozen-weight form (the wave-per-row kernel takes D <= 4096, the block kernel the rest)
+    for rows, D, pad, train_w in ((300, 4096, 0, False), (7, 1000, 24, True), (129, 4104, 0, True), (64, 8, 8, True), (33, 4096, 64, True)):
+        xb, dyb = _rand(rows, D + pad, seed=rows, scale=1.5), _rand(rows, D + pad, seed=rows + 1)
+        wb = _rand(D, seed=rows + 2) * 0.2 + 1.0
+        xs, ws = xb[:, :D].float().requires_grad_(True), wb.float().requires_grad_(True)
+        O.rms_norm(xs, ws, 1e-6).backward(dyb[:, :D].float())
+        xg = xb.to(DEV)[:, :D].detach().requires_grad_(True)
+        wg = wb.to(DEV).requires_grad_(train_w)
+        A.rmsnorm(xg, wg, 1e-6).backward(dyb.to(DEV)[:, :D])
+        assert rel_l2(xg.grad, xs.grad) < 6e-3, (rows, D)
+        if train_w:
+            assert rel_l2(wg.grad, ws.grad) < 6e-3, (rows, D)
     # SwiGLU on the interleaved layout
     I = 96
     g, u, da = _rand(20, I, seed=9), _rand(20, I, seed=10), _rand(20, I, seed=11)

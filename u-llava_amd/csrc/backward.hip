@@ -65,6 +65,85 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const elem_t* __restri
     }
 }
 
+// The same for rows of D <= 4096 elements (D % 8 == 0, 16-byte aligned rows): one WAVE per row, the row and its gradient held in
+// registers (16-byte loads, one pass over HBM, wave reductions instead of block barriers).  The scalar kernel above read 2 bytes
+// per lane in three passes with two block reductions per row: 87 us for the 2584 x 4096 rows of the training step, this one ~15.
+template <bool DW>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_wave_kernel(const elem_t* __restrict__ x, long ldx, const elem_t* __restrict__ w,
+                                                               const elem_t* __restrict__ dy, long lddy, elem_t* __restrict__ dx, long lddx,
+                                                               float* __restrict__ dw, long rows, int D, float eps) {
+    constexpr int NCH = 8;                                   // 16-byte chunks per lane: 64 * 8 * 8 = 4096 columns
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const int nchunk = D >> 3;
+    float wv[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) unpack8(*(const uint4*)(w + c * 8), wv[i]);
+    }
+    float dwp[DW ? NCH : 1][8];
+    if constexpr (DW) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dwp[i][j] = 0.f;
+    }
+    for (long row = wave; row < rows; row += nwaves) {
+        uint4 xq[NCH], gq[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            xq[i] = c < nchunk ? *(const uint4*)(x + row * ldx + c * 8) : make_uint4(0, 0, 0, 0);
+            gq[i] = c < nchunk ? *(const uint4*)(dy + row * lddy + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float xv[8];
+            unpack8(xq[i], xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s2 += xv[j] * xv[j];
+        }
+        const float r = rsqrtf(wave_sum(s2) / (float)D + eps);
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (lane + 64 * i < nchunk) {
+                float xv[8], gv[8];
+                unpack8(xq[i], xv); unpack8(gq[i], gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dot += gv[j] * wv[i][j] * (xv[j] * r);
+            }
+        }
+        dot = wave_sum(dot) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float xv[8], gv[8], o[8];
+                unpack8(xq[i], xv); unpack8(gq[i], gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = xv[j] * r;
+                    o[j] = r * (gv[j] * wv[i][j] - xh * dot);
+                    if constexpr (DW) dwp[i][j] += gv[j] * rnd(xh);
+                }
+                *(uint4*)(dx + row * lddx + c * 8) = pack8(o);
+            }
+        }
+    }
+    if constexpr (DW) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(dw + c * 8 + j, dwp[i][j]);
+        }
+    }
+}
+
 // ---- LlamaMLP activation on the interleaved gate/up layout (groups of 16 gate | 16 up columns, ULL_EPI_SWIGLU's weight order) -----
 // forward: a[m, 16g + j] = rnd(rnd(silu(gate)) * up);  backward: d_gate = da * up * silu'(gate), d_up = da * silu(gate).
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const elem_t* __restrict__ gu, elem_t* __restrict__ a, long M, int I) {
@@ -720,6 +799,16 @@ extern "C" int ULL_FN(ull_rmsnorm_bwd_)(const void* x, int64_t ldx, const void* 
                                     int64_t rows, int64_t D, float eps, void* stream) {
     if (!x || !w || !dy || !dx || rows <= 0 || D <= 0) return ULL_ERR_ARG;
     if (D > 256 * RN_MAXC) return ULL_ERR_SHAPE;
+    if (D <= 4096 && (D & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && (lddx & 7) == 0 && ((uintptr_t)w & 15) == 0) {
+        const unsigned wb = (unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+        if (dw)
+            hipLaunchKernelGGL(rmsnorm_bwd_wave_kernel<true>, dim3(wb), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, ldx, (const elem_t*)w,
+                               (const elem_t*)dy, lddy, (elem_t*)dx, lddx, (float*)dw, (long)rows, (int)D, eps);
+        else
+            hipLaunchKernelGGL(rmsnorm_bwd_wave_kernel<false>, dim3(wb), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, ldx, (const elem_t*)w,
+                               (const elem_t*)dy, lddy, (elem_t*)dx, lddx, (float*)dw, (long)rows, (int)D, eps);
+        return ull_check_launch();
+    }
     const unsigned blocks = (unsigned)(rows < 1024 ? rows : 1024);
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, ldx, (const elem_t*)w,
                        (const elem_t*)dy, lddy, (elem_t*)dx, lddx, (float*)dw, (long)rows, (int)D, eps);
