@@ -208,3 +208,43 @@ def test_keywords_stopping_criteria_semantics():
     assert c(torch.tensor([[1, 2, 3, 7, 7]]), None) is True          # last id is the single-token keyword
     assert c(torch.tensor([[1, 2, 3, 4, 6]]), None) is False
     assert c(torch.tensor([[1, 2, 3, 4, 5, 6]]), None) is True       # "t4 t5" appears in the decoded continuation
+
+
+def test_shim_registers_with_the_reference_registry():
+    """models/ullava_core.py:78, models/ullava.py:69: with the reference's `utils.registry` importable (a stand-in with the same
+    `mapping` / `register_model` / `get_model_class` surface here), importing the shim enters both classes under the reference's names,
+    replacing an earlier registration and staying idempotent.  Subprocess: `models` / `utils` must not leak into this session."""
+    import subprocess
+    import sys
+    code = f"""
+import sys, types, os
+ROOT = {ROOT!r}
+utils = types.ModuleType("utils"); utils.__path__ = []
+regmod = types.ModuleType("utils.registry")
+class registry:
+    mapping = {{"model_name_mapping": {{"ullava": object}}}}
+    @classmethod
+    def register_model(cls, name):
+        def wrap(c):
+            if name in cls.mapping["model_name_mapping"]:
+                raise KeyError(name)
+            cls.mapping["model_name_mapping"][name] = c
+            return c
+        return wrap
+    @classmethod
+    def get_model_class(cls, name):
+        return cls.mapping["model_name_mapping"].get(name, None)
+regmod.registry = registry
+sys.modules["utils"] = utils; sys.modules["utils.registry"] = regmod
+sys.path.insert(0, os.path.join(ROOT, "u-llava_amd", "shim"))
+import models
+assert registry.get_model_class("ullava_core") is models.UllavaCoreForCausalLM
+assert registry.get_model_class("ullava") is models.UllavaForCausalLM
+import importlib
+hf = importlib.import_module("u-llava_amd.hf_integration")
+assert hf.register_with_reference_registry() is True          # idempotent
+assert registry.get_model_class("ullava") is models.UllavaForCausalLM
+print("OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]

@@ -58,3 +58,22 @@ def register_with_transformers() -> bool:
             pass                                                # already registered in this process (e.g. by the reference itself)
     _DONE = True
     return True
+
+
+def register_with_reference_registry() -> bool:
+    """models/ullava_core.py:78, models/ullava.py:69 (`@registry.register_model('ullava_core' / 'ullava')`): when the reference's own
+    `utils.registry` is importable -- the callers run from the reference checkout with the shim in front of it on sys.path -- the two
+    model classes are entered under the reference's names, so `registry.get_model_class(cfg.model.arch)` (utils/config_builder.py:46,
+    tasks/base_task.py:15) resolves to the MI355X implementation.  Idempotent; returns False when there is no such registry."""
+    try:
+        reg = importlib.import_module("utils.registry").registry
+        mapping = reg.mapping["model_name_mapping"]
+    except Exception:
+        return False
+    MC = importlib.import_module("u-llava_amd.modeling_core")
+    MU = importlib.import_module("u-llava_amd.modeling_ullava")
+    for name, cls in (("ullava_core", MC.UllavaCoreForCausalLM), ("ullava", MU.UllavaForCausalLM)):
+        if mapping.get(name) is not cls:
+            mapping.pop(name, None)                             # (the reference's own class, had its models package been imported first)
+            reg.register_model(name)(cls)
+    return True

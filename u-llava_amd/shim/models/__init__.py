@@ -42,6 +42,8 @@ IGNORE_INDEX = -100
 
 # models/ullava_core.py:398-399, models/ullava.py:437-438: AutoConfig / AutoModelForCausalLM registration (when transformers is there)
 _hf.register_with_transformers()
+# models/ullava_core.py:78, models/ullava.py:69: @registry.register_model (when the reference's utils.registry is importable)
+_hf.register_with_reference_registry()
 
 __all__ = ["UllavaConfig", "UllavaForCausalLM", "UllavaCoreConfig", "UllavaCoreForCausalLM", "KeywordsStoppingCriteria",
            "smart_resize_token_embedding", "multi_modal_resize_token_embedding", "smart_special_token_and_embedding_resize",
