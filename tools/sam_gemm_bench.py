@@ -15,8 +15,8 @@ TUNE = int(os.environ.get("TUNE", 0))
 g = torch.Generator(device=dev).manual_seed(0)
 
 
-def timeit(fn, it=20):
-    for _ in range(5):
+def timeit(fn, it=40):
+    for _ in range(40):          # the clock settles over the first ~10 ms of a new kernel mix: a short warm-up reads 3-10 % slow
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
