@@ -313,9 +313,11 @@ int ull_attention_bwd_bf16(const void* Q, const void* K, const void* V, const vo
                            const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal,
                            float mult, void* scratch, void* stream);
 
-/* The same backward on the matrix cores, for hd = 64 / 128 (the LLaMA block): same arguments plus Qt, Kt, dOt = the
- * ull_transpose_v_bf16 images [B, H, hd, pitch] of Q, K and dO (pitch >= ceil64(max(Sq, Sk))); every stride a multiple of 4
- * elements, token strides of 8.  scratch: float32 [2 * B * H * ceil64(Sq)].  No atomics, same fp32 softmax recomputation. */
+/* The same backward on the matrix cores, for hd = 64 / 128: same arguments plus Qt, Kt, dOt = the ull_transpose_v_bf16 images
+ * [B, H, hd, pitch] of Q, K and dO (pitch >= ceil64(max(Sq, Sk))); every stride a multiple of 4 elements, token strides of 8.
+ * hd = 128 (the LLaMA block) stages the operand tiles through the LDS and takes the transposed fragments from the transposing LDS
+ * read: Qt / Kt / dOt are not read there and may be NULL.  scratch: float32 [2 * B * H * ceil64(Sq)].  No atomics, same fp32
+ * softmax recomputation. */
 int ull_attention_bwd_mfma_bf16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* Qt, const void* Kt,
                                 const void* dOt, int64_t pitch, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask,
                                 int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);

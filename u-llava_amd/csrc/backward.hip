@@ -563,6 +563,297 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnBwdArgs p, c
     }
 }
 
+// ---- the same two kernels for hd = 128 with the streamed operand tiles shared through the LDS -------------------------------------
+// The direct form above gives every wave its own 16-byte fragment loads from global memory: four waves of a block fetch the same Q / dO
+// (or K / V) rows and their transposed images, one vector-memory instruction per MFMA -- the texture path, not the matrix pipe, is
+// the bound (64 loads against 64 MFMAs per wave and tile: ~4x the MFMA time per CU).  Here a block DMAs each 64-row tile once
+// ([64 rows][256 B], double-buffered), all four waves read their fragments from it, and the transposed operands of the dV / dK / dQ
+// products come out of the SAME row-major tile through ds_read_b64_tr_b16 -- no Q^T / K^T / dO^T images at all.
+// Chunk position inside a row: 32-byte pairs XOR (row & 7), the chunk inside a pair XOR bit 3 of the row: conflict-free for the
+// 16-row ds_read_b128 of the "row" operands and for the 4-rows-by-32-bytes pattern of the transposing read.
+ULL_DEV void bw_glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */) {
+    uint32_t keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+typedef uint32_t bw_u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+ULL_DEV bw_u32x2 bw_tr(uint32_t addr) {      // lane i of a 16-lane group: address of row i / 4, 4 elements at column 4 * (i % 4); gets column i
+    bw_u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+ULL_DEV void bw_tr_wait(bw_u32x2 (&a)[4], bw_u32x2 (&b)[4]) {     // the compiler does not know the reads above are LDS loads
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory");
+}
+constexpr int BW_TILE = 64 * 256;            // one [64 rows][128 x 16-bit] tile
+ULL_DEV int bw_pos(int c, int r) { return (((c >> 1) ^ (r & 7)) << 1) | ((c & 1) ^ ((r >> 3) & 1)); }      // (its own inverse in c)
+// this wave's quarter (4 of 16 one-KiB pieces) of tile rows first .. first + 63 (clamped to last) of a [rows][hd = 128] operand
+ULL_DEV void bw_stage(const elem_t* base, long stride, int first, int last, uint32_t dst, int wave, int lane) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = wave * 4 + k;
+        const int row = i * 4 + (lane >> 4);
+        const int c = bw_pos(lane & 15, row);
+        bw_glds16(base + (long)min(first + row, last) * stride + c * 8, dst + i * 1024);
+    }
+}
+// "row" fragment (A operand, rows = tile rows, k = 8 head dims): row blk * 16 + fr, dims ks * 32 + fg * 8 .. +7
+ULL_DEV uint4 bw_rowfrag(const char* tile, int blk, int ks, int fr, int fg) {
+    const int row = blk * 16 + fr;
+    return *(const uint4*)(tile + row * 256 + bw_pos(ks * 4 + fg, row) * 16);
+}
+// per-lane base address for the transposed fragments of a tile: head dim 16 * db + fr of rows half * 32 + 4 * fg + {0..3} (+ 16)
+ULL_DEV uint32_t bw_tr_base(uint32_t tile, int fr, int fg) {
+    return tile + (4 * fg + (fr >> 2)) * 256 + ((((fr & 3) >> 1) ^ (fg >> 1)) << 4) + ((fr & 1) << 3);
+}
+// acc[d0 + j] += (tile^T fragment of head-dim block d0 + j, rows half * 32 ..) x bfrag, j < 4
+template <int HALF>
+ULL_DEV void bw_tr_mma4(uint32_t trb, int swr, int d0, const uint4& bfrag, f32x4_t* acc) {
+    bw_u32x2 va[4], vc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t ad = trb + (((d0 + j) ^ swr) << 5);
+        va[j] = bw_tr<HALF * 32 * 256>(ad);
+        vc[j] = bw_tr<HALF * 32 * 256 + 16 * 256>(ad);
+    }
+    bw_tr_wait(va, vc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[d0 + j] = mfma16(make_uint4(va[j].x, va[j].y, vc[j].x, vc[j].y), bfrag, acc[d0 + j]);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_tiles_kernel(AttnBwdArgs p, int sqp) {
+    extern __shared__ __attribute__((aligned(16))) char bsm[];                  // 2 x [K tile | V tile]
+    constexpr int NKS = 4, NDB = 8;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fg = lane >> 4;
+    const int q = blockIdx.x * 64 + wave * 16 + fr;
+    const int qc = min(q, p.Sq - 1);
+    const int shift = p.Sk - p.Sq;
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)bsm);
+    uint4 qf[NKS], gf[NKS];
+    float delta = 0.f;
+    {
+        const elem_t* qp = p.Q + b * p.q_bs + h * p.q_hs + (long)qc * p.q_ss;
+        const elem_t* gp = p.dO + b * p.g_bs + h * p.g_hs + (long)qc * p.g_ss;
+        const elem_t* op = p.O + b * p.o_bs + h * p.o_hs + (long)qc * p.o_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[ks] = *(const uint4*)(qp + ks * 32 + fg * 8);
+            gf[ks] = *(const uint4*)(gp + ks * 32 + fg * 8);
+            float g8[8], o8[8];
+            unpack8(gf[ks], g8);
+            unpack8(*(const uint4*)(op + ks * 32 + fg * 8), o8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta += g8[e] * o8[e];
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+    }
+    const int kend = p.causal ? min(p.Sk, blockIdx.x * 64 + 63 + shift + 1) : p.Sk;
+    const int nkt = (kend + 63) / 64;
+    const elem_t* kbase = p.K + b * p.k_bs + h * p.k_hs;
+    const elem_t* vbase = p.V + b * p.v_bs + h * p.v_hs;
+    const int32_t* km = p.key_mask ? p.key_mask + (long)b * p.Sk : nullptr;
+    auto visible = [&](int key) { return key < p.Sk && (!p.causal || key <= q + shift) && (km == nullptr || km[key] != 0); };
+    // ---- pass 1: log-sum-exp of the row (K tiles only) ---------------------------------------------------------------------------
+    float m = -INFINITY, l = 0.f;
+    bw_stage(kbase, p.k_ss, 0, p.Sk - 1, lds, wave, lane);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nkt) bw_stage(kbase, p.k_ss, (kt + 1) * 64, p.Sk - 1, lds + ((kt + 1) & 1) * 2 * BW_TILE, wave, lane);
+        const char* tk = bsm + (kt & 1) * 2 * BW_TILE;
+        float sv[16];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) acc = mfma16(bw_rowfrag(tk, cb, ks, fr, fg), qf[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = visible(kt * 64 + cb * 16 + fg * 4 + r) ? acc[r] * p.mult : -INFINITY;
+                sv[cb * 4 + r] = sc;
+                mt = fmaxf(mt, sc);
+            }
+        }
+        const float mn = fmaxf(m, mt);
+        if (mn > -INFINITY) {
+            float add = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) add += __expf(sv[e] - mn);
+            l = l * __expf(m - mn) + add;
+            m = mn;
+        }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+        const float mn = fmaxf(m, m2);
+        if (mn > -INFINITY) l = l * __expf(m - mn) + l2 * __expf(m2 - mn);
+        m = mn;
+    }
+    const float lse = l > 0.f ? m + __logf(l) : INFINITY;
+    if (fg == 0 && q < p.Sq) {
+        p.lse[(long)bh * sqp + q] = lse;
+        p.delta[(long)bh * sqp + q] = delta;
+    }
+    // ---- pass 2: dS and dQ^T (K and V tiles) ------------------------------------------------------------------------------------------
+    f32x4_t dq[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) dq[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int swr = 4 * (fg & 1) + (fr >> 2);
+    __builtin_amdgcn_s_barrier();                                   // pass 1's last tile has been read by every wave
+    bw_stage(kbase, p.k_ss, 0, p.Sk - 1, lds, wave, lane);
+    bw_stage(vbase, p.v_ss, 0, p.Sk - 1, lds + BW_TILE, wave, lane);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nkt) {
+            const uint32_t nb = lds + ((kt + 1) & 1) * 2 * BW_TILE;
+            bw_stage(kbase, p.k_ss, (kt + 1) * 64, p.Sk - 1, nb, wave, lane);
+            bw_stage(vbase, p.v_ss, (kt + 1) * 64, p.Sk - 1, nb + BW_TILE, wave, lane);
+        }
+        const char* tk = bsm + (kt & 1) * 2 * BW_TILE;
+        const char* tv = tk + BW_TILE;
+        uint32_t dsp[8];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                sa = mfma16(bw_rowfrag(tk, cb, ks, fr, fg), qf[ks], sa);
+                da = mfma16(bw_rowfrag(tv, cb, ks, fr, fg), gf[ks], da);
+            }
+            float ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = visible(kt * 64 + cb * 16 + fg * 4 + r) ? __expf(sa[r] * p.mult - lse) : 0.f;
+                ds[r] = pr * (da[r] - delta) * p.mult;
+            }
+            dsp[cb * 2] = pack2e(ds[0], ds[1]);
+            dsp[cb * 2 + 1] = pack2e(ds[2], ds[3]);
+        }
+        const uint32_t trk = bw_tr_base(lds + (kt & 1) * 2 * BW_TILE, fr, fg);
+        {
+            const uint4 bf = make_uint4(dsp[0], dsp[1], dsp[2], dsp[3]);
+            bw_tr_mma4<0>(trk, swr, 0, bf, dq);
+            bw_tr_mma4<0>(trk, swr, 4, bf, dq);
+        }
+        {
+            const uint4 bf = make_uint4(dsp[4], dsp[5], dsp[6], dsp[7]);
+            bw_tr_mma4<1>(trk, swr, 0, bf, dq);
+            bw_tr_mma4<1>(trk, swr, 4, bf, dq);
+        }
+    }
+    if (q < p.Sq) {
+        elem_t* dst = p.dQ + b * p.dq_bs + h * p.dq_hs + (long)q * p.dq_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            uint2 o;
+            o.x = pack2e(dq[db][0], dq[db][1]);
+            o.y = pack2e(dq[db][2], dq[db][3]);
+            *(uint2*)(dst + db * 16 + fg * 4) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_tiles_kernel(AttnBwdArgs p, int sqp) {
+    extern __shared__ __attribute__((aligned(16))) char bsm[];                  // 2 x [Q tile | dO tile]
+    constexpr int NKS = 4, NDB = 8;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, fg = lane >> 4;
+    const int j = blockIdx.x * 64 + wave * 16 + fr;           // this lane's key (B-operand row)
+    const int jc = min(j, p.Sk - 1);
+    const int shift = p.Sk - p.Sq;
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)bsm);
+    uint4 kf[NKS], vf[NKS];
+    {
+        const elem_t* kp = p.K + b * p.k_bs + h * p.k_hs + (long)jc * p.k_ss;
+        const elem_t* vp = p.V + b * p.v_bs + h * p.v_hs + (long)jc * p.v_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *(const uint4*)(kp + ks * 32 + fg * 8);
+            vf[ks] = *(const uint4*)(vp + ks * 32 + fg * 8);
+        }
+    }
+    const bool key_ok = j < p.Sk && (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0);
+    const int qbeg = p.causal ? max(0, blockIdx.x * 64 - shift) : 0;        // first query that can see a key of this block
+    const int nqt = (p.Sq + 63) / 64, qt0 = qbeg / 64;
+    const elem_t* qbase = p.Q + b * p.q_bs + h * p.q_hs;
+    const elem_t* gbase = p.dO + b * p.g_bs + h * p.g_hs;
+    const float* lsep = p.lse + (long)bh * sqp;
+    const float* delp = p.delta + (long)bh * sqp;
+    f32x4_t dk[NDB], dv[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) { dk[db] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const int swr = 4 * (fg & 1) + (fr >> 2);
+    if (qt0 < nqt) {
+        bw_stage(qbase, p.q_ss, qt0 * 64, p.Sq - 1, lds, wave, lane);
+        bw_stage(gbase, p.g_ss, qt0 * 64, p.Sq - 1, lds + BW_TILE, wave, lane);
+    }
+    for (int qt = qt0; qt < nqt; ++qt) {
+        const int buf = (qt - qt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (qt + 1 < nqt) {
+            const uint32_t nb = lds + (buf ^ 1) * 2 * BW_TILE;
+            bw_stage(qbase, p.q_ss, (qt + 1) * 64, p.Sq - 1, nb, wave, lane);
+            bw_stage(gbase, p.g_ss, (qt + 1) * 64, p.Sq - 1, nb + BW_TILE, wave, lane);
+        }
+        const char* tq = bsm + buf * 2 * BW_TILE;
+        const char* tg = tq + BW_TILE;
+        uint32_t pp[8], dsp[8];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                sa = mfma16(bw_rowfrag(tq, qb, ks, fr, fg), kf[ks], sa);
+                da = mfma16(bw_rowfrag(tg, qb, ks, fr, fg), vf[ks], da);
+            }
+            // sa[r] = S[query i = qt*64 + qb*16 + 4fg + r][key j]
+            const int i0 = qt * 64 + qb * 16 + fg * 4;
+            const f32x4_t l4 = *(const f32x4_t*)(lsep + i0), d4 = *(const f32x4_t*)(delp + i0);
+            float pr[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + r;
+                const bool vis = key_ok && i < p.Sq && (!p.causal || j <= i + shift);
+                pr[r] = vis ? __expf(sa[r] * p.mult - l4[r]) : 0.f;
+                ds[r] = vis ? pr[r] * (da[r] - d4[r]) * p.mult : 0.f;
+            }
+            pp[qb * 2] = pack2e(pr[0], pr[1]); pp[qb * 2 + 1] = pack2e(pr[2], pr[3]);
+            dsp[qb * 2] = pack2e(ds[0], ds[1]); dsp[qb * 2 + 1] = pack2e(ds[2], ds[3]);
+        }
+        const uint32_t trq = bw_tr_base(lds + buf * 2 * BW_TILE, fr, fg), trg = trq + BW_TILE;
+        {
+            const uint4 bp = make_uint4(pp[0], pp[1], pp[2], pp[3]), bd = make_uint4(dsp[0], dsp[1], dsp[2], dsp[3]);
+            bw_tr_mma4<0>(trg, swr, 0, bp, dv); bw_tr_mma4<0>(trg, swr, 4, bp, dv);
+            bw_tr_mma4<0>(trq, swr, 0, bd, dk); bw_tr_mma4<0>(trq, swr, 4, bd, dk);
+        }
+        {
+            const uint4 bp = make_uint4(pp[4], pp[5], pp[6], pp[7]), bd = make_uint4(dsp[4], dsp[5], dsp[6], dsp[7]);
+            bw_tr_mma4<1>(trg, swr, 0, bp, dv); bw_tr_mma4<1>(trg, swr, 4, bp, dv);
+            bw_tr_mma4<1>(trq, swr, 0, bd, dk); bw_tr_mma4<1>(trq, swr, 4, bd, dk);
+        }
+    }
+    if (j < p.Sk) {
+        elem_t* dkp = p.dK + b * p.dk_bs + h * p.dk_hs + (long)j * p.dk_ss;
+        elem_t* dvp = p.dV + b * p.dv_bs + h * p.dv_hs + (long)j * p.dv_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            uint2 o;
+            o.x = pack2e(dk[db][0], dk[db][1]); o.y = pack2e(dk[db][2], dk[db][3]);
+            *(uint2*)(dkp + db * 16 + fg * 4) = o;
+            o.x = pack2e(dv[db][0], dv[db][1]); o.y = pack2e(dv[db][2], dv[db][3]);
+            *(uint2*)(dvp + db * 16 + fg * 4) = o;
+        }
+    }
+}
+
 // ---- models/ullava_core.py:327-338 backward: d/dlogits of mean CE(logits[:, :-1], labels[:, 1:]) ----------------------------------
 // dlogits[b, s, :] = (softmax(logits[b, s]) - onehot(labels[b, s + 1])) * g / count for counted positions, 0 elsewhere.
 // stats float[2] = {sum of token losses, counted tokens} from the forward; gout = pointer to the upstream gradient (one float).
@@ -868,11 +1159,12 @@ extern "C" int ULL_FN(ull_attention_bwd_)(const void* Q, const void* K, const vo
 extern "C" int ULL_FN(ull_attention_bwd_mfma_)(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* Qt, const void* Kt,
                                            const void* dOt, int64_t pitch, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask,
                                            int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream) {
-    if (!Q || !K || !V || !O || !dO || !Qt || !Kt || !dOt || !dQ || !dK || !dV || !strides || !scratch || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0)
-        return ULL_ERR_ARG;
+    if (!Q || !K || !V || !O || !dO || !dQ || !dK || !dV || !strides || !scratch || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) return ULL_ERR_ARG;
     if (hd != 64 && hd != 128) return ULL_ERR_SHAPE;
+    const bool tiles = hd == 128;              // LDS-tile kernels: transposed operands through the transposing LDS read, no images needed
+    if (!tiles && (!Qt || !Kt || !dOt)) return ULL_ERR_ARG;
     const int64_t need = ((Sq > Sk ? Sq : Sk) + 63) / 64 * 64;
-    if (pitch < need || (pitch & 7)) return ULL_ERR_SHAPE;
+    if (!tiles && (pitch < need || (pitch & 7))) return ULL_ERR_SHAPE;
     for (int i = 0; i < 24; ++i)
         if (strides[i] & 3) return ULL_ERR_SHAPE;              // 8-byte fragment stores / 16-byte loads need aligned rows
     AttnBwdArgs p;
@@ -889,7 +1181,12 @@ extern "C" int ULL_FN(ull_attention_bwd_mfma_)(const void* Q, const void* K, con
     p.lse = (float*)scratch; p.delta = (float*)scratch + B * H * sqp;
     p.B = (int)B; p.H = (int)H; p.Sq = (int)Sq; p.Sk = (int)Sk; p.hd = (int)hd; p.causal = causal; p.mult = mult;
     const dim3 gq((unsigned)((Sq + 63) / 64), (unsigned)(B * H)), gk((unsigned)((Sk + 63) / 64), (unsigned)(B * H));
-    if (hd == 128) {
+    if (tiles) {
+        for (int i = 1; i < 15; i += 3)
+            if (s[i] & 7) return ULL_ERR_SHAPE;                // head strides of Q, K, V, O, dO: the DMA copies 16-byte chunks
+        hipLaunchKernelGGL(attn_bwd_dq_tiles_kernel, gq, dim3(256), 4 * BW_TILE, (hipStream_t)stream, p, sqp);
+        hipLaunchKernelGGL(attn_bwd_dkv_tiles_kernel, gk, dim3(256), 4 * BW_TILE, (hipStream_t)stream, p, sqp);
+    } else if (hd == 128) {
         hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<128>, gq, dim3(256), 0, (hipStream_t)stream, p, (const elem_t*)Kt, (int)pitch, sqp);
         hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<128>, gk, dim3(256), 0, (hipStream_t)stream, p, (const elem_t*)Qt, (const elem_t*)dOt, (int)pitch, sqp);
     } else {

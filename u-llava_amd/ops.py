@@ -615,11 +615,14 @@ def attention_bwd(q, k, v, o, do, dq, dk, dv, strides, key_mask, B: int, H: int,
     arr = (ctypes.c_int64 * 24)(*flat)
     (q_bs, q_hs, q_ss), (k_bs, k_hs, k_ss), _, _, (g_bs, g_hs, g_ss) = strides[:5]
     if hd in (64, 128) and q_hs == hd and k_hs == hd and g_hs == hd and all(x % 4 == 0 for x in flat) and all(flat[i] % 8 == 0 for i in range(2, 24, 3)):
-        # matrix-core kernels: they want Q, K and dO also as transpose_v images (keys / queries permuted inside 32-blocks)
+        # matrix-core kernels.  hd 128 (the LLaMA block): operand tiles staged through the LDS, transposed fragments from the
+        # transposing LDS read.  hd 64: fragments straight from global memory; Q, K and dO also as transpose_v images.
         pitch = ((max(Sq, Sk) + 63) // 64) * 64
-        qt = transpose_v(q, q_bs, q_ss, B, Sq, H, hd, pitch)
-        kt = transpose_v(k, k_bs, k_ss, B, Sk, H, hd, pitch)
-        gt = transpose_v(do, g_bs, g_ss, B, Sq, H, hd, pitch)
+        qt = kt = gt = None
+        if hd != 128:
+            qt = transpose_v(q, q_bs, q_ss, B, Sq, H, hd, pitch)
+            kt = transpose_v(k, k_bs, k_ss, B, Sk, H, hd, pitch)
+            gt = transpose_v(do, g_bs, g_ss, B, Sq, H, hd, pitch)
         scratch = torch.empty(2 * B * H * (((Sq + 63) // 64) * 64), device=q.device, dtype=torch.float32)
         _lib.call("ull_attention_bwd_mfma_" + _SFX[q.dtype], _p(q), _p(k), _p(v), _p(o), _p(do), _p(qt), _p(kt), _p(gt), pitch, _p(dq), _p(dk), _p(dv),
                   arr, _p(key_mask), B, H, Sq, Sk, hd, int(causal), float(mult), _p(scratch), _stream())
