@@ -146,26 +146,42 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_wave_kernel(const elem_t* __r
 
 // ---- LlamaMLP activation on the interleaved gate/up layout (groups of 16 gate | 16 up columns, ULL_EPI_SWIGLU's weight order) -----
 // forward: a[m, 16g + j] = rnd(rnd(silu(gate)) * up);  backward: d_gate = da * up * silu'(gate), d_up = da * silu(gate).
+// (16-byte accesses: a chunk of 8 outputs 16g + 8h .. +7 reads the gate chunk at column 32g + 8h and the up chunk 16 columns on)
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const elem_t* __restrict__ gu, elem_t* __restrict__ a, long M, int I) {
-    const long total = M * I;
+    const int cpr = I >> 3;                                  // output chunks per row
+    const long total = M * cpr;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long m = i / I;
-        const int c = (int)(i % I), g = c >> 4, j = c & 15;
-        const float gate = e2f(gu[m * 2 * I + g * 32 + j]), up = e2f(gu[m * 2 * I + g * 32 + 16 + j]);
-        a[i] = f2e(rnd(act_silu(gate)) * up);
+        const long m = i / cpr;
+        const int oc = (int)(i % cpr), g = oc >> 1, hh = oc & 1;
+        const elem_t* src = gu + m * 2 * I + g * 32 + hh * 8;
+        float gate[8], up[8], o[8];
+        unpack8(*(const uint4*)src, gate);
+        unpack8(*(const uint4*)(src + 16), up);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rnd(act_silu(gate[e])) * up[e];
+        *(uint4*)(a + m * I + oc * 8) = pack8(o);
     }
 }
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const elem_t* __restrict__ gu, const elem_t* __restrict__ da, elem_t* __restrict__ dgu,
                                                          long M, int I) {
-    const long total = M * I;
+    const int cpr = I >> 3;
+    const long total = M * cpr;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long m = i / I;
-        const int c = (int)(i % I), g = c >> 4, j = c & 15;
-        const long ig = m * 2 * I + g * 32 + j, iu = ig + 16;
-        const float gate = e2f(gu[ig]), up = e2f(gu[iu]), d = e2f(da[i]);
-        const float s = act_sigmoid(gate);
-        dgu[ig] = f2e(d * up * (s * (1.0f + gate * (1.0f - s))));
-        dgu[iu] = f2e(d * (gate * s));
+        const long m = i / cpr;
+        const int oc = (int)(i % cpr), g = oc >> 1, hh = oc & 1;
+        const long ig = m * 2 * I + g * 32 + hh * 8;
+        float gate[8], up[8], d[8], og[8], ou[8];
+        unpack8(*(const uint4*)(gu + ig), gate);
+        unpack8(*(const uint4*)(gu + ig + 16), up);
+        unpack8(*(const uint4*)(da + m * I + oc * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s = act_sigmoid(gate[e]);
+            og[e] = d[e] * up[e] * (s * (1.0f + gate[e] * (1.0f - s)));
+            ou[e] = d[e] * (gate[e] * s);
+        }
+        *(uint4*)(dgu + ig) = pack8(og);
+        *(uint4*)(dgu + ig + 16) = pack8(ou);
     }
 }
 
