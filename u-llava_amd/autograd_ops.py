@@ -147,10 +147,10 @@ class _SelfAttention(torch.autograd.Function):
     def forward(ctx, qkv, key_mask, B, S, H, hd, causal):
         D = H * hd
         T = B * S
-        vt = ops.transpose_v(qkv[:, 2 * D:], S * 3 * D, 3 * D, B, S, H, hd)
         att = torch.empty(T, D, device=qkv.device, dtype=qkv.dtype)
-        st = (S * 3 * D, hd, 3 * D)
-        ops.attention(qkv, qkv[:, D:], vt, att, B, H, S, S, hd, st, st, (S * D, hd, D), key_mask, causal=causal, scale_mode=1, scale=hd ** -0.5)
+        st = (S * 3 * D, hd, 3 * D)                 # V as rows of the q|k|v buffer (the wrapper makes the V^T image where no kernel takes rows)
+        ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], att, B, H, S, S, hd, st, st, (S * D, hd, D), key_mask, causal=causal, scale_mode=1,
+                      scale=hd ** -0.5, v_strides=st)
         ctx.save_for_backward(qkv, att, key_mask)
         ctx.dims = (B, S, H, hd, causal)
         return att
