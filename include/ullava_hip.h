@@ -83,6 +83,11 @@ int64_t ull_gemm_streamk_ws_bytes(void);
 int ull_gemv_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                   int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
+/* The same contract for 2 <= M <= 16 (batched decode steps) on the matrix cores: 16 output features x 16 padded rows per 16x16x32
+ * MFMA, weights streamed once, K % 32 == 0. */
+int ull_gemm_skinny_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
+                         int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+
 /* ull_gemv_bf16 with the preceding LlamaRMSNorm fused in: C = epilogue(rmsnorm(X; norm_w, eps) * W^T), M * K <= 16384.
  * Decode-step form of input_layernorm -> q/k/v_proj and post_attention_layernorm -> gate/up_proj (hf LlamaDecoderLayer.forward). */
 int ull_gemv_rmsnorm_bf16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -377,6 +382,7 @@ int ull_gemm_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C
 int ull_gemm_qkv_rope_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const void* rope_cos, const void* rope_sin, int64_t rope_cols, int64_t head_dim, int flags, void* ws, int64_t ws_bytes, void* stream);
 int ull_rope_table_f16(const void* positions, const void* inv_freq, int64_t tokens, int64_t half, void* cos_out, void* sin_out, void* stream);
 int ull_gemv_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+int ull_gemm_skinny_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 int ull_gemv_rmsnorm_f16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 int ull_rmsnorm_f16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
 int ull_shifted_cross_entropy_f16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, void* out, void* stream);

@@ -72,6 +72,44 @@ def test_gemv_decode_shapes(M):
     assert_close_bf16(y, F.silu(_mm_ref(x, wg)) * _mm_ref(x, wu), what="gemv swiglu")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [2, 4, 5, 8, 16])
+def test_skinny_gemm_batched_decode_shapes(M, dt):
+    """2 <= M <= 16 against LLaMA-sized weights (ull_gemm_skinny: the weight stream on the matrix cores): every epilogue of the
+    decode step, a vocabulary that is not a multiple of 16, the fused RMSNorm form -- against fp32 references and against the same
+    rows pushed through the M = 1 GEMV one by one (same rounding points; fp32 summation order differs)."""
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    g = torch.Generator().manual_seed(M)
+    def rnd_t(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(dt)
+    def close(a, b, what):
+        a, b = a.float().cpu(), b.float().cpu()
+        bound = b.abs().clamp_min(float(b.abs().max()) * 1e-2) * ulp * 2.02
+        bad = (a - b).abs() > bound
+        assert float(bad.float().mean()) <= 2e-3, f"{what}: {int(bad.sum())}/{bad.numel()} beyond 2 ulp"
+    K, N = 4096, 1043                     # N * K >= 2^22, N % 16 != 0
+    x, w, b, r = rnd_t(M, K), rnd_t(N, K, scale=K ** -0.5), rnd_t(N), rnd_t(M, N)
+    xd, wd = x.to(DEV), w.to(DEV)
+    ref = x.double() @ w.double().t()
+    close(ops.linear(xd, wd), ref.to(dt), "plain")
+    close(ops.linear(xd, wd, b.to(DEV), residual=r.to(DEV)), (r.double() + (ref + b.double()).to(dt).double()).to(dt), "bias + residual")
+    close(ops.linear(xd, wd, b.to(DEV), act="gelu"), F.gelu((ref + b.double()).to(dt).float()).to(dt), "bias + gelu")
+    out32 = ops.linear(xd, wd, out_f32=True)
+    assert out32.dtype == torch.float32 and float((out32.cpu().double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    one_by_one = torch.cat([ops.linear(xd[i:i + 1], wd, b.to(DEV), residual=r.to(DEV)[i:i + 1]) for i in range(M)])
+    close(ops.linear(xd, wd, b.to(DEV), residual=r.to(DEV)), one_by_one, "against the GEMV row by row")
+    I = 2048
+    wg, wu = rnd_t(I, K, scale=K ** -0.5), rnd_t(I, K, scale=K ** -0.5)
+    y = ops.linear(xd, M_.interleave_gate_up(wg, wu).to(DEV), swiglu=True)
+    gate, up = (x.double() @ wg.double().t()).to(dt), (x.double() @ wu.double().t()).to(dt)
+    close(y, (F.silu(gate.float()).to(dt).float() * up.float()).to(dt), "swiglu")
+    nw = rnd_t(K) * 0.1 + 1.0
+    xn = O.rms_norm(x, nw, 1e-6) if dt == torch.bfloat16 else None
+    if xn is not None:
+        close(ops.linear(xd, wd, rms_w=nw.to(DEV), rms_eps=1e-6), (xn.double() @ w.double().t()).to(dt), "rmsnorm + linear")
+
+
 @pytest.mark.parametrize("M,K", [(1, 4096), (4, 4096), (2, 1088), (1, 11008)])
 def test_gemv_fused_rmsnorm(M, K):
     """decode-step input_layernorm -> projection in one launch == the two separate kernels == the reference ops."""

@@ -142,6 +142,109 @@ __global__ __launch_bounds__(256) void gemv_kernel(const elem_t* __restrict__ X,
     }
 }
 
+// ---- 2 <= M <= 16 (batched decode steps): the same weight stream on the matrix cores -------------------------------------------------
+// At M = 4 the GEMV above already spends more time on its 4 x 8 FMAs per weight chunk than on the stream (2.2 TB/s), and M > 4 fell
+// to the 128 x 128 GEMM whose grid is a few dozen blocks.  Here 16 output features x 16 (padded) rows of X are one 16x16x32 MFMA per
+// 64 bytes of each weight row: a block of 8 waves owns 16 features (SwiGLU: 16 gate + 16 up rows), every wave one eighth of K,
+// weight fragments straight from HBM (8 in flight per lane), X fragments from L2 (M x K x 2 bytes, shared by every block), partial
+// sums through LDS, then the GEMV's epilogue (same flags, same rounding points).  MFMA work is 16 / M times the useful flops and
+// still far below the stream's time.
+template <bool SW>
+__global__ __launch_bounds__(512) void skinny_gemm_kernel(const elem_t* __restrict__ X, long ldx, const elem_t* __restrict__ W, long ldw, void* C,
+                                                          long ldc, const elem_t* __restrict__ bias, const elem_t* __restrict__ R, long ldr, int M,
+                                                          int N, int K, int flags, int n_out) {
+    __shared__ f32x4_t part[SW ? 2 : 1][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+    const int o0 = blockIdx.x * 16;                              // first output feature of the block
+    // weight row of A-operand row fr: plain: o0 + fr; SwiGLU pack: gate rows (o0/16)*32 + fr, up rows 16 below
+    const int wr0 = SW ? (o0 >> 4) * 32 + fr : min(o0 + fr, N - 1);
+    const elem_t* w0 = W + (long)wr0 * ldw + fg * 8;
+    const elem_t* w1 = w0 + 16 * ldw;
+    const elem_t* xr = X + (long)min(fr, M - 1) * ldx + fg * 8;  // rows >= M repeat the last row: those accumulator columns are not stored
+    const int nks = K >> 5;                                      // 32-wide k-steps
+    const int ks0 = (int)((long)nks * wave / 8), ks1 = (int)((long)nks * (wave + 1) / 8);
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = SW ? 4 : 8;              // (SwiGLU streams two weight rows per fragment: 8 would cost the second block per CU its registers)
+    for (int k0 = ks0; k0 < ks1; k0 += U) {
+        uint4 wq[U], uq[U], xq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = min(k0 + u, ks1 - 1);                 // past the end: a repeated, unused fragment
+            wq[u] = *(const uint4*)(w0 + ks * 32);
+            if constexpr (SW) uq[u] = *(const uint4*)(w1 + ks * 32);
+            xq[u] = *(const uint4*)(xr + ks * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < ks1) {
+                a0 = mfma16(wq[u], xq[u], a0);
+                if constexpr (SW) a1 = mfma16(uq[u], xq[u], a1);
+            }
+        }
+    }
+    part[0][wave][lane] = a0;
+    if constexpr (SW) part[1][wave][lane] = a1;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+        a0 += part[0][w][lane];
+        if constexpr (SW) a1 += part[1][w][lane];
+    }
+    // a0[r] = (x_m . w_o) for m = fr, o = o0 + 4 fg + r
+    const int m = fr;
+    if (m >= M) return;
+    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+    float t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + fg * 4 + r;
+        float v;
+        if constexpr (SW) {
+            v = rnd(rnd(act_silu(rnd(a0[r]))) * rnd(a1[r]));
+        } else {
+            v = a0[r];
+            if (o < n_out) {
+                if ((flags & EPI_BIAS) && (flags & EPI_BIAS_ROUNDED)) v = rnd(v);
+                if (flags & EPI_BIAS) v += e2f(bias[o]);
+                if (!(flags & EPI_OUT_F32) || act || (flags & EPI_RESID)) v = rnd(v);
+                if (act == 1) v = act_quick_gelu_e(v);
+                else if (act == 2) v = rnd(act_gelu_erf(v));
+                else if (act == 3) v = fmaxf(v, 0.f);
+            }
+        }
+        if ((flags & EPI_RESID) && o < n_out) v = rnd(e2f(R[(long)m * ldr + o]) + v);
+        t[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + fg * 4 + r;
+        if (o < n_out) {
+            if (flags & EPI_OUT_F32) ((float*)C)[(long)m * ldc + o] = t[r];
+            else ((elem_t*)C)[(long)m * ldc + o] = f2e(t[r]);
+        }
+    }
+}
+
+int launch_skinny(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr,
+                  int64_t M, int64_t N, int64_t K, int flags, void* stream) {
+    if (!X || !W || !C || M <= 0 || N <= 0 || K <= 0) return ULL_ERR_ARG;
+    if (M > 16 || (K & 31) || (ldx & 7) || (ldw & 7)) return ULL_ERR_SHAPE;
+    if ((flags & EPI_BIAS) && !bias) return ULL_ERR_ARG;
+    if ((flags & EPI_RESID) && !R) return ULL_ERR_ARG;
+    if ((flags & EPI_SWIGLU) && ((N & 31) || (flags & (EPI_BIAS | EPI_ACT_MASK)))) return ULL_ERR_SHAPE;
+    const int n_out = (int)((flags & EPI_SWIGLU) ? N / 2 : N);
+    const unsigned blocks = (unsigned)((n_out + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & EPI_SWIGLU)
+        hipLaunchKernelGGL(skinny_gemm_kernel<true>, dim3(blocks), dim3(512), 0, st, (const elem_t*)X, ldx, (const elem_t*)W, ldw, C, ldc,
+                           (const elem_t*)bias, (const elem_t*)R, ldr, (int)M, (int)N, (int)K, flags, n_out);
+    else
+        hipLaunchKernelGGL(skinny_gemm_kernel<false>, dim3(blocks), dim3(512), 0, st, (const elem_t*)X, ldx, (const elem_t*)W, ldw, C, ldc,
+                           (const elem_t*)bias, (const elem_t*)R, ldr, (int)M, (int)N, (int)K, flags, n_out);
+    return ull_check_launch();
+}
+
 int launch_gemv(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr,
                 int64_t M, int64_t N, int64_t K, int flags, const void* norm_w, float eps, void* stream) {
     if (!X || !W || !C || M <= 0 || N <= 0 || K <= 0) return ULL_ERR_ARG;
@@ -185,4 +288,10 @@ extern "C" int ULL_FN(ull_gemv_rmsnorm_)(const void* X, int64_t ldx, const void*
                                      void* stream) {
     if (!norm_w) return ULL_ERR_ARG;
     return launch_gemv(X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, norm_w, eps, stream);
+}
+
+// The same contract for 2 <= M <= 16 on the matrix cores (batched decode steps); K % 32 == 0.
+extern "C" int ULL_FN(ull_gemm_skinny_)(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
+                                    int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream) {
+    return launch_skinny(X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, stream);
 }

@@ -153,10 +153,28 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     lead = tuple(x.shape[:-1])
     if x.shape[-1] != K:
         raise RuntimeError(f"u-llava_amd.linear: K mismatch {x.shape[-1]} vs {K}")
-    if rms_w is not None and not (M <= 4 and K % 8 == 0 and M * K <= 16384):
+    # batched decode steps against LLaMA-sized weights: the weight stream on the matrix cores (the GEMV is FMA-bound from M = 4 on,
+    # the tiled GEMM's grid is a few dozen blocks at these M).  Small weights stay where they were.
+    skinny = 2 <= M <= 16 and K % 32 == 0 and N * K >= (1 << 22) and w.stride(0) % 8 == 0 and w.stride(1) == 1 and tune == 0
+    if rms_w is not None and (skinny or not (M <= 4 and K % 8 == 0 and M * K <= 16384)):
         x = rmsnorm(x, rms_w, rms_eps)
         rms_w = None
         M, ldx = _rows(x)
+    if skinny:
+        n_out = N // 2 if swiglu else N
+        if out is None:
+            out = torch.empty(*lead, n_out, device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+        flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | \
+            (EPI_SWIGLU if swiglu else 0) | (EPI_F32 if out_f32 else 0) | (EPI_BIAS_ROUNDED if bias_after_rounding else 0)
+        if bias is not None:
+            _chk(bias, "bias", x.dtype)
+        ldr = 0
+        if residual is not None:
+            _chk(residual, "residual", x.dtype)
+            ldr = _rows(residual)[1]
+        _lib.call("ull_gemm_skinny_" + _SFX[x.dtype], _p(x), ldx, _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias), _p(residual), ldr, M, N, K,
+                  flags, _stream())
+        return out
     if M <= 4 and K % 8 == 0:
         # decode shape: weight-streaming GEMV (no padding, no MFMA)
         n_out = N // 2 if swiglu else N
