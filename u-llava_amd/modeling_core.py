@@ -659,8 +659,12 @@ class UllavaCoreForCausalLM(nn.Module):
         steps_hidden = []
         cache = None
         self._cache_headroom = max_new_tokens + 1
+        # No padding anywhere (no mask given, or a mask of ones -- one host read, here): the steps run without a key mask.  The results
+        # are the same (position_ids = cumsum(ones) - 1 = arange; every key attended) and the attention kernels skip their per-key
+        # mask loads, which sit on the latency chain of every decode step.
+        no_pad = attention_mask is None or bool(attention_mask.ne(0).all())
         for step in range(max_new_tokens):
-            mask = torch.ones_like(seq) if attention_mask is None else torch.cat(
+            mask = None if no_pad else torch.cat(
                 [attention_mask, attention_mask.new_ones(B, seq.shape[1] - attention_mask.shape[1])], dim=1)
             inputs = self.prepare_inputs_for_generation(input_ids=seq, attention_mask=mask, images=images, videos=videos,
                                                         past_key_values=cache if use_cache else None, use_cache=use_cache)
