@@ -248,3 +248,41 @@ print("OK")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
+
+
+def test_lora_adapter_is_merged_at_load(tmp_path):
+    """inference_ullava.py:41-43 loads a LoRA checkpoint with PeftModel.from_pretrained(model.llm, path); here the adapter PEFT wrote
+    (adapter_config.json + adapter_model.safetensors, `base_model.model.<module>.lora_A|B.weight`) is merged into the targets at
+    load: W + (alpha / r) * B @ A, everything else untouched."""
+    import json
+    from safetensors.torch import save_file
+    CK, M = pkg("checkpoint"), pkg("modeling_core")
+    base = _tiny_core()
+    d = str(tmp_path / "ckpt")
+    base.save_pretrained(d)
+    r, alpha = 4, 8.0
+    g = torch.Generator().manual_seed(3)
+    sd, want = {}, {}
+    for li in range(base.config.num_hidden_layers):
+        for name in ("q_proj", "v_proj"):
+            mod = f"model.layers.{li}.self_attn.{name}"
+            w = dict(base.named_modules())[mod].weight
+            A, B = torch.randn(r, w.shape[1], generator=g) * 0.1, torch.randn(w.shape[0], r, generator=g) * 0.1
+            sd[f"base_model.model.{mod}.lora_A.weight"] = A.to(w.dtype)
+            sd[f"base_model.model.{mod}.lora_B.weight"] = B.to(w.dtype)
+            want[mod] = (w.detach().float() + (B.to(w.dtype).float() @ A.to(w.dtype).float()) * (alpha / r)).to(w.dtype)
+    assert not CK.has_lora_adapter(d)
+    save_file(sd, os.path.join(d, "adapter_model.safetensors"))
+    json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "target_modules": ["q_proj", "v_proj"], "fan_in_fan_out": False},
+              open(os.path.join(d, "adapter_config.json"), "w"))
+    assert CK.has_lora_adapter(d)
+    m = M.UllavaCoreForCausalLM.from_pretrained(d, torch_dtype=base.model.embed_tokens.weight.dtype)
+    mods = dict(m.named_modules())
+    for mod, w in want.items():
+        assert torch.equal(mods[mod].weight.detach().cpu(), w), mod
+    k0 = "model.layers.0.self_attn.k_proj"
+    assert torch.equal(mods[k0].weight.detach().cpu(), dict(base.named_modules())[k0].weight.detach().cpu())
+    # a rank that does not match the config is refused
+    json.dump({"peft_type": "LORA", "r": r + 1, "lora_alpha": alpha}, open(os.path.join(d, "adapter_config.json"), "w"))
+    with pytest.raises(RuntimeError):
+        M.UllavaCoreForCausalLM.from_pretrained(d, torch_dtype=base.model.embed_tokens.weight.dtype)

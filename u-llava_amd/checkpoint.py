@@ -168,6 +168,8 @@ def core_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict: 
     raw = _merge_config(read_config(path), config_overrides)
     model = cls(UllavaCoreConfig(**raw), device=device, dtype=_dtype_arg(torch_dtype))
     load_into(model, path, strict=strict)
+    if has_lora_adapter(path):                               # inference_ullava_core.py with a LoRA checkpoint directory
+        merge_lora_adapter(model, path)
     model._packed = None
     return model
 
@@ -182,6 +184,67 @@ def ullava_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict
     hard_missing = [k for k in missing if not k.startswith("visual_model.image_encoder.")]
     if strict and (hard_missing or unexpected):
         raise RuntimeError(f"u-llava_amd: checkpoint {path} does not match the model: missing {hard_missing[:8]}, unexpected {unexpected[:8]}")
+    if has_lora_adapter(path):                               # inference_ullava.py:41-43 (PeftModel.from_pretrained(model.llm, llm_path))
+        merge_lora_adapter(model.llm, path)
     model.llm._packed = None
     model._sam.invalidate()
     return model
+
+
+# -- LoRA adapters (inference_ullava.py:41-43: `PeftModel.from_pretrained(model.llm, path)` when --lora_r > 0) ---------------------------
+# PEFT wraps nn.Linear.forward; this implementation reads the weights into fused GEMM operands and never calls that forward, so an
+# adapter is MERGED into the base weights at load time instead: W += (lora_alpha / r) * B @ A for every target module -- what
+# `PeftModel.merge_and_unload()` leaves behind.  Reads the files PEFT writes (adapter_config.json + adapter_model.safetensors / .bin,
+# keys `base_model.model.<module path>.lora_A[.<adapter>].weight` [r, in] and `.lora_B[...].weight` [out, r]).  Host-side weight
+# preparation like the rest of this file; the product of the two small matrices is taken in fp32.
+def has_lora_adapter(path: str) -> bool:
+    return os.path.isfile(os.path.join(path, "adapter_config.json")) and any(
+        os.path.isfile(os.path.join(path, f)) for f in ("adapter_model.safetensors", "adapter_model.bin"))
+
+
+def merge_lora_adapter(llm: torch.nn.Module, path: str, adapter_name: str = "default") -> List[str]:
+    """Merge the LoRA adapter stored under `path` into `llm` (an UllavaCoreForCausalLM).  Returns the merged module paths."""
+    with open(os.path.join(path, "adapter_config.json")) as f:
+        cfg = json.load(f)
+    if cfg.get("peft_type", "LORA") != "LORA":
+        raise RuntimeError(f"u-llava_amd: adapter type {cfg.get('peft_type')} is not LoRA")
+    r, alpha = int(cfg["r"]), float(cfg.get("lora_alpha", cfg["r"]))
+    fan_in_fan_out = bool(cfg.get("fan_in_fan_out", False))
+    fn = os.path.join(path, "adapter_model.safetensors")
+    sd = _load_file(fn) if os.path.isfile(fn) else _load_file(os.path.join(path, "adapter_model.bin"))
+    pairs: Dict[str, Dict[str, torch.Tensor]] = {}
+    for k, v in sd.items():
+        for tag in ("lora_A", "lora_B"):
+            marker = f".{tag}."
+            if marker in k and k.endswith(".weight"):
+                mod = k[:k.index(marker)]
+                for pre in ("base_model.model.", "base_model."):
+                    if mod.startswith(pre):
+                        mod = mod[len(pre):]
+                        break
+                pairs.setdefault(mod, {})[tag] = v
+    if not pairs:
+        raise RuntimeError(f"u-llava_amd: no lora_A / lora_B tensors in {path}")
+    modules = dict(llm.named_modules())
+    merged = []
+    with torch.no_grad():
+        for mod, ab in sorted(pairs.items()):
+            if "lora_A" not in ab or "lora_B" not in ab:
+                raise RuntimeError(f"u-llava_amd: adapter for {mod} lacks lora_A or lora_B")
+            target = modules.get(mod)
+            if target is None or not hasattr(target, "weight"):
+                raise RuntimeError(f"u-llava_amd: adapter target {mod} is not a module of the model")
+            A, B = ab["lora_A"].float(), ab["lora_B"].float()
+            if A.shape[0] != r or B.shape[1] != r:
+                raise RuntimeError(f"u-llava_amd: adapter rank mismatch on {mod}: A {tuple(A.shape)}, B {tuple(B.shape)}, r = {r}")
+            delta = (B @ A) * (alpha / r)
+            if fan_in_fan_out:
+                delta = delta.t()
+            w = target.weight
+            if tuple(delta.shape) != tuple(w.shape):
+                raise RuntimeError(f"u-llava_amd: adapter delta {tuple(delta.shape)} does not fit {mod}.weight {tuple(w.shape)}")
+            w.copy_((w.detach().float().cpu() + delta).to(w.dtype).to(w.device))
+            merged.append(mod)
+    if hasattr(llm, "_packed"):
+        llm._packed = None                                   # fused q|k|v / tile-major copies describe the old weights
+    return merged
