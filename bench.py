@@ -294,9 +294,16 @@ def workload_step(name, dev, rank, batch_override=None):
         labels = ids.clone()
         labels[:, :P + 3] = -100
         trainable = []
+        lora_r = int(os.environ.get("ULL_BENCH_LORA_R", "0"))       # > 0: configs/train/ullava_lora.yaml (r = 8 adapters on q_proj, v_proj)
+        if lora_r > 0:
+            model.add_lora(lora_r, 16.0, 0.05, ("q_proj", "v_proj"))
+            model.train()
         for n, p_ in model.named_parameters():
-            p_.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or n.startswith("vision_projector") or
-                                (n.startswith("model.") and (".q_proj." in n or ".v_proj." in n)))
+            if lora_r > 0:
+                p_.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or n.startswith("vision_projector") or ".lora_" in n)
+            else:
+                p_.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or n.startswith("vision_projector") or
+                                    (n.startswith("model.") and (".q_proj." in n or ".v_proj." in n)))
             if p_.requires_grad:
                 trainable.append(p_)
         flops_img *= 3                                           # forward + ~2x backward (dW only for the trainable set: an upper bound)

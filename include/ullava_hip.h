@@ -168,6 +168,10 @@ int ull_video_pool_bf16(const void* f, void* out, int64_t B, int64_t T, int64_t 
 /* dst[i,:] = src[idx[i],:]  (models/ullava.py:190-199: boolean-mask gather of [SEG]/[LOC] rows, done BEFORE the projector). */
 int ull_gather_rows_bf16(const void* src, int64_t lds, const void* idx, void* dst, int64_t ldd, int64_t n, int64_t D, void* stream);
 
+/* nn.Dropout in training mode (PEFT lora_dropout, train_ullava.py:222): y = keep[i] ? round(x[i] / (1 - p)) : 0, scale = 1 / (1 - p), keep = one
+ * byte per element from the caller's RNG.  Its own backward (apply to dy with the same mask). */
+int ull_dropout_apply_bf16(const void* x, const void* keep, void* y, int64_t n, float scale, void* stream);
+
 /* out = bf16(a + b[row % b_rows])  (bf16 tensor adds: queries + query_pe, keys + key_pe, x + pos_embed). */
 int ull_add_rows_bf16(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream);
 
@@ -396,6 +400,7 @@ int ull_im2col_f16(const void* img, void* out, int64_t n_img, int64_t C, int64_t
 int ull_embed_splice_f16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
 int ull_video_pool_f16(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch, int64_t tok_off, void* stream);
 int ull_gather_rows_f16(const void* src, int64_t lds, const void* idx, void* dst, int64_t ldd, int64_t n, int64_t D, void* stream);
+int ull_dropout_apply_f16(const void* x, const void* keep, void* y, int64_t n, float scale, void* stream);
 int ull_add_rows_f16(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream);
 int ull_window_partition_f16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
 int ull_window_unpartition_add_f16(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);

@@ -3,6 +3,7 @@ oracle's ops on the CPU, and the full training path of UllavaCoreForCausalLM aga
 tests/golden/gen_golden.py::gen_core_grads).  Tolerance: gradients are compared in relative L2 norm; for the model-level test the
 HIP bf16 gradients must be as close to the reference's fp32 gradients as the reference's own bf16 backward is (x3)."""
 import math
+import os
 
 import pytest
 import torch
@@ -353,3 +354,77 @@ def test_weight_caches_are_keyed_by_tensor_object_not_address():
         a_.add_(1)
     k1 = M_._frozen_pack("t", (a_, b_), lambda: torch.cat((a_, b_), dim=0))
     assert k1 is not k0 and torch.equal(k1, torch.cat((a_, b_), dim=0))
+
+
+def test_lora_adapters_on_the_training_path():
+    """train_ullava.py:219-237 (get_peft_model on q_proj, v_proj): add_lora freezes the language model and trains lora_A / lora_B; the
+    forward adds (alpha / r) * B(A(x)) to the projections.  Checked against the oracle's fp32 forward on W + (alpha / r) * B @ A with
+    autograd through A and B (the same function of A and B), against the merged weights on the inference kernels, and through a
+    save_pretrained / from_pretrained round trip in PEFT's file layout."""
+    import tempfile
+    from helpers import core_model_from_fixture
+    M_ = pkg("modeling_core")
+    fx = load_fixture("g12_core_grads_bf16.pt")
+    model, sd = core_model_from_fixture(fx, DEV)
+    ids, mask, images, labels = (fx[k].to(DEV) for k in ("input_ids", "attention_mask", "images", "labels"))
+    r, alpha = 4, 8.0
+    model.add_lora(r, alpha, 0.0, ("q_proj", "v_proj"))
+    g = torch.Generator().manual_seed(11)
+    for l in model.model.layers:                                  # B is zero after init: give it values so that both factors see gradients
+        for t in ("q_proj", "v_proj"):
+            lb = getattr(l.self_attn, t).lora_B.weight
+            lb.data.copy_((torch.randn(lb.shape, generator=g) * 0.05).to(lb.dtype))
+    trainable = sorted(n for n, p in model.named_parameters() if p.requires_grad)
+    assert trainable and all(".lora_A." in n or ".lora_B." in n or n.startswith("vision_projector") for n in trainable), trainable
+    model.train()
+    out = model(input_ids=ids, attention_mask=mask, images=images, labels=labels)
+    out.loss.backward()
+    # fp32 reference: the oracle on W_eff = W + s * B @ A, autograd through A and B
+    cfg = fx["cfg"]
+    sd32 = {k: v.float() for k, v in sd.items()}
+    leaves = {}
+    for li, l in enumerate(model.model.layers):
+        for t in ("q_proj", "v_proj"):
+            lin = getattr(l.self_attn, t)
+            a_ = lin.lora_A.weight.detach().float().cpu().requires_grad_(True)
+            b_ = lin.lora_B.weight.detach().float().cpu().requires_grad_(True)
+            leaves[f"model.layers.{li}.self_attn.{t}.lora_A.weight"] = a_
+            leaves[f"model.layers.{li}.self_attn.{t}.lora_B.weight"] = b_
+            key = f"model.layers.{li}.self_attn.{t}.weight"
+            sd32[key] = sd32[key] + (b_ @ a_) * (alpha / r)
+    ref = O.core_forward(sd32, cfg, fx["input_ids"], fx["attention_mask"], fx["images"].float(), labels=fx["labels"])
+    ref["loss"].backward()
+    assert abs(float(out.loss) - float(ref["loss"])) <= 0.02 * abs(float(ref["loss"])), (float(out.loss), float(ref["loss"]))
+    params = dict(model.named_parameters())
+    for n, leaf in leaves.items():
+        gd = params[n].grad
+        assert gd is not None, n
+        e = rel_l2(gd, leaf.grad)
+        cos = float(F.cosine_similarity(gd.float().cpu().flatten(), leaf.grad.flatten(), dim=0))
+        assert e <= 0.06 and cos >= 0.998, (n, e, cos)
+    for n, p in model.named_parameters():
+        if ".self_attn.q_proj.weight" in n or n == "lm_head.weight":
+            assert p.grad is None and not p.requires_grad, n
+    # PEFT-layout round trip: adapter files beside the base weights; loading merges them; the merged inference forward agrees
+    logits_graph = out.logits.detach().float().cpu()
+    with tempfile.TemporaryDirectory() as d:
+        model.save_pretrained(d)
+        assert os.path.isfile(os.path.join(d, "adapter_config.json")) and os.path.isfile(os.path.join(d, "adapter_model.safetensors"))
+        merged = M_.UllavaCoreForCausalLM.from_pretrained(d, torch_dtype=torch.bfloat16, device=DEV)
+    assert not any("lora_" in n for n, _ in merged.named_parameters())
+    with torch.no_grad():
+        lm = merged(input_ids=ids, attention_mask=mask, images=images).logits.float().cpu()
+    assert rel_l2(lm, logits_graph) < 0.03
+    model.merge_lora()
+    with torch.no_grad():
+        l2 = model(input_ids=ids, attention_mask=mask, images=images).logits.float().cpu()
+    assert torch.equal(l2, lm)                       # the same merged weights on the same kernels
+    # dropout: keeps ~(1 - p) of the elements, scaled by 1 / (1 - p), and its backward uses the same mask
+    A = pkg("autograd_ops")
+    x = torch.ones(64, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    torch.manual_seed(0)
+    y = A.dropout(x, 0.25)
+    kept = (y != 0)
+    assert 0.70 < float(kept.float().mean()) < 0.80 and torch.allclose(y[kept].float(), torch.full((), 1 / 0.75).to(torch.bfloat16).float())
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, kept)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ull_box_losses_bwd_f32": [_ptr, _i32, _ptr, _i64, _ptr, _ptr, _ptr],
     "ull_bilinear_bwd_f32": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_gemv_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
+    "ull_dropout_apply_bf16": [_ptr, _ptr, _ptr, _i64, _f32, _ptr],
     "ull_gemm_skinny_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_gemv_rmsnorm_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],

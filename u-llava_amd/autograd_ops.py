@@ -264,6 +264,31 @@ def gelu(x):
     return _Gelu.apply(x)
 
 
+class _Dropout(torch.autograd.Function):
+    """nn.Dropout(p) in training mode; the keep mask is drawn from torch's generator of the device (the reference's RNG), the scaling
+    and the zeroing run in the HIP kernel.  p == 0 never gets here."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        keep = (torch.rand(x.shape, device=x.device) >= p).to(torch.uint8)
+        ctx.save_for_backward(keep)
+        ctx.p = p
+        return ops.dropout_apply(x, keep, p)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (keep,) = ctx.saved_tensors
+        return ops.dropout_apply(dy.contiguous(), keep, ctx.p), None
+
+
+def dropout(x, p: float):
+    if p <= 0.0:
+        return x
+    if p >= 1.0:
+        raise ValueError("dropout probability must be < 1")
+    return _Dropout.apply(x, p)
+
+
 class _Add(torch.autograd.Function):
     """rnd(a + b[row % b_rows]) (ops.add_rows); gradients pass through (b's only when it is not broadcast)."""
 

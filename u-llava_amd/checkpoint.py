@@ -105,7 +105,21 @@ def save_pretrained(model: torch.nn.Module, path: str, max_shard_bytes: int = 5 
     cfg["torch_dtype"] = str(next(model.parameters()).dtype).replace("torch.", "")
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(cfg, f, indent=2, sort_keys=True)
-    sd = {_reference_key(k): v.detach().to("cpu").contiguous() for k, v in model.state_dict().items()}
+    full = model.state_dict()
+    sd = {_reference_key(k): v.detach().to("cpu").contiguous() for k, v in full.items() if ".lora_A." not in k and ".lora_B." not in k}
+    lora = {k: v.detach().to("cpu").contiguous() for k, v in full.items() if ".lora_A." in k or ".lora_B." in k}
+    if lora:
+        # train_ullava.py:287-289 with lora_r > 0: the base / head weights as above, the adapter beside them the way
+        # PeftModel.save_pretrained writes it (keys relative to the wrapped language model)
+        core = getattr(model, "llm", model)
+        lc = getattr(core, "_lora", None) or {}
+        from safetensors.torch import save_file as _save_adapter
+        _save_adapter({"base_model.model." + (k[4:] if k.startswith("llm.") else k): v for k, v in lora.items()},
+                      os.path.join(path, "adapter_model.safetensors"), metadata={"format": "pt"})
+        with open(os.path.join(path, "adapter_config.json"), "w") as f:
+            json.dump({"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": lc.get("r"), "lora_alpha": lc.get("lora_alpha"),
+                       "lora_dropout": lc.get("lora_dropout", 0.0), "target_modules": list(lc.get("target_modules", ())), "bias": "none",
+                       "fan_in_fan_out": False, "inference_mode": True}, f, indent=2, sort_keys=True)
     shards, cur, size = [], {}, 0
     for k in sorted(sd):
         n = sd[k].numel() * sd[k].element_size()

@@ -246,6 +246,22 @@ extern "C" int ULL_FN(ull_gather_rows_)(const void* src, int64_t lds_, const voi
     return ull_check_launch();
 }
 
+// nn.Dropout in training mode (PEFT's lora_dropout in front of lora_A, train_ullava.py:222): y = keep ? rnd(x * scale) : 0 with
+// scale = 1 / (1 - p); the keep mask (one byte per element) comes from the caller's RNG.  The backward is the same map on dy.
+namespace {
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const elem_t* __restrict__ x, const uint8_t* __restrict__ keep, elem_t* __restrict__ y,
+                                                            long n, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = keep[i] ? f2e(e2f(x[i]) * scale) : f2e(0.f);
+}
+}  // namespace
+extern "C" int ULL_FN(ull_dropout_apply_)(const void* x, const void* keep, void* y, int64_t n, float scale, void* stream) {
+    if (!x || !keep || !y || n <= 0) return ULL_ERR_ARG;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const elem_t*)x, (const uint8_t*)keep, (elem_t*)y,
+                       (long)n, scale);
+    return ull_check_launch();
+}
+
 extern "C" int ULL_FN(ull_add_rows_)(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream) {
     if (!a || !b || !out || rows <= 0 || b_rows <= 0) return ULL_ERR_ARG;
     if (D & 7) return ULL_ERR_SHAPE;

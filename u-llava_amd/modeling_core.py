@@ -403,11 +403,76 @@ class UllavaCoreForCausalLM(nn.Module):
             return ops.linear(x, vp.weight, vp.bias)
         return ops.linear(ops.linear(x, vp[0].weight, vp[0].bias, act="gelu"), vp[2].weight, vp[2].bias)
 
+    # -- LoRA (train_ullava.py:219-237: get_peft_model(model.llm, LoraConfig(r, lora_alpha, target_modules, lora_dropout))) ---------
+    def add_lora(self, r: int, lora_alpha: float = 16.0, lora_dropout: float = 0.0, target_modules=("q_proj", "v_proj")):
+        """Attach LoRA adapters to the attention projections named in `target_modules` (the reference's default: q_proj, v_proj) of every
+        LLaMA layer: `lora_A.weight` [r, in] (kaiming-uniform, PEFT's init), `lora_B.weight` [out, r] (zeros), the base weights and
+        every other language-model weight frozen, the adapters trainable -- what get_peft_model leaves.  The forward adds
+        (lora_alpha / r) * B(A(dropout(x))) to the projection as PEFT's Linear does; save_pretrained writes the adapter in PEFT's
+        file layout and from_pretrained merges such files (checkpoint.merge_lora_adapter)."""
+        import math
+        targets = tuple(target_modules)
+        if not targets or any(t not in ("q_proj", "k_proj", "v_proj") for t in targets):
+            raise NotImplementedError("LoRA targets on this path: q_proj, k_proj, v_proj (the reference's configuration: q_proj, v_proj)")
+        for p_ in self.model.parameters():
+            p_.requires_grad = False
+        for p_ in self.lm_head.parameters():
+            p_.requires_grad = False
+        for l in self.model.layers:
+            for t in targets:
+                lin = getattr(l.self_attn, t)
+                dev, dt = lin.weight.device, lin.weight.dtype
+                lin.lora_A, lin.lora_B = _Holder(), _Holder()
+                a = torch.empty(r, lin.in_features, dtype=torch.float32)
+                torch.nn.init.kaiming_uniform_(a, a=math.sqrt(5))
+                lin.lora_A.weight = nn.Parameter(a.to(dt).to(dev), requires_grad=True)
+                lin.lora_B.weight = nn.Parameter(torch.zeros(lin.out_features, r, dtype=dt, device=dev), requires_grad=True)
+        self._lora = {"r": int(r), "lora_alpha": float(lora_alpha), "lora_dropout": float(lora_dropout), "target_modules": targets}
+        self._packed = None
+        return self
+
+    def _lora_delta_operands(self, attn):
+        """(A_cat [n*r, D], B_cat [3D, n*r] already scaled by lora_alpha / r) for the fused q|k|v projection of one layer: B_cat is block
+        structured, so z = x A_cat^T followed by z B_cat^T adds each target's own B(A(x)) to its own third of the q|k|v row."""
+        cfg = self._lora
+        r, s_ = cfg["r"], cfg["lora_alpha"] / cfg["r"]
+        D = self.config.hidden_size
+        As, Bs = [], []
+        present = [t for t in ("q_proj", "k_proj", "v_proj") if hasattr(getattr(attn, t), "lora_A")]
+        for i, t in enumerate(present):
+            lin = getattr(attn, t)
+            As.append(lin.lora_A.weight)
+            blk = torch.zeros(3 * D, r, device=lin.weight.device, dtype=lin.weight.dtype)
+            off = ("q_proj", "k_proj", "v_proj").index(t) * D
+            blk = torch.cat([blk[:off], lin.lora_B.weight * s_, blk[off + D:]], dim=0)      # (weight preparation; s_ = 2 in the reference's config)
+            Bs.append(blk)
+        return torch.cat(As, dim=0), torch.cat(Bs, dim=1)
+
+    def merge_lora(self):
+        """Fold the adapters into the base weights (PeftModel.merge_and_unload) and drop them: the inference kernels read plain weights."""
+        cfg = getattr(self, "_lora", None)
+        if cfg is None:
+            return self
+        s_ = cfg["lora_alpha"] / cfg["r"]
+        with torch.no_grad():
+            for l in self.model.layers:
+                for t in cfg["target_modules"]:
+                    lin = getattr(l.self_attn, t)
+                    delta = (lin.lora_B.weight.float() @ lin.lora_A.weight.float()) * s_
+                    lin.weight.copy_((lin.weight.float() + delta).to(lin.weight.dtype))
+                    del lin.lora_A, lin.lora_B
+        self._lora = None
+        self._packed = None
+        _clear_transposes()
+        return self
+
     # -- training path ---------------------------------------------------------------------------------------
     def _training_graph(self) -> bool:
         """True when this call must build an autograd graph: gradients enabled and some parameter of the language model or the
         projector asks for one (the reference freezes / unfreezes by `requires_grad`, train_ullava.py:207-261).  The CLIP tower
         is frozen by both training scripts and always runs the inference kernels without a graph."""
+        if getattr(self, "_lora", None) is not None:
+            return True                      # un-merged adapters live in the graph path only (merge_lora() for the inference kernels)
         if not torch.is_grad_enabled():
             return False
         return any(p.requires_grad for p in self.lm_head.parameters()) or any(p.requires_grad for p in self.model.parameters()) or \
@@ -448,7 +513,14 @@ class UllavaCoreForCausalLM(nn.Module):
             qkv_w = (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
             w_qkv = _frozen_pack("qkv", qkv_w, lambda: torch.cat(qkv_w, dim=0))
             h = A.rmsnorm(x, l.input_layernorm.weight, cfg.rms_norm_eps)
-            qkv = A.rope(A.linear(h, w_qkv), pos, inv_freq, 2 * H, hd)
+            qkv_lin = A.linear(h, w_qkv)
+            if getattr(self, "_lora", None) is not None:
+                # PEFT's Linear.forward: result += lora_B(lora_A(dropout(x))) * scaling -- here as two skinny GEMMs for the whole q|k|v row,
+                # the base projection riding along as the second one's residual operand
+                a_cat, b_cat = self._lora_delta_operands(a)
+                hd_in = A.dropout(h, self._lora["lora_dropout"]) if (self.training and self._lora["lora_dropout"] > 0) else h
+                qkv_lin = A.linear(A.linear(hd_in, a_cat), b_cat, residual=qkv_lin)
+            qkv = A.rope(qkv_lin, pos, inv_freq, 2 * H, hd)
             att = A.self_attention(qkv, key_mask, B, S, H, hd, True)
             x = A.linear(att, a.o_proj.weight, residual=x)
             h = A.rmsnorm(x, l.post_attention_layernorm.weight, cfg.rms_norm_eps)

@@ -365,6 +365,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     return out
 
 
+def dropout_apply(x: torch.Tensor, keep: torch.Tensor, p: float) -> torch.Tensor:
+    """y = keep ? x / (1 - p) : 0 (keep: uint8, same number of elements)."""
+    _chk(x, "x"); _chk(keep, "keep", torch.uint8)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.call("ull_dropout_apply_" + _SFX[x.dtype], _p(x), _p(keep), _p(y), x.numel(), float(1.0 / (1.0 - p)), _stream())
+    return y
+
+
 def sam_window_attention(qkv: torch.Tensor, pad_row: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, B: int, H: int, W: int,
                          nH: int, hd: int, ws: int) -> torch.Tensor:
     """Block.forward's window_partition + Attention + window_unpartition (image_encoder.py:176-190) on image-order tokens:
