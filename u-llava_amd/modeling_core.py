@@ -446,6 +446,14 @@ class UllavaCoreForCausalLM(nn.Module):
             off = ("q_proj", "k_proj", "v_proj").index(t) * D
             blk = torch.cat([blk[:off], lin.lora_B.weight * s_, blk[off + D:]], dim=0)      # (weight preparation; s_ = 2 in the reference's config)
             Bs.append(blk)
+        # the GEMM kernels take K in 64-wide tiles: the rank axis is zero-padded here, once per operand pair, so that neither the forward
+        # nor the backward GEMMs pad their activations (zero rows of A_cat / zero columns of B_cat add exact zeros)
+        nr = len(present) * r
+        pad = (-nr) % 64
+        if pad:
+            w0 = As[0]
+            As.append(torch.zeros(pad, D, device=w0.device, dtype=w0.dtype))
+            Bs.append(torch.zeros(3 * D, pad, device=w0.device, dtype=w0.dtype))
         return torch.cat(As, dim=0), torch.cat(Bs, dim=1)
 
     def merge_lora(self):
