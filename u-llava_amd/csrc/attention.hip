@@ -1022,7 +1022,8 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     f32x4_t oacc[NDS];
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY;
+    f32x4_t lacc = {0.f, 0.f, 0.f, 0.f};     // sum of the (rounded) probabilities of this lane's query: P^T times a row of ones on the matrix pipe
     // one 64-key tile: scores (+ bias), running max, P, P*V
     auto tile = [&](int kt, float rh) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1060,7 +1061,8 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
         const float mn = fmaxf(m, tm);                         // finite from tile 0 on (key 0 is always in range)
         if (__builtin_amdgcn_ballot_w64(mn > m) != 0) {        // some query of this wave has a new maximum
             const float alpha = __expf(m - mn);                // exp(-inf) = 0 on the first tile
-            l *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lacc[r] *= alpha;
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds)
 #pragma unroll
@@ -1072,9 +1074,16 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
         for (int i = 0; i < 8; ++i) {
             const float e0 = __expf(sv[2 * i] - m), e1 = __expf(sv[2 * i + 1] - m);
             pk[i] = pack2e(e0, e1);
-            // the sum runs over the ROUNDED probabilities, so that O / l is a true weighted mean of V rows
-            l += pk_lo(pk[i]) + pk_hi(pk[i]);
         }
+        // The row sum runs over the ROUNDED probabilities, so that O / l is a true weighted mean of V rows: one more "V^T row" of ones
+        // through the MFMA (2 per tile) instead of unpacking and adding every probability again on the VALU, which is the bound here.
+#ifdef ULL_ELEM_F16
+        const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+#else
+        const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#endif
+        lacc = mfma16(ones, make_uint4(pk[0], pk[1], pk[2], pk[3]), lacc);
+        lacc = mfma16(ones, make_uint4(pk[4], pk[5], pk[6], pk[7]), lacc);
         if constexpr (VROW) {
             static_assert(FL == FL_SAM_ENC, "hd = 80: five head-dim blocks");
             const int swr = 4 * (fg & 1) + (fr >> 2);
@@ -1139,9 +1148,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
     } else {
         for (int kt = 0; kt < nkt; ++kt) tile(kt, 0.f);
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / lacc[0];             // every accumulator row holds the same sum over all keys for query fr
     if (qi < p.Sq) {
         elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
