@@ -104,6 +104,10 @@ def test_skinny_gemm_batched_decode_shapes(M, dt):
     y = ops.linear(xd, M_.interleave_gate_up(wg, wu).to(DEV), swiglu=True)
     gate, up = (x.double() @ wg.double().t()).to(dt), (x.double() @ wu.double().t()).to(dt)
     close(y, (F.silu(gate.float()).to(dt).float() * up.float()).to(dt), "swiglu")
+    # the down projection's K = 11008 (344 k-steps: an uneven eighth per wave)
+    K2, N2 = 11008, 400
+    x2, w2, r2 = rnd_t(M, K2), rnd_t(N2, K2, scale=K2 ** -0.5), rnd_t(M, N2)
+    close(ops.linear(x2.to(DEV), w2.to(DEV), residual=r2.to(DEV)), (r2.double() + (x2.double() @ w2.double().t()).to(dt).double()).to(dt), "K = 11008 + residual")
     nw = rnd_t(K) * 0.1 + 1.0
     xn = O.rms_norm(x, nw, 1e-6) if dt == torch.bfloat16 else None
     if xn is not None:
