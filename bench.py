@@ -172,54 +172,90 @@ def gemm_roofline(cfg, tokens, device, iters=40, warm=10):
                 traffic=traffic, traffic_detail=detail, per_launch=per)
 
 
-def cpu_baseline(image_size, prompt_tokens):
-    """Oracle (CPU restatement of the reference path, torch bf16) on a bounded sample: ONE image at the benchmark shape through
-    1 of 23 CLIP layers and 1 of 32 LLaMA layers + lm_head, each timed as 1 warm-up + 3 runs (median), extrapolated linearly in
-    layer count (core count stated)."""
-    from oracle import ullava_oracle as O
-    W = importlib.import_module("u-llava_amd.weights")
-    # pick the thread count on a probe matmul: 256-thread hosts are often slower with every hardware thread in use
+def _cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def _pick_threads():
+    """thread count on a probe matmul (256-thread hosts are often slower with every hardware thread in use); returns (n, table)."""
     probe_x, probe_w = torch.randn(643, 4096).to(torch.bfloat16), torch.randn(4096, 4096).to(torch.bfloat16)
-    best_n, best_t = 1, float("inf")
+    best_n, best_t, table = 1, float("inf"), {}
     for n in sorted({min(os.cpu_count(), c) for c in (8, 32, 64, 128, os.cpu_count())}):
         torch.set_num_threads(n)
         torch.nn.functional.linear(probe_x, probe_w)
         t0 = time.perf_counter()
         torch.nn.functional.linear(probe_x, probe_w)
         dt = time.perf_counter() - t0
+        table[n] = round(dt * 1e3, 2)
         if dt < best_t:
             best_n, best_t = n, dt
     torch.set_num_threads(best_n)
-    P = (image_size // 14) ** 2
-    S = 2 + P + 1 + prompt_tokens
-    D, I, V, Dv, Iv = 4096, 11008, 32011, 1024, 4096
-    nl, nv = 1, 1
-    shapes = {"model.embed_tokens.weight": (V, D), "model.norm.weight": (D,), "lm_head.weight": (V, D),
-              "vision_projector.weight": (D, Dv), "vision_projector.bias": (D,)}
-    for l in range(nl):
+    return best_n, table
+
+
+def _c1_state_dict(device, n_llama=32, n_clip=24, P=256, V=32011):
+    """Random-init weights of ViT-L/14-224 + LLaMA-7B in the reference's state-dict layout, generated on the GPU (seconds, instead of
+    minutes of host RNG: BASELINE.md section 3 "do not use HF random init") and copied to host memory as bf16 (13.9 GB)."""
+    D, I, Dv, Iv = 4096, 11008, 1024, 4096
+    g = torch.Generator(device=device).manual_seed(11)
+    sd = {}
+
+    def mat(name, *shape):
+        sd[name] = (torch.randn(*shape, device=device, generator=g) * 0.02).to(torch.bfloat16).cpu()
+
+    def one(name, n):
+        sd[name] = torch.ones(n, dtype=torch.bfloat16)
+
+    def zero(name, n):
+        sd[name] = torch.zeros(n, dtype=torch.bfloat16)
+    mat("model.embed_tokens.weight", V, D); mat("lm_head.weight", V, D); one("model.norm.weight", D)
+    mat("vision_projector.weight", D, Dv); zero("vision_projector.bias", D)
+    for l in range(n_llama):
         p = f"model.layers.{l}."
         for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            shapes[p + f"self_attn.{n}.weight"] = (D, D)
-        shapes[p + "mlp.gate_proj.weight"] = (I, D)
-        shapes[p + "mlp.up_proj.weight"] = (I, D)
-        shapes[p + "mlp.down_proj.weight"] = (D, I)
-        shapes[p + "input_layernorm.weight"] = (D,)
-        shapes[p + "post_attention_layernorm.weight"] = (D,)
+            mat(p + f"self_attn.{n}.weight", D, D)
+        mat(p + "mlp.gate_proj.weight", I, D); mat(p + "mlp.up_proj.weight", I, D); mat(p + "mlp.down_proj.weight", D, I)
+        one(p + "input_layernorm.weight", D); one(p + "post_attention_layernorm.weight", D)
     ve = "vision_encoder."
-    shapes.update({ve + "embeddings.class_embedding": (Dv,), ve + "embeddings.patch_embedding.weight": (Dv, 3, 14, 14),
-                   ve + "embeddings.position_embedding.weight": (P + 1, Dv), ve + "pre_layrnorm.weight": (Dv,), ve + "pre_layrnorm.bias": (Dv,)})
-    for l in range(nv):
+    mat(ve + "embeddings.class_embedding", Dv); mat(ve + "embeddings.patch_embedding.weight", Dv, 3, 14, 14)
+    mat(ve + "embeddings.position_embedding.weight", P + 1, Dv); one(ve + "pre_layrnorm.weight", Dv); zero(ve + "pre_layrnorm.bias", Dv)
+    for l in range(n_clip):
         p = f"{ve}encoder.layers.{l}."
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
-            shapes[p + f"self_attn.{n}.weight"] = (Dv, Dv)
-            shapes[p + f"self_attn.{n}.bias"] = (Dv,)
-        shapes.update({p + "layer_norm1.weight": (Dv,), p + "layer_norm1.bias": (Dv,), p + "layer_norm2.weight": (Dv,), p + "layer_norm2.bias": (Dv,),
-                       p + "mlp.fc1.weight": (Iv, Dv), p + "mlp.fc1.bias": (Iv,), p + "mlp.fc2.weight": (Dv, Iv), p + "mlp.fc2.bias": (Dv,)})
-    sd = W.seeded_state_dict(shapes, 0, torch.bfloat16, hf_init=True)
-    vcfg = dict(hidden_size=Dv, num_attention_heads=16, num_hidden_layers=nv, patch_size=14, layer_norm_eps=1e-5)
-    lcfg = dict(hidden_size=D, num_attention_heads=32, num_hidden_layers=nl, rms_norm_eps=1e-6)
-    img = torch.randn(1, 3, image_size, image_size).to(torch.bfloat16)
-    emb = torch.randn(1, S, D).to(torch.bfloat16)
+            mat(p + f"self_attn.{n}.weight", Dv, Dv); zero(p + f"self_attn.{n}.bias", Dv)
+        for n in ("layer_norm1", "layer_norm2"):
+            one(p + n + ".weight", Dv); zero(p + n + ".bias", Dv)
+        mat(p + "mlp.fc1.weight", Iv, Dv); zero(p + "mlp.fc1.bias", Iv); mat(p + "mlp.fc2.weight", Dv, Iv); zero(p + "mlp.fc2.bias", Dv)
+    return sd
+
+
+def cpu_baseline(device, c4_image=336, c4_prompt=64):
+    """the oracle (torch-CPU bf16 restatement of the reference path) on ONE whole C1 forward -- 224x224 image +
+    32-token prompt, S = 291, random-init ViT-L/14 (23 of 24 layers feed the projector) + all 32 LLaMA-7B layers + lm_head -- 1 warm-up +
+    3 timed forwards, median; thread count and CPU model stated.  Secondary record: the same oracle at the C4 shape (the GPU headline's
+    shape) from ONE and TWO CLIP / LLaMA layers, extrapolated linearly in layer count, with the 1- vs 2-layer check of that linearity."""
+    from oracle import ullava_oracle as O
+    best_n, probe = _pick_threads()
+    t_build = time.perf_counter()
+    sd = _c1_state_dict(device)
+    t_build = time.perf_counter() - t_build
+    V, D = sd["lm_head.weight"].shape
+    vcfg = dict(hidden_size=1024, num_attention_heads=16, num_hidden_layers=24, intermediate_size=4096, image_size=224, patch_size=14,
+                num_channels=3, layer_norm_eps=1e-5)
+    cfg = dict(hidden_size=D, num_hidden_layers=32, num_attention_heads=32, intermediate_size=11008, vocab_size=V, rms_norm_eps=1e-6,
+               rope_theta=10000.0, vision_hidden_layer=-2, projector_type="mlp", mm_token_ids=dict(MM), vision_config=vcfg)
+    g = torch.Generator().manual_seed(5)
+    P = 256
+    ids = torch.tensor([[1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * P + [MM["IMG_END"]] + torch.randint(5, 32000, (32,), generator=g).tolist()])
+    mask = torch.ones_like(ids)
+    img = torch.randn(1, 3, 224, 224, generator=g).to(torch.bfloat16)
 
     def t(fn, n=3):
         fn()                                           # 1 warm-up
@@ -230,18 +266,136 @@ def cpu_baseline(image_size, prompt_tokens):
             ts.append(time.perf_counter() - t0)
         return statistics.median(ts)
     with torch.no_grad():
-        t_clip = t(lambda: O.clip_vision_hidden_states(sd, vcfg, img, n_layers_to_run=nv))
-        t_clip0 = t(lambda: O.clip_vision_hidden_states(sd, vcfg, img, n_layers_to_run=0))
-        t_llm = t(lambda: O.llama_model(sd, lcfg, emb))
-        lcfg0 = dict(lcfg, num_hidden_layers=0)
-        t_llm0 = t(lambda: O.llama_model(sd, lcfg0, emb))
-        hs = O.llama_model(sd, lcfg0, emb)[0][-1]
-        t_head = t(lambda: torch.nn.functional.linear(hs, sd["lm_head.weight"]))
-    per_img = t_clip0 + max(t_clip - t_clip0, 0.0) / nv * 23 + t_llm0 + max(t_llm - t_llm0, 0.0) / nl * 32 + t_head
-    return dict(value=round(1.0 / per_img, 4), unit="images/sec", cores=best_n, kind="port",
-                sample=f"oracle (torch-CPU bf16 restatement of the reference path), 1 image {image_size}x{image_size} S={S}: "
-                       f"{nv}/23 CLIP layers + {nl}/32 LLaMA-7B layers + lm_head, each 1 warm-up + 3 timed (median), extrapolated "
-                       f"linearly in layer count ({per_img:.2f} s/image; {best_n} of {os.cpu_count()} host threads, fastest on a probe matmul)")
+        out = O.core_forward(sd, cfg, ids, mask, img)
+        finite = bool(torch.isfinite(out["logits"].float()).all())
+        del out
+        t_c1 = t(lambda: O.core_forward(sd, cfg, ids, mask, img))
+        # secondary: C4 shape from 1 and 2 layers (the 336-px position table is a fresh random one: timing only)
+        P4 = (c4_image // 14) ** 2
+        S4 = 2 + P4 + 1 + c4_prompt
+        sd4 = dict(sd)
+        sd4["vision_encoder.embeddings.position_embedding.weight"] = (torch.randn(P4 + 1, 1024, generator=g) * 0.02).to(torch.bfloat16)
+        img4 = torch.randn(1, 3, c4_image, c4_image, generator=g).to(torch.bfloat16)
+        emb4 = torch.randn(1, S4, D, generator=g).to(torch.bfloat16)
+        v4 = dict(vcfg, image_size=c4_image)
+        tc = [t(lambda n=n: O.clip_vision_hidden_states(sd4, v4, img4, n_layers_to_run=n)) for n in (0, 1, 2)]
+        tl = [t(lambda n=n: O.llama_model(sd4, dict(cfg, num_hidden_layers=n), emb4)) for n in (0, 1, 2)]
+        hs = O.llama_model(sd4, dict(cfg, num_hidden_layers=0), emb4)[0][-1]
+        t_head = t(lambda: torch.nn.functional.linear(hs, sd4["lm_head.weight"]))
+    per_clip, per_llm = max(tc[2] - tc[0], 0.0) / 2, max(tl[2] - tl[0], 0.0) / 2
+    c4_s = tc[0] + per_clip * 23 + tl[0] + per_llm * 32 + t_head
+    lin = dict(clip_layer_s_1=round(tc[1] - tc[0], 4), clip_layer_s_2nd=round(tc[2] - tc[1], 4),
+               llama_layer_s_1=round(tl[1] - tl[0], 4), llama_layer_s_2nd=round(tl[2] - tl[1], 4))
+    return dict(value=round(1.0 / t_c1, 4), unit="images/sec", cores=best_n, kind="port", cpu_model=_cpu_model_name(),
+                host_threads=os.cpu_count(), seconds_per_image=round(t_c1, 3), logits_finite=finite,
+                sample=f"oracle (torch-CPU bf16 restatement of the reference path), WHOLE C1 forward: 1 image 224x224 + 32-token prompt, S=291, "
+                       f"ViT-L/14 (23 layers used) + projector + 32 LLaMA-7B layers + lm_head (V={V}), random-init weights, 1 warm-up + 3 timed "
+                       f"forwards, median {t_c1:.2f} s; {best_n} of {os.cpu_count()} host threads (fastest on a probe matmul: {probe} ms); "
+                       f"weights generated on `{device.type}` and held in host memory, {t_build:.0f} s (not timed)",
+                c4_shape_extrapolated=dict(value=round(1.0 / c4_s, 4), unit="images/sec", seconds_per_image=round(c4_s, 3),
+                                           sample=f"same oracle, C4 shape ({c4_image}x{c4_image}, S={S4}): (2-layer - 0-layer)/2 per CLIP / LLaMA "
+                                                  "layer x 23 / 32 + embeddings + lm_head", linearity_check=lin))
+
+
+def _parse_cpulist(txt):
+    out = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def numa_topology():
+    """{node: [cpus]} from sysfs, or None."""
+    base = "/sys/devices/system/node"
+    try:
+        nodes = sorted(int(d[4:]) for d in os.listdir(base) if d.startswith("node") and d[4:].isdigit())
+        topo = {n: _parse_cpulist(open(f"{base}/node{n}/cpulist").read()) for n in nodes}
+        return {n: c for n, c in topo.items() if c} or None
+    except OSError:
+        return None
+
+
+def gpu_numa_node(index):
+    """NUMA node of GPU `index` (its PCI function's sysfs entry), or None."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        n = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        return n if n >= 0 else None
+    except Exception:
+        return None
+
+
+def rank_cpu_set(rank, world, allowed, numa, gpu_nodes=None):
+    """CPUs for local rank `rank` of `world`: disjoint, contiguous shares of the allowed set.  With a NUMA map, a rank stays inside one
+    node: the node of its GPU when `gpu_nodes` (node per local rank) is known -- ranks whose GPUs hang off the same node split that node's
+    CPUs -- else nodes dealt out in order when the rank count is a multiple of the node count.  Fewer CPUs than ranks: no pinning."""
+    allowed = sorted(allowed)
+    if world <= 1 or len(allowed) < world:
+        return allowed
+    aset = set(allowed)
+    if numa:
+        nodes = {n: [c for c in cpus if c in aset] for n, cpus in sorted(numa.items())}
+        nodes = {n: c for n, c in nodes.items() if c}
+        if gpu_nodes and all(g in nodes for g in gpu_nodes):
+            peers = [r for r in range(world) if gpu_nodes[r] == gpu_nodes[rank]]
+            cpus, k, j = nodes[gpu_nodes[rank]], len(peers), peers.index(rank)
+            if len(cpus) >= k:
+                return cpus[j * len(cpus) // k:(j + 1) * len(cpus) // k]
+        elif nodes and world % len(nodes) == 0:
+            per = world // len(nodes)
+            cpus = nodes[sorted(nodes)[rank // per]]
+            j = rank % per
+            if len(cpus) >= per:
+                return cpus[j * len(cpus) // per:(j + 1) * len(cpus) // per]
+    return allowed[rank * len(allowed) // world:(rank + 1) * len(allowed) // world]
+
+
+def pin_rank_to_cpus(local, world, use_gpu_topology):
+    """One process per GPU, each on its own CPUs (with 8 Python launch threads on one host, migration and shared caches
+    are what separates 8 GPUs from 8x one GPU).  Returns a small record for the JSON line, or None when nothing was pinned."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        numa = numa_topology()
+        gpu_nodes = None
+        if use_gpu_topology and torch.cuda.is_available() and torch.cuda.device_count() >= world:
+            gn = [gpu_numa_node(i) for i in range(world)]
+            gpu_nodes = gn if all(g is not None for g in gn) else None
+        cpus = rank_cpu_set(local, world, allowed, numa, gpu_nodes)
+        if not cpus or len(cpus) == len(allowed):
+            return None
+        os.sched_setaffinity(0, cpus)
+        torch.set_num_threads(max(1, min(len(cpus), 16)))
+        return {"cpus_per_rank": len(cpus), "rank0_cpus": f"{cpus[0]}-{cpus[-1]}", "numa_nodes": len(numa) if numa else None,
+                "gpu_numa_aware": gpu_nodes is not None}
+    except OSError:
+        return None
+
+
+def check_finite(out):
+    """The timed steps must have computed something: every floating-point tensor the last step returned (logits; for RES also the
+    masks and boxes; for training the loss) is finite.  Raises otherwise -- a bench line is only printed for a sane forward."""
+    if out is None:
+        return
+    todo, n = [out], 0
+    while todo:
+        o = todo.pop()
+        if isinstance(o, torch.Tensor):
+            if o.is_floating_point() and o.numel():
+                if not bool(torch.isfinite(o.float() if o.dtype != torch.float32 else o).all()):
+                    raise SystemExit("bench.py: non-finite values in the outputs of the last timed step")
+                n += 1
+        elif isinstance(o, dict):
+            todo += [v for k, v in o.items() if k not in ("past_key_values", "hidden_states", "gt_masks", "gt_boxes")]
+        elif isinstance(o, (list, tuple)):
+            todo += list(o)
+    if n == 0:
+        raise SystemExit("bench.py: the last timed step returned no tensor to check")
 
 
 def timed_steps(step, steps, warmup, dist, batch, device):
@@ -255,14 +409,16 @@ def timed_steps(step, steps, warmup, dist, batch, device):
     if dist:
         dist.barrier()
     sync()
+    last = None
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        last = step()
     sync()
     if dist:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    check_finite(last)                                                        # outside the timed region: the last step's outputs
     return D.global_rate(float(batch * steps), elapsed, device=device)        # (images/s whole job, images, max elapsed)
 
 
@@ -349,6 +505,9 @@ def main():
     ap.add_argument("--no-res", action="store_true", help="skip the C3 RES sub-record of the default (c4) run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks (only with --stub)")
     ap.add_argument("--stub", action="store_true", help="replace the model step by a fixed host-side delay (tests the N-rank protocol without a GPU)")
+    ap.add_argument("--init-pg", action="store_true", help="initialise the process group (RCCL) even at --gpus 1, so that the barrier and the "
+                    "two scalar all-reduces of the aggregation run through RCCL on a single-GPU box")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to CPU sets")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -363,10 +522,18 @@ def main():
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
+    affinity = None if a.no_pin else pin_rank_to_cpus(local, world, use_gpu_topology=not a.stub)
     dist = None
-    if world > 1:
+    if world > 1 or a.init_pg:
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                      # --init-pg outside a launcher
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist_.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
         else:
@@ -379,11 +546,13 @@ def main():
 
         def step():
             time.sleep(0.01 * (1 + rank))                        # rank r is (r+1)x slower: the MAX over ranks must show
+            return torch.zeros(1)
         value, total_images, elapsed = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": round(value, 3), "unit": "images/sec (whole job)", "n_gpus": world, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "stub", "total_images": total_images,
+                              "cpu_affinity": affinity,
                               "config": {"workload": "stub step (host-side delay), " + desc, "per_gpu_batch": batch,
                                          "global_batch": batch * world, "parallelism": f"dp{world}"}}), flush=True)
         if dist:
@@ -416,7 +585,8 @@ def main():
             torch.cuda.empty_cache()
 
     if rank == 0:
-        line = {"metric": METRIC, "value": round(value, 3), "unit": "images/sec (whole job, all GPUs)",
+        line = {"metric": METRIC, "value": round(value, 3), "unit": "images/sec (whole job, all GPUs)", "cpu_affinity": affinity,
+                "outputs_finite": True, "process_group": (a.backend if dist is not None else None),
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": desc, "per_gpu_batch": batch, "global_batch": batch * world, "seq_len": S, "image": image_size,
@@ -430,7 +600,7 @@ def main():
         if roof is not None:
             line["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(image_size, prompt)
+            line["cpu_baseline"] = cpu_baseline(dev)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

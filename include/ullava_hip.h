@@ -337,10 +337,13 @@ int ull_shifted_cross_entropy_bwd_bf16(const void* logits, int64_t ld, const voi
                                        const void* gout, void* dlogits, void* stream);
 
 /* Backward of ull_embed_splice_bf16: demb [B, S, D] -> d_table float32 [vocab, D] += (caller zeroes; NULL = not needed), d_img /
- * d_vid = gradients of the projected visual features (same layouts as the forward's inputs; NULL = not needed). */
+ * d_vid = gradients of the projected visual features (same layouts as the forward's inputs; NULL = not needed).  Rows inside a
+ * spliced span never reach d_table (reference models/ullava_core.py:243-245: torch.cat drops the placeholder rows), with or without
+ * d_img / d_vid.  detach_text != 0 = projector_from_scratch (:230-240, :255-264): in samples that carry an image / video only the
+ * start- and end-token rows accumulate into d_table; text-only samples keep every row. */
 int ull_embed_splice_bwd_bf16(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch,
                               int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab,
-                              void* stream);
+                              int detach_text, void* stream);
 
 /* torch.nn.LayerNorm backward (SAM transformer.py norm1-4 / norm_final_attn): dx; dw, db float32 [D] += (caller zeroes; may be NULL). */
 int ull_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, void* db,
@@ -424,7 +427,7 @@ int ull_rope_bwd_inplace_f16(void* dx, int64_t row_stride, const void* positions
 int ull_attention_bwd_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
 int ull_attention_bwd_mfma_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* Qt, const void* Kt, const void* dOt, int64_t pitch, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
 int ull_shifted_cross_entropy_bwd_f16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, const void* stats, const void* gout, void* dlogits, void* stream);
-int ull_embed_splice_bwd_f16(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
+int ull_embed_splice_bwd_f16(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D, int64_t vocab, int detach_text, void* stream);
 int ull_layernorm_bwd_f16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, void* db, int64_t rows, int64_t D, float eps, void* stream);
 int ull_layernorm2d_cl_bwd_f16(const void* x, const void* w, const void* b, const void* dy, void* dx, void* dw, void* db, int64_t rows, int64_t C, float eps, int gelu, void* stream);
 int ull_gelu_fwd_f16(const void* x, void* y, int64_t n, void* stream);

@@ -261,13 +261,19 @@ def embed_images_videos(sd, cfg: dict, input_ids: Tensor, images: Optional[Tenso
             pos = int(torch.where(cur_ids == ids["IMG_START"])[0][0])
             feat = vision_projector(sd, cfg, img_f[ii])
             n = feat.shape[0]
-            new = torch.cat((cur[: pos + 1], feat, cur[pos + n + 1:]), dim=0)
+            if cfg.get("projector_from_scratch", False):     # :230-240: text rows detached except the start / end token rows
+                new = torch.cat((cur[:pos].detach(), cur[pos:pos + 1], feat, cur[pos + n + 1:pos + n + 2], cur[pos + n + 2:].detach()), dim=0)
+            else:
+                new = torch.cat((cur[: pos + 1], feat, cur[pos + n + 1:]), dim=0)
             ii += 1
         else:
             pos = int(torch.where(cur_ids == ids["VID_START"])[0][0])
             feat = vision_projector(sd, cfg, vid_f[vi])
             n = feat.shape[0]
-            new = torch.cat((cur[: pos + 1], feat, cur[pos + n + 1:]), dim=0)
+            if cfg.get("projector_from_scratch", False):     # :255-264
+                new = torch.cat((cur[:pos].detach(), cur[pos:pos + 1], feat, cur[pos + n + 1:pos + n + 2], cur[pos + n + 2:].detach()), dim=0)
+            else:
+                new = torch.cat((cur[: pos + 1], feat, cur[pos + n + 1:]), dim=0)
             vi += 1
         out.append(new)
     return torch.stack(out, dim=0)

@@ -79,7 +79,7 @@ def core_cfg_dict(d=64, layers=2, heads=4, inter=128, vocab=100, v_hidden=32, v_
 def build_ref_core(cd):
     vc = dict(cd["vision_config"])
     cfg = UllavaCoreConfig(vision_config=vc, vision_hidden_layer=cd["vision_hidden_layer"],
-                           projector_type=cd["projector_type"], projector_from_scratch=False,
+                           projector_type=cd["projector_type"], projector_from_scratch=bool(cd.get("projector_from_scratch", False)),
                            mm_token_ids=cd["mm_token_ids"], hidden_size=cd["hidden_size"],
                            intermediate_size=cd["intermediate_size"], num_hidden_layers=cd["num_hidden_layers"],
                            num_attention_heads=cd["num_attention_heads"], num_key_value_heads=cd["num_attention_heads"],
@@ -549,6 +549,60 @@ def gen_core_grads(name, dtype, seed):
                     loss=r.loss.detach(), grads=ref_grads))
 
 
+# --------------------------------------------------------------------------- G14 embedding-gradient routing of the two training stages
+def gen_stage_grads(name, dtype, seed, from_scratch):
+    """Which rows of `embed_tokens` receive a gradient (ullava_core.py:213-269), on a mixed batch (text-only sample + two image samples):
+    from_scratch=True  = Stage I (train_ullava_core.py:145-156): projector_from_scratch, trainable projector + input embeddings, text rows
+                         of image samples detached except IMG_START / IMG_END;
+    from_scratch=False = Stage II with the projector frozen and the language model trainable: the placeholder rows inside the spliced
+                         span get NO gradient (torch.cat drops them), whether or not the projector asks for one."""
+    print(f"[{name}]")
+    cd = core_cfg_dict(v_hidden=1024, v_layers=2, v_heads=16, v_inter=64)          # the text-only branch hard-codes zeros(256, 1024)
+    cd["projector_from_scratch"] = bool(from_scratch)
+    m = build_ref_core(cd)
+    assert m.projector_from_scratch == bool(from_scratch)
+    shapes, sd = load_seeded(m, seed, dtype)
+    m.train()
+    m.requires_grad_(False)
+    if from_scratch:
+        train = lambda n_: n_.startswith("vision_projector.") or n_ == "model.embed_tokens.weight"
+    else:
+        train = lambda n_: n_.startswith("model.") or n_.startswith("lm_head.")
+    for n_, p_ in m.named_parameters():
+        p_.requires_grad = train(n_)
+    a = img_ids(4, 6, seed=3)
+    S = len(a)
+    b = [1] + [6, 7, 8, 9, 10, 11, 12, 7] + [0] * (S - 9)
+    c = img_ids(4, 3, seed=4)
+    c = c + [0] * (S - len(c))
+    ids = torch.tensor([a, b, c])
+    mask = (ids != 0).long()
+    labels = ids.clone()
+    labels[mask == 0] = -100
+    labels[0, :7] = -100
+    labels[2, :7] = -100
+    g = torch.Generator().manual_seed(seed + 7)
+    images = torch.randn(2, 3, 28, 28, generator=g).to(dtype)
+    r = m(input_ids=ids, attention_mask=mask, images=images, labels=labels)
+    r.loss.backward()
+    ref_grads = {n_: p_.grad.detach().clone() for n_, p_ in m.named_parameters() if p_.grad is not None}
+    leaves = {k: (v.clone().requires_grad_(True) if (train(k) and v.is_floating_point()) else v) for k, v in sd.items()}
+    o = O.core_forward(leaves, cd, ids, mask, images, labels=labels)
+    eq(o["loss"].detach(), r.loss.detach(), "loss")
+    o["loss"].backward()
+    for k, gr in ref_grads.items():
+        assert leaves[k].grad is not None, k
+        eq(leaves[k].grad, gr, f"grad[{k}]")
+    et = ref_grads["model.embed_tokens.weight"]
+    rows = sorted(int(i) for i in et.float().abs().sum(1).nonzero().flatten())
+    print(f"   loss {float(r.loss):.5f}; {len(ref_grads)} gradients bit-exact; embed_tokens rows with a gradient: {rows}")
+    assert MM["IMG_PATCH"] not in rows
+    keep = {k: v for k, v in ref_grads.items() if k == "model.embed_tokens.weight" or k.startswith("vision_projector.")}
+    norms = {k: float(v.float().norm()) for k, v in ref_grads.items()}
+    save(name, dict(cfg=cd, seed=seed, dtype=str(dtype), shapes=shapes, input_ids=ids, attention_mask=mask, labels=labels, images=images,
+                    loss=r.loss.detach(), grads=keep, grad_norms=norms, trainable=sorted(k for k in sd if train(k)), embed_rows=rows))
+
+
 # --------------------------------------------------------------------------- G13 gradients of the full RES / REC training loss
 def gen_full_grads(name, dtype, seed):
     """UllavaForCausalLM.forward(inference=False)["loss"].backward() with the trainable set of train_ullava.py:207-261 (no LoRA: the
@@ -668,6 +722,10 @@ if __name__ == "__main__":
     if want("grads"):
         gen_core_grads("g12_core_grads_fp32.pt", torch.float32, 12)
         gen_core_grads("g12_core_grads_bf16.pt", torch.bfloat16, 12)
+    if want("stagegrads"):
+        for dt, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+            gen_stage_grads(f"g14_stage1_grads_{tag}.pt", dt, 14, True)
+            gen_stage_grads(f"g14_stage2_frozen_projector_grads_{tag}.pt", dt, 14, False)
     if want("signatures"):
         gen_signatures("reference_signatures.json")
     if want("losses"):

@@ -56,7 +56,8 @@ def core_model_from_fixture(fx, device):
     C = pkg("configuration")
     cd = fx["cfg"]
     cfg = C.UllavaCoreConfig(vision_config=cd["vision_config"], vision_hidden_layer=cd["vision_hidden_layer"],
-                             projector_type=cd["projector_type"], projector_from_scratch=False, mm_token_ids=cd["mm_token_ids"],
+                             projector_type=cd["projector_type"], projector_from_scratch=bool(cd.get("projector_from_scratch", False)),
+                             mm_token_ids=cd["mm_token_ids"],
                              vocab_size=cd["vocab_size"], hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
                              num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"],
                              rms_norm_eps=cd["rms_norm_eps"], rope_theta=cd["rope_theta"])

@@ -180,6 +180,41 @@ def test_core_training_path_matches_reference_gradients_g12():
     print("worst relative L2 error of a HIP gradient vs the fp32 reference gradient:", worst)
 
 
+@pytest.mark.parametrize("stage", ["stage1", "stage2_frozen_projector"])
+def test_embedding_gradient_routing_matches_reference_g14(stage):
+    """The two training stages route the embedding gradient differently (reference ullava_core.py:213-269; fixtures G14 made from the
+    reference's own .grad on a mixed batch = text-only sample + two image samples):
+      stage1 (projector_from_scratch, train_ullava_core.py:145-156: projector + input embeddings trainable): text rows of image samples
+        are detached except IMG_START / IMG_END, the text-only sample keeps all rows;
+      stage2 with a FROZEN projector: the <image_patch> placeholder rows inside the span get no gradient although no d_img is asked for.
+    The set of embed_tokens rows with a non-zero gradient must be EXACTLY the reference's, and the values within the G12 rule."""
+    from helpers import core_model_from_fixture
+    fx, fx32 = load_fixture(f"g14_{stage}_grads_bf16.pt"), load_fixture(f"g14_{stage}_grads_fp32.pt")
+    model, sd = core_model_from_fixture(fx, DEV)
+    assert bool(model.projector_from_scratch) == (stage == "stage1")
+    model.train()
+    trainable = set(fx["trainable"])
+    for n, p in model.named_parameters():
+        p.requires_grad = n in trainable
+    ids, mask, images, labels = (fx[k].to(DEV) for k in ("input_ids", "attention_mask", "images", "labels"))
+    out = model(input_ids=ids, attention_mask=mask, images=images, labels=labels)
+    assert abs(float(out.loss) - float(fx["loss"])) <= 0.02 * abs(float(fx["loss"]))
+    out.loss.backward()
+    et = model.model.embed_tokens.weight.grad
+    rows = sorted(int(i) for i in et.float().abs().sum(1).nonzero().flatten())
+    assert rows == fx["embed_rows"], (rows, fx["embed_rows"])
+    assert fx["cfg"]["mm_token_ids"]["IMG_PATCH"] not in rows
+    for n, truth in fx32["grads"].items():
+        g = dict(model.named_parameters())[n].grad
+        assert g is not None, n
+        e_ref, e_hip = rel_l2(fx["grads"][n], truth), rel_l2(g, truth)
+        print(f"{stage} {n:40s} HIP {e_hip:.4f} reference-bf16 {e_ref:.4f}")
+        assert e_hip <= max(3.0 * e_ref, 0.02), n
+    for n, nrm in fx32["grad_norms"].items():
+        g = dict(model.named_parameters())[n].grad
+        assert g is not None and abs(float(g.float().norm()) - nrm) <= 0.05 * nrm + 1e-6, n
+
+
 def test_sam_side_backward_ops():
     """LayerNorm, LayerNorm2d(+GELU), GELU, decoder attention (7 x 4096 and 4096 x 7), mask product, bilinear, mask / box losses:
     HIP backward vs torch autograd of the oracle's fp32 ops."""
@@ -415,10 +450,25 @@ def test_lora_adapters_on_the_training_path():
     with torch.no_grad():
         lm = merged(input_ids=ids, attention_mask=mask, images=images).logits.float().cpu()
     assert rel_l2(lm, logits_graph) < 0.03
+    # evaluation WHILE the adapters are attached (train_ullava.py's eval loop; use_cache=True is the config default): under no_grad the
+    # inference kernels run on a temporarily merged pack -- the parameters stay un-merged, the pack follows the adapters when they change
+    with torch.no_grad():
+        l_att = model(input_ids=ids, attention_mask=mask, images=images, use_cache=True).logits.float().cpu()
+        seq_att = model.generate(input_ids=ids[:1, :len(fx["input_ids"][0])], images=images[:1], max_new_tokens=4, do_sample=False, use_cache=True)
+    assert torch.equal(l_att, lm) and hasattr(model.model.layers[0].self_attn.q_proj, "lora_A")
+    lb0 = model.model.layers[0].self_attn.q_proj.lora_B.weight
+    with torch.no_grad():
+        lb0.mul_(2.0)                                # an "optimizer step": the version counter moves, the pack must follow
+        l_moved = model(input_ids=ids, attention_mask=mask, images=images).logits.float().cpu()
+        lb0.mul_(0.5)
+        l_back = model(input_ids=ids, attention_mask=mask, images=images).logits.float().cpu()
+    assert not torch.equal(l_moved, lm) and torch.equal(l_back, lm)
     model.merge_lora()
     with torch.no_grad():
         l2 = model(input_ids=ids, attention_mask=mask, images=images).logits.float().cpu()
+        seq_m = model.generate(input_ids=ids[:1, :len(fx["input_ids"][0])], images=images[:1], max_new_tokens=4, do_sample=False, use_cache=True)
     assert torch.equal(l2, lm)                       # the same merged weights on the same kernels
+    assert torch.equal(seq_att, seq_m)
     # dropout: keeps ~(1 - p) of the elements, scaled by 1 / (1 - p), and its backward uses the same mask
     A = pkg("autograd_ops")
     x = torch.ones(64, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True)

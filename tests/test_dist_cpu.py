@@ -94,15 +94,24 @@ def _grad_worker(rank, world, port, q):
     params = [torch.nn.Parameter(torch.zeros(s)) for s in ((7, 5), (33,), (4, 4, 3), (1,))]
     for p in params:
         p.grad = torch.randn(p.shape, generator=g)
-    params.append(torch.nn.Parameter(torch.zeros(3)))            # no gradient: skipped
+    # a head that only rank 0's batch exercised (no [SEG] row on rank 1: modeling_ullava._select never touches seg_projector there):
+    # rank 1 has NO .grad for it, the bucket layout must not depend on that and both ranks must end with g0 / 2
+    head = torch.nn.Parameter(torch.zeros(6, 2))
+    if rank == 0:
+        head.grad = torch.full((6, 2), 3.0)
+    params.insert(2, head)
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)      # frozen on every rank: skipped, stays without a gradient
+    params.append(frozen)
     nb = D.allreduce_gradients(params, bucket_bytes=200)         # forces several buckets
+    assert frozen.grad is None
     q.put((rank, nb, [p.grad.clone() for p in params[:-1]]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_gradient_allreduce_gloo_world2():
-    """data-parallel gradient averaging (bucketed) over 2 CPU ranks: every rank ends with the mean of the per-rank gradients."""
+    """data-parallel gradient averaging (bucketed) over 2 CPU ranks: every rank ends with the mean of the per-rank gradients, a
+    parameter that has a gradient on one rank only is averaged against zeros (same bucket layout on both ranks)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -118,5 +127,43 @@ def test_gradient_allreduce_gloo_world2():
     per_rank = [[torch.randn(s, generator=gens[r]) for s in shapes] for r in range(2)]
     for (rank, nb, grads) in out:
         assert nb >= 2
+        head = grads.pop(2)
+        torch.testing.assert_close(head, torch.full((6, 2), 1.5))
         for i, g in enumerate(grads):
             torch.testing.assert_close(g, (per_rank[0][i] + per_rank[1][i]) / 2, rtol=1e-6, atol=1e-6)
+
+
+def test_bench_launch_and_aggregation_gloo_world8_stub():
+    """The 8-rank launch the driver's scaling run uses (one rank per GPU of an 8-GPU node), on CPU with the stub step: 8 ranks start,
+    pin themselves (bench.pin_rank_to_cpus), the timing protocol aggregates SUM(images) / MAX(elapsed), one JSON line comes back."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--stub", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["total_images"] == 8 * 32 * 2 and rec["config"]["global_batch"] == 256
+    assert rec["ms_per_step"] >= 80.0                    # rank 7 sleeps 80 ms per step: the MAX over ranks
+    aff = rec["cpu_affinity"]                            # 8 CPUs here -> one per rank; hosts with < 8 usable CPUs do not pin
+    assert aff is None or (aff["cpus_per_rank"] >= 1 and aff["cpus_per_rank"] * 8 <= os.cpu_count())
+
+
+def test_rank_cpu_sets_partition_the_host():
+    """per-rank CPU pinning (host-side contention is what threatens >= 6x at 8 GPUs): disjoint, contiguous, covers the
+    allowed CPUs, and follows NUMA nodes when the rank count divides them."""
+    sys.path.insert(0, ROOT)
+    import bench
+    allowed = list(range(0, 96)) + list(range(128, 224))            # 192 usable CPUs with a hole
+    sets = [bench.rank_cpu_set(r, 8, allowed, None) for r in range(8)]
+    assert all(len(s) == 24 for s in sets) and sorted(c for s in sets for c in s) == allowed
+    numa = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    sets = [bench.rank_cpu_set(r, 4, list(range(128)), numa) for r in range(4)]
+    assert sets[0] == list(range(0, 32)) and sets[1] == list(range(32, 64)) and sets[2] == list(range(64, 96))
+    assert bench.rank_cpu_set(0, 1, list(range(16)), None) == list(range(16))
+    assert bench.rank_cpu_set(2, 3, [0, 1], None) == [0, 1]         # fewer CPUs than ranks: no pinning

@@ -286,3 +286,38 @@ def test_lora_adapter_is_merged_at_load(tmp_path):
     json.dump({"peft_type": "LORA", "r": r + 1, "lora_alpha": alpha}, open(os.path.join(d, "adapter_config.json"), "w"))
     with pytest.raises(RuntimeError):
         M.UllavaCoreForCausalLM.from_pretrained(d, torch_dtype=base.model.embed_tokens.weight.dtype)
+
+
+def test_no_repeat_ngram_rule_matches_transformers_processor():
+    """generate(no_repeat_ngram_size=n) (reference models/ullava.py:360 forwards it to HF generate): the host-side banned-token rule must be
+    transformers' NoRepeatNGramLogitsProcessor's, row by row, on random id histories with many repeats."""
+    from transformers.generation.logits_process import NoRepeatNGramLogitsProcessor
+    M = pkg("modeling_core")
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 2, 3, 4):
+        for L in (1, 2, 3, 7, 40):
+            ids = torch.randint(0, 6, (5, L), generator=g)
+            scores = torch.zeros(5, 6)
+            want = NoRepeatNGramLogitsProcessor(n)(ids, scores.clone())
+            banned = M.no_repeat_ngram_banned_tokens(ids.tolist(), n)
+            got = scores.clone()
+            for b, toks in enumerate(banned):
+                if toks:
+                    got[b, torch.tensor(toks)] = float("-inf")
+            assert torch.equal(got, want), (n, L)
+
+
+def test_generate_rejects_unknown_options():
+    """Options the decoding loop does not implement must raise, not be swallowed (HF validates model kwargs the same way)."""
+    C, M = pkg("configuration"), pkg("modeling_core")
+    cfg = C.UllavaCoreConfig(vision_config=dict(hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64, image_size=28,
+                                                patch_size=14), vocab_size=50, hidden_size=64, intermediate_size=128, num_hidden_layers=1,
+                             num_attention_heads=4)
+    m = M.UllavaCoreForCausalLM(cfg)
+    ids = torch.ones(1, 3, dtype=torch.long)
+    with pytest.raises(TypeError, match="repetition_penalty"):
+        m.generate(input_ids=ids, repetition_penalty=1.2)
+    with pytest.raises(NotImplementedError):
+        m.generate(input_ids=ids, num_beams=4)
+    with pytest.raises(ValueError):
+        m.generate(input_ids=ids, no_repeat_ngram_size=-1)

@@ -163,6 +163,27 @@ def test_core_gradients_g12(name):
         _eq(leaves[k].grad, g)
 
 
+@pytest.mark.parametrize("name", ["g14_stage1_grads_fp32.pt", "g14_stage1_grads_bf16.pt", "g14_stage2_frozen_projector_grads_fp32.pt",
+                                  "g14_stage2_frozen_projector_grads_bf16.pt"])
+def test_embedding_gradient_routing_g14(name):
+    """Which embed_tokens rows get a gradient in the two training stages (ullava_core.py:213-269): Stage I detaches the text rows of image
+    samples except IMG_START / IMG_END; the placeholder rows inside the spliced span never get one.  Oracle autograd == reference .grad."""
+    fx = load_fixture(name)
+    sd = fixture_state_dict(fx)
+    trainable = set(fx["trainable"])
+    leaves = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    o = O.core_forward(leaves, fx["cfg"], fx["input_ids"], fx["attention_mask"], fx["images"], labels=fx["labels"])
+    _eq(o["loss"].detach(), fx["loss"])
+    o["loss"].backward()
+    for k, g in fx["grads"].items():
+        _eq(leaves[k].grad, g)
+    for k, nrm in fx["grad_norms"].items():
+        assert float(leaves[k].grad.float().norm()) == nrm, k
+    et = leaves["model.embed_tokens.weight"].grad
+    assert sorted(int(i) for i in et.float().abs().sum(1).nonzero().flatten()) == fx["embed_rows"]
+    assert fx["cfg"]["mm_token_ids"]["IMG_PATCH"] not in fx["embed_rows"]
+
+
 def test_full_training_gradients_g13():
     """autograd through oracle forward + losses == the reference's forward(inference=False)['loss'].backward() on the trainable set of
     train_ullava.py:207-261 (strided samples + exact norms of 151 gradients; fp32 fixture, the bf16 one is replayed on the GPU box)."""

@@ -33,7 +33,7 @@ SIGNATURES = {
     "ull_attention_bwd_mfma_bf16": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, ctypes.POINTER(_i64), _ptr, _i64, _i64,
                                     _i64, _i64, _i64, _i32, _f32, _ptr, _ptr],
     "ull_shifted_cross_entropy_bwd_bf16": [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr],
-    "ull_embed_splice_bwd_bf16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr],
+    "ull_embed_splice_bwd_bf16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_colsum_bf16": [_ptr, _i64, _i64, _i64, _ptr, _ptr],
     "ull_transpose2d_bf16": [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     "ull_sum_slabs_bf16": [_ptr, _ptr, _i64, _i64, _f32, _ptr],

@@ -191,24 +191,28 @@ def shifted_cross_entropy(logits, labels):
 
 class _EmbedSplice(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off):
+    def forward(ctx, table, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off, detach_text):
         ctx.save_for_backward(ids, spans)
         ctx.meta = (table.shape[0], None if img_feat is None else tuple(img_feat.shape), None if vid_feat is None else tuple(vid_feat.shape),
-                    img_tokens, img_pitch, img_off, table.dtype)
+                    img_tokens, img_pitch, img_off, table.dtype, detach_text)
         return ops.embed_splice(ids, table, img_feat, vid_feat, spans, img_tokens, img_pitch, img_off)
 
     @staticmethod
     def backward(ctx, demb):
         ids, spans = ctx.saved_tensors
-        vocab, img_shape, vid_shape, img_tokens, img_pitch, img_off, dt = ctx.meta
+        vocab, img_shape, vid_shape, img_tokens, img_pitch, img_off, dt, detach_text = ctx.meta
+        # span lengths travel even when the features need no gradient (frozen projector): span rows never reach the table
         d_table, d_img, d_vid = ops.embed_splice_bwd(ids, demb.contiguous(), vocab, img_shape if ctx.needs_input_grad[1] else None,
                                                      vid_shape if ctx.needs_input_grad[2] else None, spans, img_tokens, img_pitch, img_off,
-                                                     need_table=ctx.needs_input_grad[0])
-        return (d_table.to(dt) if d_table is not None else None), d_img, d_vid, None, None, None, None, None
+                                                     need_table=ctx.needs_input_grad[0], vid_tokens=vid_shape[-2] if vid_shape is not None else 0,
+                                                     detach_text=detach_text)
+        return (d_table.to(dt) if d_table is not None else None), d_img, d_vid, None, None, None, None, None, None
 
 
-def embed_splice(table, img_feat, vid_feat, ids, spans, img_tokens=0, img_pitch=0, img_off=0):
-    return _EmbedSplice.apply(table, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off)
+def embed_splice(table, img_feat, vid_feat, ids, spans, img_tokens=0, img_pitch=0, img_off=0, detach_text=False):
+    """detach_text: reference `projector_from_scratch` (ullava_core.py:230-240): text rows of image / video samples are detached,
+    except the start / end token rows."""
+    return _EmbedSplice.apply(table, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off, bool(detach_text))
 
 
 # ---- SAM mask decoder / postprocess / losses (training of `mask_decoder`, seg / det heads: train_ullava.py:248-261) ------------------

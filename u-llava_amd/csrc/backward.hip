@@ -898,28 +898,32 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const elem_t* __restrict__ 
     }
 }
 
-// ---- models/ullava_core.py:191,243-245 backward of the embedding lookup + visual-token splice --------------------------------------
+// ---- models/ullava_core.py:191,230-269 backward of the embedding lookup + visual-token splice --------------------------------------
 // rows that came from the token table add into d_table (fp32 [vocab, D], atomics: ids repeat); rows of the spliced span are the
-// gradient of the projected visual features (each written once).
+// gradient of the projected visual features (each written once) and NEVER reach the table: the reference's torch.cat drops the
+// placeholder rows of the looked-up embeddings (:243-245), whether or not the projector asks for a gradient.
+// detach_text (projector_from_scratch, :230-240 / :255-264): in a sample that carries an image / video only the start-token row
+// and the end-token row (position start + tokens + 1) keep their gradient, every other text row is .detach()ed; a text-only sample
+// (:213-220) keeps all of its rows.
 __global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const int64_t* __restrict__ ids, const elem_t* __restrict__ demb, float* __restrict__ d_table,
                                                                elem_t* __restrict__ d_img, int n_img_tok, int img_pitch, int img_off,
                                                                elem_t* __restrict__ d_vid, int n_vid_tok, const int32_t* __restrict__ spans, int S,
-                                                               int D, long vocab) {
+                                                               int D, long vocab, int detach_text) {
     const long row = blockIdx.x;
     const int b = (int)(row / S), s = (int)(row % S);
     const elem_t* g = demb + row * D;
     if (spans != nullptr) {
         const int kind = spans[b * 4], pos = spans[b * 4 + 1], idx = spans[b * 4 + 2];
-        if (kind == 1 && d_img != nullptr && s > pos && s <= pos + n_img_tok) {
-            elem_t* o = d_img + ((long)idx * img_pitch + img_off + (s - pos - 1)) * D;
-            for (int c = threadIdx.x; c < D; c += 256) o[c] = g[c];
+        const int ntok = kind == 1 ? n_img_tok : (kind == 2 ? n_vid_tok : 0);
+        if (ntok > 0 && s > pos && s <= pos + ntok) {
+            elem_t* base = kind == 1 ? d_img : d_vid;
+            if (base != nullptr) {
+                elem_t* o = kind == 1 ? base + ((long)idx * img_pitch + img_off + (s - pos - 1)) * D : base + ((long)idx * n_vid_tok + (s - pos - 1)) * D;
+                for (int c = threadIdx.x; c < D; c += 256) o[c] = g[c];
+            }
             return;
         }
-        if (kind == 2 && d_vid != nullptr && s > pos && s <= pos + n_vid_tok) {
-            elem_t* o = d_vid + ((long)idx * n_vid_tok + (s - pos - 1)) * D;
-            for (int c = threadIdx.x; c < D; c += 256) o[c] = g[c];
-            return;
-        }
+        if (detach_text && ntok > 0 && s != pos && s != pos + ntok + 1) return;
     }
     long id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
@@ -1222,11 +1226,11 @@ extern "C" int ULL_FN(ull_shifted_cross_entropy_bwd_)(const void* logits, int64_
 
 extern "C" int ULL_FN(ull_embed_splice_bwd_)(const void* ids, const void* demb, void* d_table, void* d_img, int64_t n_img_tok, int64_t img_pitch,
                                          int64_t img_off, void* d_vid, int64_t n_vid_tok, const void* spans, int64_t B, int64_t S, int64_t D,
-                                         int64_t vocab, void* stream) {
+                                         int64_t vocab, int detach_text, void* stream) {
     if (!ids || !demb || B <= 0 || S <= 0 || D <= 0 || vocab <= 0) return ULL_ERR_ARG;
     hipLaunchKernelGGL(embed_splice_bwd_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, (const elem_t*)demb,
                        (float*)d_table, (elem_t*)d_img, (int)n_img_tok, (int)img_pitch, (int)img_off, (elem_t*)d_vid, (int)n_vid_tok,
-                       (const int32_t*)spans, (int)S, (int)D, (long)vocab);
+                       (const int32_t*)spans, (int)S, (int)D, (long)vocab, detach_text);
     return ull_check_launch();
 }
 

@@ -186,6 +186,25 @@ def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     return torch.stack((gate.view(I // 16, 16, K), up.view(I // 16, 16, K)), dim=1).reshape(2 * I, K).contiguous()
 
 
+def no_repeat_ngram_banned_tokens(rows, ngram_size: int):
+    """transformers' NoRepeatNGramLogitsProcessor rule (generation/logits_process.py `_calc_banned_ngram_tokens`; reference
+    models/ullava.py:360 forwards `no_repeat_ngram_size` to HF generate): for every row (list of ids so far, prompt included), the tokens
+    that followed an earlier occurrence of the row's last ngram_size - 1 tokens.  Host-side integer bookkeeping, like HF's."""
+    out = []
+    for toks in rows:
+        cur = len(toks)
+        if ngram_size <= 0 or cur + 1 < ngram_size:
+            out.append([])
+            continue
+        prefix = tuple(toks[cur + 1 - ngram_size:cur])
+        banned = []
+        for i in range(cur - ngram_size + 1):
+            if tuple(toks[i:i + ngram_size - 1]) == prefix:
+                banned.append(toks[i + ngram_size - 1])
+        out.append(banned)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------
 class UllavaCoreForCausalLM(nn.Module):
     config_class = UllavaCoreConfig
@@ -297,10 +316,20 @@ class UllavaCoreForCausalLM(nn.Module):
         """Build the MI355X layouts.  Call again after changing parameters."""
         cfg = self.config
         pk = {"llama": [], "clip": []}
+        lora = getattr(self, "_lora", None)
+
+        def eff(lin):
+            """the projection the inference kernels see: with an (un-merged) LoRA adapter attached, W + (alpha / r) B A rounded once --
+            PeftModel.merge_adapter's arithmetic -- WITHOUT touching the parameters (generate() / evaluate() under no_grad while
+            the adapters train: train_ullava.py's evaluation loop; the pack is rebuilt when the adapters change, see _pk)."""
+            if lora is None or not hasattr(lin, "lora_A"):
+                return lin.weight
+            s_ = lora["lora_alpha"] / lora["r"]
+            return (lin.weight.float() + (lin.lora_B.weight.float() @ lin.lora_A.weight.float()) * s_).to(lin.weight.dtype)
         for l in self.model.layers:
             a, m = l.self_attn, l.mlp
             pk["llama"].append(dict(
-                w_qkv=torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).contiguous(),
+                w_qkv=torch.cat([eff(a.q_proj), eff(a.k_proj), eff(a.v_proj)], dim=0).contiguous(),
                 w_o=a.o_proj.weight, w_gu=interleave_gate_up(m.gate_proj.weight, m.up_proj.weight), w_down=m.down_proj.weight,
                 ln1=l.input_layernorm.weight, ln2=l.post_attention_layernorm.weight))
         for l in self.vision_encoder.encoder.layers:
@@ -327,6 +356,7 @@ class UllavaCoreForCausalLM(nn.Module):
             for t in (d["w_qkv"], d["w_out"], d["fc1"].weight, d["fc2"].weight):
                 ops.register_tiled(t)
         ops.register_tiled(self.lm_head.weight)
+        pk["lora_versions"] = self._lora_versions()
         self._packed = pk
         if free_originals:
             for l in self.model.layers:
@@ -334,9 +364,15 @@ class UllavaCoreForCausalLM(nn.Module):
                     mod.weight.data = torch.empty(0, device=mod.weight.device, dtype=mod.weight.dtype)
         return self
 
+    def _lora_versions(self):
+        if getattr(self, "_lora", None) is None:
+            return None
+        return tuple(p_._version for l in self.model.layers for t in ("q_proj", "k_proj", "v_proj") if hasattr(getattr(l.self_attn, t), "lora_A")
+                     for p_ in (getattr(l.self_attn, t).lora_A.weight, getattr(l.self_attn, t).lora_B.weight))
+
     def _pk(self):
-        if self._packed is None:
-            self.pack_weights()
+        if self._packed is None or self._packed.get("lora_versions") != self._lora_versions():
+            self.pack_weights()              # (adapters attached and changed since the pack was made: an optimizer step bumps ._version)
         return self._packed
 
     # -- CLIP ----------------------------------------------------------------------------------------------
@@ -479,10 +515,10 @@ class UllavaCoreForCausalLM(nn.Module):
         """True when this call must build an autograd graph: gradients enabled and some parameter of the language model or the
         projector asks for one (the reference freezes / unfreezes by `requires_grad`, train_ullava.py:207-261).  The CLIP tower
         is frozen by both training scripts and always runs the inference kernels without a graph."""
-        if getattr(self, "_lora", None) is not None:
-            return True                      # un-merged adapters live in the graph path only (merge_lora() for the inference kernels)
         if not torch.is_grad_enabled():
-            return False
+            return False                     # no_grad / eval with adapters attached: inference kernels on a temporarily merged pack (_pk)
+        if getattr(self, "_lora", None) is not None:
+            return True
         return any(p.requires_grad for p in self.lm_head.parameters()) or any(p.requires_grad for p in self.model.parameters()) or \
             any(p.requires_grad for p in self.vision_projector.parameters())
 
@@ -574,7 +610,10 @@ class UllavaCoreForCausalLM(nn.Module):
             if mm is None:
                 spans = None
         if self._training_graph():
-            emb = A.embed_splice(self.model.embed_tokens.weight, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off)
+            # projector_from_scratch (stage 1, configs/train/ullava_core.yaml): reference :230-240 detaches every text row of a
+            # sample that carries an image / video except its start / end token rows
+            emb = A.embed_splice(self.model.embed_tokens.weight, img_feat, vid_feat, ids, spans, img_tokens, img_pitch, img_off,
+                                 detach_text=bool(self.projector_from_scratch))
         else:
             emb = ops.embed_splice(ids, self.model.embed_tokens.weight, img_feat, vid_feat, spans, img_tokens, img_pitch, img_off)
         return None, emb
@@ -725,6 +764,14 @@ class UllavaCoreForCausalLM(nn.Module):
         softmax(logits / temperature) with optional nucleus filtering."""
         if num_beams != 1:
             raise NotImplementedError("beam search is not used by the reference callers (num_beams=1)")
+        if kwargs:
+            # HF generate() validates its model kwargs and raises on unknown ones; options this loop does not implement must not be
+            # swallowed (a silently ignored `repetition_penalty` changes the ids)
+            raise TypeError(f"generate() got unsupported keyword arguments {sorted(kwargs)} (supported: greedy / sampling with temperature, "
+                            "top_p, no_repeat_ngram_size, stopping_criteria, eos_token_id, pad_token_id, max_new_tokens)")
+        ngram = int(no_repeat_ngram_size) if no_repeat_ngram_size else 0
+        if ngram < 0:
+            raise ValueError(f"`no_repeat_ngram_size` has to be a positive integer, but is {no_repeat_ngram_size}")
         use_cache = self.config.use_cache if use_cache is None else use_cache
         seq = input_ids
         B = seq.shape[0]
@@ -763,6 +810,12 @@ class UllavaCoreForCausalLM(nn.Module):
                     else:
                         steps_hidden.append(out.hidden_states)
             logits = out.logits[:, -1].float()
+            if ngram > 0:
+                # HF NoRepeatNGramLogitsProcessor (logits processors run before the sampling warpers): tokens that would complete an
+                # n-gram already present in the row (prompt included) get -inf
+                for b_, banned in enumerate(no_repeat_ngram_banned_tokens(seq.tolist(), ngram)):
+                    if banned:
+                        logits[b_, torch.as_tensor(banned, device=logits.device)] = float("-inf")
             if do_sample and temperature and temperature > 0:
                 probs = torch.softmax(logits / temperature, dim=-1)
                 if top_p is not None and top_p < 1.0:

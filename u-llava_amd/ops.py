@@ -678,17 +678,19 @@ def shifted_cross_entropy_bwd(logits: torch.Tensor, labels: torch.Tensor, stats:
 
 
 def embed_splice_bwd(ids, demb, vocab: int, img_shape=None, vid_shape=None, spans=None, img_tokens: int = 0, img_pitch: int = 0, img_off: int = 0,
-                     need_table: bool = True):
-    """-> (d_table float32 [vocab, D] or None, d_img [n_img, pitch, D] or None, d_vid or None); rows not written stay zero."""
+                     need_table: bool = True, vid_tokens: int = 0, detach_text: bool = False):
+    """-> (d_table float32 [vocab, D] or None, d_img [n_img, pitch, D] or None, d_vid or None); rows not written stay zero.
+    img_tokens / vid_tokens: span lengths (needed even when d_img / d_vid are not: span rows never reach the table).
+    detach_text: projector_from_scratch -- only the start / end token rows of samples with an image / video reach the table."""
     _chk(ids, "input_ids", torch.int64); _chk(demb, "demb")
     B, S = ids.shape
     D = demb.shape[-1]
     d_table = torch.zeros(vocab, D, device=demb.device, dtype=torch.float32) if need_table else None
     d_img = torch.zeros(img_shape, device=demb.device, dtype=demb.dtype) if img_shape is not None else None
     d_vid = torch.zeros(vid_shape, device=demb.device, dtype=demb.dtype) if vid_shape is not None else None
-    n_vid = vid_shape[-2] if vid_shape is not None else 0
+    n_vid = vid_shape[-2] if vid_shape is not None else vid_tokens
     _lib.call("ull_embed_splice_bwd_" + _SFX[demb.dtype], _p(ids), _p(demb.contiguous()), _p(d_table), _p(d_img), img_tokens, img_pitch, img_off,
-              _p(d_vid), n_vid, _p(spans), B, S, D, vocab, _stream())
+              _p(d_vid), n_vid, _p(spans), B, S, D, vocab, int(detach_text), _stream())
     return d_table, d_img, d_vid
 
 
