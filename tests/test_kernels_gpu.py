@@ -696,3 +696,23 @@ def test_per_op_fixture_g6_real_dims(name, dt):
         got = ops.clip_embed_ln(patches, x["cls"].to(DEV), x[posk].to(DEV), x["ln_w"].to(DEV), x["ln_b"].to(DEV), n, tokens, 1e-5)
         # LayerNorm subtracts the row mean: a one-unit flip of an input near the mean is many units of the output -- absolute bound
         check(got, f"clip_embed_ln_{isz}", 2e-2, floor_frac=0.25, ulps=2.0)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("R,n,scale", [(2, 8, 0.5), (3, 1001, 1.0 / 3), (8, 4099, 0.125), (7, 262147, 1.0 / 7), (1, 77, 1.0)])
+def test_sum_slabs_against_fp32_sum(dt, R, n, scale):
+    """`ull_sum_slabs` (the local reduction of the direct-exchange gradient all-reduce, dist.allreduce_gradients): out[i] =
+    rnd(scale * sum_r x[r, i]) with fp32 accumulation in slab order -- bit-exact against torch's fp32 sum over the same order for
+    R <= 8 (odd n, every world size of one node)."""
+    ops = pkg("ops")
+    g = torch.Generator().manual_seed(R * 1000 + n)
+    x = torch.randn(R, n, generator=g).to(dt)
+    want = torch.zeros(n, dtype=torch.float32)
+    for r in range(R):                                       # the kernel's order: slab 0, 1, ... accumulated in fp32
+        want = want + x[r].float()
+    want = (want * torch.tensor(scale, dtype=torch.float32)).to(dt)
+    got = ops.sum_slabs(x.to(DEV), scale)
+    assert got.dtype == dt and tuple(got.shape) == (n,)
+    assert torch.equal(got.cpu(), want), float((got.cpu().float() - want.float()).abs().max())
+    with pytest.raises(RuntimeError):
+        ops.sum_slabs(x.float().to(DEV), scale)              # no fp32 build: allreduce_gradients routes fp32 buckets to all_reduce
