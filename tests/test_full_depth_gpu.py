@@ -6,8 +6,8 @@ on a second HIP stream, B = 8), checked through size-independent properties -- t
     holding the same weights at the same batch -- and at single-sample size such shallow full-width models are what
     tests/test_model_gpu.py::test_full_width_forward_against_oracle compares with the oracle;
   * batch independence: sample b inside the batch vs the same sample alone.  The two sizes take different tile kernels / stream-K
-    splits (different fp32 summation order -> single-ulp flips), which a random-init 32-layer stack amplifies; the bounds below are
-    the measured figures x 1.5 (printed on every run).
+    splits; measured on MI355X they nevertheless agree bit for bit at every depth (both accumulate K in the same order), which the
+    asserts pin (exact for embeddings / layer 0, the 1.5-ulp rule of test_model_gpu.py for logits; the record is printed on every run).
 
 Also here: the never-before-executed RCCL surfaces at world size 1 (process-group init, barrier, the two scalar all-reduces of the bench
 aggregation, the direct-exchange gradient reduction), run in a subprocess under a timeout.
@@ -69,11 +69,13 @@ def test_c4_bench_workload_full_depth():
     s32 = _stats(full.logits[bsel], one.logits[0])
     agree = float((full.logits[bsel].argmax(-1) == one.logits[0].argmax(-1)).float().mean())
     print("C4 full depth, sample 5 in B=32 vs alone:", json.dumps(dict(embeds=s_emb, layer0=s_l1, logits_3_layers=s3, logits_32_layers=s32, argmax_agree=agree)))
-    assert s_emb["max"] <= 2.0 ** -7 * s_emb["ref_max"]                      # CLIP + projector + splice: single-ulp level
-    assert s_l1["max"] <= 2.0 ** -6 * s_l1["ref_max"]
-    assert s3["max"] <= 2.0 ** -6 * s3["ref_max"] and s3["mean"] <= 2.0 ** -8 * s3["ref_std"]     # the 1.5-ulp rule of test_model_gpu.py
-    # 32 random-init layers amplify the flips: bounded at the measured level x 1.5 (see the printed record)
-    assert s32["mean"] <= 0.06 * s32["ref_std"] and agree >= 0.80
+    # measured on MI355X: every one of these is bit-identical (frac_equal 1.0) -- the 128x128 kernel of the single-sample run and the
+    # 256x256 kernel (+ stream-K tail) of the batch accumulate K in the same order.  Embeddings and layer 0 are asserted exact; the
+    # logits get the 1.5-ulp rule of test_model_gpu.py so that a legitimate change of the K-split policy does not read as a failure
+    assert s_emb["max"] == 0.0 and s_l1["max"] == 0.0
+    for s_ in (s3, s32):
+        assert s_["max"] <= 2.0 ** -6 * s_["ref_max"] and s_["mean"] <= 2.0 ** -8 * s_["ref_std"]
+    assert agree >= 0.99
 
 
 def test_res_bench_workload_full_depth():
@@ -100,14 +102,14 @@ def test_res_bench_workload_full_depth():
         assert bool(torch.isfinite(e_all.float()).all())
         s = _stats(e_all[3], e_one[0])
         print("SAM ViT-H 32 blocks, image 3 in B=8 vs alone:", json.dumps(s))
-        # batch 8 and batch 1 take the same 256x256 tiles (4096 rows per image) except for stream-K tails; measured x 1.5
-        assert s["max"] <= 0.05 * s["ref_max"] and s["mean"] <= 0.01 * s["ref_std"]
+        # batch 8 and batch 1 take the same 256x256 tiles (4096 rows per image) except for stream-K tails; measured: bit-identical
+        assert s["max"] <= 2.0 ** -7 * s["ref_max"] and s["frac_equal"] >= 0.999
         model.overlap_sam_encoder = False
         o3 = step()
         model.overlap_sam_encoder = True
         sm = _stats(torch.stack(o3["pred_masks"]), torch.stack(o1["pred_masks"]))
         print("RES masks, SAM encoder on the main stream vs on the side stream:", json.dumps(sm))
-        assert sm["max"] <= 0.05 * sm["ref_max"]
+        assert sm["max"] <= 2.0 ** -7 * sm["ref_max"]              # measured: bit-identical
 
 
 RCCL_SCRIPT = r"""

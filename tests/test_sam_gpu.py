@@ -314,18 +314,19 @@ def test_full_forward_fixture_g8():
     assert [m.shape[0] for m in out["pred_masks"]] == [2, 1] and [b.shape[0] for b in out["pred_boxes"]] == [1, 2]   # [SEG]/[LOC] shift
     valid = fx["attention_mask"].bool()
     print("logits err", rel_err(out["logits"].cpu()[valid], fx["logits"][valid]))
-    assert rel_err(out["logits"].cpu()[valid], fx["logits"][valid]) < 0.03
+    # measured 0.0037 = one bf16 ulp at the top of the logit range (an ulp is 2^-8 .. 2^-7 of the value): bound = two such flips
+    assert rel_err(out["logits"].cpu()[valid], fx["logits"][valid]) <= 2.0 ** -7
     emb = model.get_visual_embs(images_sam.to(DEV)).cpu()
     e = rel_err(emb[:, ::16, ::4, ::4], fx["image_embeddings_sample"])
     print("SAM encoder embedding err vs reference", e)
-    assert e < 0.05
+    assert e < 0.0105                       # measured 0.0068 (x 1.5)
     for i in range(2):
         assert out["pred_masks"][i].dtype == torch.float32 and tuple(out["pred_masks"][i].shape) == tuple(fx["pred_mask_shapes"][i])
         em = rel_err(out["pred_masks"][i].cpu()[:, ::8, ::8], fx["pred_mask_samples"][i])
         eb = rel_err(out["pred_boxes"][i], fx["pred_boxes"][i])
         print(f"sample {i}: mask err {em:.4f} box err {eb:.4f}")
         RESULTS.append(dict(test="g8_bf16", sample=i, mask_vs_reference=em, box_vs_reference=eb))
-        assert em < 0.08 and eb < 0.05
+        assert em < 0.018 and eb == 0.0      # measured: masks 0.0106 / 0.0120 (x 1.5), boxes bit-exact
 
 
 def test_evaluate_greedy_tiny():
@@ -471,7 +472,7 @@ def test_sam_encoder_blocks_fixture_g9():
     e = float((got[:, ::2, ::2, ::2].float() - fx["embedding_sample"].float()).abs().max()) / fx["embedding_max"]
     print(f"G9 SAM blocks (d=1280): HIP vs reference fixture {e:.5f}")
     RESULTS.append(dict(test="g9_bf16", hip_vs_reference=e))
-    assert e < 0.03
+    assert e < 0.017                        # measured 0.0112 (x 1.5); the per-stage flip counts above carry the cross-host rule
 
 
 def test_evaluate_fixture_g11():
@@ -491,7 +492,7 @@ def test_evaluate_fixture_g11():
         eb = rel_err(boxes[0], fx["pred_boxes"])
         print(f"evaluate(use_cache={use_cache}): mask err vs reference {em:.4f}, box err {eb:.4f}")
         RESULTS.append(dict(test="g11_evaluate_bf16", use_cache=use_cache, mask_vs_reference=em, box_vs_reference=eb))
-        assert em < 0.08 and eb < 0.05
+        assert em < 0.0155 and eb == 0.0     # measured: masks 0.0103 (x 1.5), boxes bit-exact
 
 
 def test_evaluate_sampling_path_is_seeded_and_valid():
