@@ -69,6 +69,7 @@ def init_random_(model, seed):
 def build_model(image_size, device, seed=0, with_sam=False):
     C = importlib.import_module("u-llava_amd.configuration")
     llm = dict(vision_config=dict(image_size=image_size, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
+               projector_from_scratch=False,            # train_ullava.py:162 (stage 2); forward-identical either way
                mm_token_ids=dict(MM), vocab_size=32011)
     if with_sam:
         M = importlib.import_module("u-llava_amd.modeling_ullava")

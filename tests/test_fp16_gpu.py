@@ -189,7 +189,8 @@ def test_full_forward_fp16_fixture_g8():
     C, M = pkg("configuration"), pkg("modeling_ullava")
     cfg, cd = fx["cfg"], fx["cfg"]["llm"]
     ucfg = C.UllavaConfig(llm_config=dict(vision_config=cd["vision_config"], vision_hidden_layer=cd["vision_hidden_layer"],
-                                          projector_type="mlp", mm_token_ids=cd["mm_token_ids"], vocab_size=cd["vocab_size"],
+                                          projector_type="mlp", projector_from_scratch=bool(cd.get("projector_from_scratch", False)),   # the fixtures' reference model: False
+                                          mm_token_ids=cd["mm_token_ids"], vocab_size=cd["vocab_size"],
                                           hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
                                           num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"]),
                             seg_token_idx=cfg["seg_token_idx"], loc_token_idx=cfg["loc_token_idx"], sam_config=dict(cfg["sam"]))

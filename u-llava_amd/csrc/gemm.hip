@@ -42,6 +42,7 @@ constexpr int EPI_W_TILED = 64, EPI_X_TILED = 128;
 // SAM's TwoWayTransformer, whose `keys` are still the permuted NCHW view: cross_attn_token_to_image.{k,v}_proj and
 // cross_attn_image_to_token.q_proj (transformer.py:92-93,151-182).
 constexpr int EPI_BIAS_ROUNDED = 256;
+constexpr int ULL_W4_FORCE_STAGED = 512;          // tools / tests: the 4-wave kernel's LDS-staged epilogue where the direct one would run
 
 struct GemmArgs {
     const elem_t* X; const elem_t* W; void* C;
@@ -184,7 +185,9 @@ ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_
 // SW2 (SwiGLU, wave tile 128 accumulator columns wide): the two 64-column halves park their 32 outputs side by side in ONE region
 // (sw_half = 0 / 1 picks the side) and a single finish pass stores 64 outputs = whole 128-byte lines per row; finishing the halves
 // separately wrote every output line in two 64-byte pieces at different times (WRITE_SIZE +30 %).  nw0 = the tile's first column.
-template <bool SWIGLU, int JT, bool ROPE = false, int PHASE = 0, bool RAW1 = false, int UNR = 2, bool SW2 = false>
+// PERM (the 4-wave kernel's accumulator <-> column maps, see gemm256w4_kernel): 0 = acc[i][j][r] is column i*16 + 4*fg + r of the wave's 64;
+// 1 = column 32*(i>>1) + 8*fg + 4*(i&1) + r; with SWIGLU, 1 = gate acc[2pp] / up acc[2pp+1] give output 8*fg + 4*pp + r of the half's 32.
+template <bool SWIGLU, int JT, bool ROPE = false, int PHASE = 0, bool RAW1 = false, int UNR = 2, bool SW2 = false, int PERM = 0>
 ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg, int lane, int mrow0, int nw0, const char* reg_partner = nullptr,
                              int sw_half = 0) {
     constexpr int ROWS = JT * 16;
@@ -203,12 +206,13 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
 
     const EpiCtx ectx = epi_ctx(p, SWIGLU);
     auto finish8 = [&](float (&a)[8], int m, int n) { big_finish8(ectx, a, m, n); };
+    auto col_of = [&](int i) { return PERM ? 32 * (i >> 1) + 8 * fg + 4 * (i & 1) : i * 16 + fg * 4; };   // first of the lane's 4 columns
     float bias_v[4][4];                                    // -0.0f: x + (-0.0f) == x bit-for-bit when there is no bias
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = nw0 + i * 16 + fg * 4 + r;
+            const int n = nw0 + col_of(i) + r;
             bias_v[i][r] = (!SWIGLU && (flags & EPI_BIAS) && !bias_late && n < p.N) ? e2f(p.bias[n]) : -0.0f;
         }
 
@@ -235,7 +239,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                     uint2 o;
                     o.x = pack2e(v[0], v[1]);
                     o.y = pack2e(v[2], v[3]);
-                    *(uint2*)(reg + (j * 16 + fr) * PITCH + (SW2 ? sw_half * 64 : 0) + (ip * 16 + fg * 4) * 2) = o;
+                    *(uint2*)(reg + (j * 16 + fr) * PITCH + (SW2 ? sw_half * 64 : 0) + (PERM ? 8 * fg + 4 * ip : ip * 16 + fg * 4) * 2) = o;
                 }
             } else {
 #pragma clang loop unroll(full)
@@ -248,7 +252,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                         o.x = pack2e(acc[i][j][0], acc[i][j][1]);
                         o.y = pack2e(acc[i][j][2], acc[i][j][3]);
                     }
-                    *(uint2*)(reg + (j * 16 + fr) * PITCH + (i * 16 + fg * 4) * 2) = o;
+                    *(uint2*)(reg + (j * 16 + fr) * PITCH + col_of(i) * 2) = o;
                 }
             }
         }
@@ -407,7 +411,7 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                         f32x4_t o = acc[i][h * JH + jj];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] += bias_v[i][r];
-                        *(f32x4_t*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fg * 4) * 4) = o;
+                        *(f32x4_t*)(reg + (jj * 16 + fr) * PITCH + col_of(i) * 4) = o;
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -867,6 +871,170 @@ ULL_DEV void mfma16_inplace(f32x4_t& c, const uint4& a, const uint4& b) {
 }
 
 
+// ---- the 4-wave kernel's W-row permutation and its register-direct epilogue ---------------------------------------------------
+// Which physical W row feeds MFMA row q = 4*a + b (a = q >> 2, b = q & 3) of block i of a 64-row half is a free choice: the MFMA does
+// not care, only the epilogue has to know.  The natural choice (row 16*i + q) leaves a lane with four SCATTERED groups of 4 output
+// columns per token, which is why the epilogue had to go through the LDS to build whole rows (park, barrier-free wait, row loop:
+// 7.8 of the 13.5 us a tile round cost at K = 128, profiles/r02_gemm_epilogue_costs.txt).  With
+//     plain / RoPE:  row = 32*(i>>1) + 8*a + 4*(i&1) + b          SwiGLU ([16 gate | 16 up] packs):  row = 32*(a>>1) + 16*(i&1) + 8*(a&1) + 4*(i>>1) + b
+// a lane (fg = a, r = b) owns 8 CONSECUTIVE output columns per block pair (i>>1) -- columns 32*(i>>1) + 8*fg + 4*(i&1) + r -- resp.
+// gate (i even) and up (i odd) of the 8 consecutive SwiGLU outputs 8*fg + 4*(i>>1) + r: the four lanes of a token write 64 contiguous
+// bytes with one 16-byte store each, straight from the accumulators, and both halves of a RoPE head (columns n and n + 64) sit in the
+// same lane.  No LDS, no barrier: the epilogue is ~130 conversions and 32 stores per wave.
+// The rows a ds_read_b128 fetches are then no longer 16 consecutive ones, so the XOR swizzle of the W tile uses the row bits that
+// vary across the 16 lanes of a fragment read instead of row & 7: s(row) = bit1 | bits 3,4 << 1 (plain), bit1 | bit3 << 1 | bit5 << 2
+// (SwiGLU) -- for the reading lane both are simply fr >> 1, and every 16-lane service group of the read hits 64 distinct banks.
+template <bool SWIGLU> ULL_DEV int w4_row_swizzle(int row) {
+    return SWIGLU ? (((row >> 1) & 1) | (((row >> 3) & 1) << 1) | (((row >> 5) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 3) << 1));
+}
+// physical W row (within the wave's 128) read by fragment c = 4*h + i, minus the lane-dependent part
+template <bool SWIGLU> ULL_DEV constexpr int w4_frag_row(int c) {
+    return SWIGLU ? 64 * (c >> 2) + 16 * (c & 1) + 4 * ((c >> 1) & 1) : 32 * (c >> 1) + 4 * (c & 1);
+}
+template <bool SWIGLU> ULL_DEV int w4_lane_row(int fr) {
+    return SWIGLU ? 32 * (fr >> 3) + 8 * ((fr >> 2) & 1) + (fr & 3) : 8 * (fr >> 2) + (fr & 3);
+}
+// first of the 4 consecutive physical rows (= slab columns of the stream-K tail) that acc[h][i][.][0..3] of lane group fg holds
+template <bool SWIGLU> ULL_DEV int w4_acc_row(int h, int i, int fg) {
+    return SWIGLU ? h * 64 + 32 * (fg >> 1) + 16 * (i & 1) + 8 * (fg & 1) + 4 * (i >> 1) : h * 64 + 32 * (i >> 1) + 8 * fg + 4 * (i & 1);
+}
+
+// Register-direct epilogue of the 4-wave kernel for 16-bit outputs with 16-byte-aligned rows and no activation: plain, + bias,
+// + residual, SwiGLU, RoPE.  Same rounding points as the staged epilogue (bit-identical results: tests/test_kernels_gpu.py forces both
+// kernel forms through every epilogue): rnd(acc + bias); SwiGLU rnd(rnd(silu(rnd(g))) * rnd(u)); residual rnd(res + rnd(.)); RoPE
+// rnd(rnd(x cos) + rnd(-+x' sin)) on x = rnd(acc).
+// The accumulators live in AGPRs (tied operands of the MFMA asm).  Left to the allocator, the epilogue's reads become 16-byte scratch
+// stores of whole AGPR tuples and scratch loads into VGPRs ("folded spills": 168 of the 256 values went through memory); an opaque
+// asm on the copy makes the AGPR -> VGPR move happen HERE, four v_accvgpr_read at the point of use.
+ULL_DEV f32x4_t w4_acc_to_vgpr(const f32x4_t& a) {
+    f32x4_t t = a;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+template <bool SWIGLU, bool ROPE>
+ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int lane, int mrow0, int nw0) {
+    // One group of 16 token rows (j) at a time, fenced by sched_barriers: left to itself the scheduler hoists every accumulator read
+    // and every load of the 8 groups to the top (~250 live registers, spilled around the K-loop).  Loads of group j + 1 (residual rows,
+    // RoPE table rows) are issued before the arithmetic of group j.
+    const int fr = lane & 15, fg = lane >> 4;
+    if constexpr (SWIGLU) {
+        const int n_out = p.N / 2, nb = nw0 / 2 + 8 * fg;
+        elem_t* cb = (elem_t*)p.C + nb;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 8; ++j) {
+            const int m = mrow0 + j * 16 + fr;
+#pragma clang loop unroll(full)
+            for (int h = 0; h < 2; ++h) {
+                float v[8];
+#pragma clang loop unroll(full)
+                for (int pp = 0; pp < 2; ++pp) {
+                    const f32x4_t ag = w4_acc_to_vgpr(acc[h][2 * pp][j]), au = w4_acc_to_vgpr(acc[h][2 * pp + 1][j]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = rnd(ag[r]);                          // gate_proj output (16-bit tensor)
+                        const float u = rnd(au[r]);                          // up_proj output
+                        v[4 * pp + r] = rnd(act_silu(g)) * u;                // silu -> 16 bit, product -> 16 bit (by the pack)
+                    }
+                }
+                if (m < p.M && nb + h * 32 + 8 <= n_out) *(uint4*)(cb + (long)m * p.ldc + h * 32) = pack8(v);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const int flags = p.flags;
+        const bool has_bias = flags & EPI_BIAS, has_res = flags & EPI_RESID;
+        const bool rope_on = ROPE && nw0 < p.rope_cols;          // the wave's 128 columns are one head
+        const int nb = nw0 + 8 * fg;                             // + h*64 + pp*32: the lane's 8 columns
+        uint4 bvp[2][2];                                         // the lane's 32 bias values, packed (unpacked at use: 16 registers held, not 32)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int n = nb + h * 64 + pp * 32;
+                bvp[h][pp] = (has_bias && n + 8 <= p.N) ? *(const uint4*)(p.bias + n) : uint4{0, 0, 0, 0};
+            }
+        elem_t* cb = (elem_t*)p.C + nb;
+        const elem_t* rb = p.R + nb;
+        auto body = [&](auto with_bias, auto with_res) {
+            constexpr bool WB = decltype(with_bias)::value, WR = decltype(with_res)::value;
+            uint4 rv[2][2][2], tc[2][2], ts[2][2];               // [buffer][h][pp] residual rows, [buffer][pp] RoPE table rows
+            auto fetch = [&](int j, int buf) {
+                const long mc = min(mrow0 + j * 16 + fr, p.M - 1);
+                if constexpr (WR) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) rv[buf][h][pp] = *(const uint4*)(rb + mc * p.ldr + h * 64 + pp * 32);   // (columns past N: masked at the store)
+                }
+                if constexpr (ROPE) {
+                    if (rope_on) {
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            tc[buf][pp] = *(const uint4*)(p.rope_cos + mc * 64 + pp * 32 + 8 * fg);
+                            ts[buf][pp] = *(const uint4*)(p.rope_sin + mc * 64 + pp * 32 + 8 * fg);
+                        }
+                    }
+                }
+            };
+            fetch(0, 0);
+#pragma clang loop unroll(full)
+            for (int j = 0; j < 8; ++j) {
+                const int m = mrow0 + j * 16 + fr;
+                if (j + 1 < 8) fetch(j + 1, (j + 1) & 1);
+                uint4 o[2][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        float v[8], bv[8];
+                        if constexpr (WB) unpack8(bvp[h][pp], bv);
+                        const f32x4_t a0 = w4_acc_to_vgpr(acc[h][2 * pp][j]), a1 = w4_acc_to_vgpr(acc[h][2 * pp + 1][j]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = e < 4 ? a0[e & 3] : a1[e & 3];
+                            v[e] = WB ? a + bv[e] : a;
+                        }
+                        o[h][pp] = pack8(v);                                 // the Linear's 16-bit output
+                    }
+                if constexpr (ROPE) {
+                    if (rope_on) {
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            float x0[8], x1[8], cs[8], sn[8];
+                            unpack8(o[0][pp], x0); unpack8(o[1][pp], x1);
+                            unpack8(tc[j & 1][pp], cs); unpack8(ts[j & 1][pp], sn);
+                            float y0[8], y1[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                y0[e] = rnd(x0[e] * cs[e]) + rnd(-x1[e] * sn[e]);   // dims 0..63 of the head: rotate_half contributes -x[d + 64]
+                                y1[e] = rnd(x1[e] * cs[e]) + rnd(x0[e] * sn[e]);
+                            }
+                            o[0][pp] = pack8(y0); o[1][pp] = pack8(y1);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        if constexpr (WR) {
+                            float a[8], b[8];
+                            unpack8(o[h][pp], a); unpack8(rv[j & 1][h][pp], b);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
+                            o[h][pp] = pack8(a);
+                        }
+                        if (m < p.M && nb + h * 64 + pp * 32 + 8 <= p.N) *(uint4*)(cb + (long)m * p.ldc + h * 64 + pp * 32) = o[h][pp];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (has_bias) { if (has_res) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+        else { if (has_res) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+    }
+}
+
 template <bool SWIGLU, bool ROPE = false>
 __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -902,8 +1070,9 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = (wave * 8 + i) * 8 + srow;
+        const int wchunk = (lane & 7) ^ w4_row_swizzle<SWIGLU>(r);          // the W tile's swizzle follows the permuted fragment reads
         xo[i] = x_tiled ? (uint32_t)(r * BK + schunk * 8) * 2 : (uint32_t)(((long)(min(m0 + r, p.M - 1) - m0) * p.ldx + schunk * 8) * 2);
-        wo[i] = w_tiled ? (uint32_t)(r * BK + schunk * 8) * 2 : (uint32_t)(((long)(min(n0 + r, p.N - 1) - n0) * p.ldw + schunk * 8) * 2);
+        wo[i] = w_tiled ? (uint32_t)(r * BK + wchunk * 8) * 2 : (uint32_t)(((long)(min(n0 + r, p.N - 1) - n0) * p.ldw + wchunk * 8) * 2);
     }
     const elem_t* xbase = x_tiled ? p.X + ((long)bm * nk_total) * BM * BK : p.X + (long)m0 * p.ldx;
     const elem_t* wbase = w_tiled ? p.W + ((long)bn * nk_total) * BN * BK : p.W + (long)n0 * p.ldw;
@@ -931,13 +1100,16 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
     int swz[2];
     swz[0] = ((0 + fg) ^ (lane & 7)) << 4;
     swz[1] = ((4 + fg) ^ (lane & 7)) << 4;
+    int wswz[2];                                      // W tile: permuted rows, swizzle = fr >> 1 for the reading lane (see w4_row_swizzle)
+    wswz[0] = ((0 + fg) ^ (fr >> 1)) << 4;
+    wswz[1] = ((4 + fg) ^ (fr >> 1)) << 4;
     const int xoff = (wm * 128 + fr) * (BK * 2);
-    const int woff = OP_BYTES + (wn * 128 + fr) * (BK * 2);
+    const int woff = OP_BYTES + (wn * 128 + w4_lane_row<SWIGLU>(fr)) * (BK * 2);
     // c-th fragment read of a half step: the 8 W fragments first (all of them feed the first two chunks), then X in use order
     auto read_one = [&](int kt, int kk, Frags4& f, int c) {
-        const char* base = smem + (kt & 1) * SLOT_BYTES + swz[kk];
-        if (c < 8) f.w[c] = *(const uint4*)(base + woff + c * 16 * (BK * 2));
-        else f.x[c - 8] = *(const uint4*)(base + xoff + (c - 8) * 16 * (BK * 2));
+        const char* base = smem + (kt & 1) * SLOT_BYTES;
+        if (c < 8) f.w[c] = *(const uint4*)(base + wswz[kk] + woff + w4_frag_row<SWIGLU>(c) * (BK * 2));
+        else f.x[c - 8] = *(const uint4*)(base + swz[kk] + xoff + (c - 8) * 16 * (BK * 2));
     };
 
     f32x4_t acc[2][4][8];                             // [half of the 128 n-columns][i][j]
@@ -1083,7 +1255,7 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
 #if defined(ULL_ABL_NOEPI)
     if (p.M > 0) return;
 #endif
-    // ---- epilogue: acc[h][i][j][r] = D[n = n0 + wn*128 + h*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
+    // ---- epilogue: acc[h][i][j][r] = D[n = n0 + wn*128 + w4_acc_row(h, i, fg) + r][m = m0 + wm*128 + j*16 + fr] (physical W row n) ------
     if (split) {
         float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
 #pragma clang loop unroll(full)
@@ -1092,36 +1264,48 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
             for (int h = 0; h < 2; ++h)
 #pragma clang loop unroll(full)
                 for (int i = 0; i < 4; ++i)
-                    *(f32x4_t*)(slab + (wm * 128 + j * 16 + fr) * BN + wn * 128 + h * 64 + i * 16 + fg * 4) = acc[h][i][j];
+                    *(f32x4_t*)(slab + (wm * 128 + j * 16 + fr) * BN + wn * 128 + w4_acc_row<SWIGLU>(h, i, fg)) = acc[h][i][j];
         return;
+    }
+    const int mrow0 = m0 + wm * 128, nw0 = n0 + wn * 128;
+    {
+        // 16-bit output, 16-byte-aligned rows, whole groups of 8 columns, no activation: straight from the accumulators (wave-uniform test)
+        const int fl = p.flags;
+        const bool direct = ROPE || (!(fl & (EPI_ACT_MASK | EPI_OUT_F32 | EPI_BIAS_ROUNDED)) && (p.ldc & 7) == 0 && ((SWIGLU ? p.N / 2 : p.N) & 7) == 0 &&
+                                     (!(fl & EPI_RESID) || (p.ldr & 7) == 0) && !(fl & ULL_W4_FORCE_STAGED));
+        if (direct) {
+            w4_direct_epilogue<SWIGLU, ROPE>(p, acc, lane, mrow0, nw0);
+            return;
+        }
     }
     __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
     char* reg0 = smem + wave * (2 * 128 * 144);      // 36 KiB per wave: two bf16 regions, or one fp32 region of 128 rows x 272 B
-    char* reg1 = reg0 + 128 * 144;
-    const int mrow0 = m0 + wm * 128, nw0 = n0 + wn * 128;
     // The flag-dependent half of the epilogue (finish) never touches an accumulator, so it is compiled once and run per 64-column half.
+    // (RoPE launches always qualify for the direct form: the entry point insists on aligned rows and whole heads.)
     if constexpr (ROPE) {
-        // the wave owns whole heads (128 columns): park both halves, then rotate each against the other
-        staged_epilogue<SWIGLU, 8, true, 1, true, 4>(p, acc[0], reg0, lane, mrow0, nw0);
-        staged_epilogue<SWIGLU, 8, true, 1, true, 4>(p, acc[1], reg1, lane, mrow0, nw0 + 64);
-#pragma clang loop unroll(disable)
-        for (int h = 0; h < 2; ++h)
-            staged_epilogue<SWIGLU, 8, true, 2, true, 4>(p, acc[0], h ? reg1 : reg0, lane, mrow0, nw0 + 64 * h, h ? reg0 : reg1);
+        return;
+    } else if constexpr (SWIGLU) {
+        staged_epilogue<true, 8, false, 1, true, 4, true, 1>(p, acc[0], reg0, lane, mrow0, nw0, nullptr, 0);
+        staged_epilogue<true, 8, false, 1, true, 4, true, 1>(p, acc[1], reg0, lane, mrow0, nw0, nullptr, 1);
+        staged_epilogue<true, 8, false, 2, true, 4, true, 1>(p, acc[0], reg0, lane, mrow0, nw0);
     } else {
-        if constexpr (SWIGLU) {
-            staged_epilogue<true, 8, false, 1, true, 4, true>(p, acc[0], reg0, lane, mrow0, nw0, nullptr, 0);
-            staged_epilogue<true, 8, false, 1, true, 4, true>(p, acc[1], reg0, lane, mrow0, nw0, nullptr, 1);
-            staged_epilogue<true, 8, false, 2, true, 4, true>(p, acc[0], reg0, lane, mrow0, nw0);
-        } else {
 #pragma clang loop unroll(disable)
-            for (int h = 0; h < 2; ++h) {
-                if (h == 0) staged_epilogue<false, 8, false, 1, true, 4>(p, acc[0], reg0, lane, mrow0, nw0);
-                else staged_epilogue<false, 8, false, 1, true, 4>(p, acc[1], reg0, lane, mrow0, nw0 + 64);
-                staged_epilogue<false, 8, false, 2, true, 4>(p, acc[0], reg0, lane, mrow0, nw0 + 64 * h);
-            }
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0) staged_epilogue<false, 8, false, 1, true, 4, false, 1>(p, acc[0], reg0, lane, mrow0, nw0);
+            else staged_epilogue<false, 8, false, 1, true, 4, false, 1>(p, acc[1], reg0, lane, mrow0, nw0 + 64);
+            staged_epilogue<false, 8, false, 2, true, 4, false, 1>(p, acc[0], reg0, lane, mrow0, nw0 + 64 * h);
         }
     }
 }
+
+// (Round 3 built the persistent form a third time, now on top of the register-direct epilogue -- one workgroup per CU chaining its
+// items into one K-step stream, the last two steps of an item prefetching K-tiles 0 / 1 of the next, the epilogue's stores left in
+// flight under the next item's first step; no LDS juggling, no extra barrier, zero spills, bit-identical results.  Measured against
+// the one-tile-per-block launch of the SAME kernel body on the same box (tools/gemm_shapes.py, profiles/r03_gemm_notes.md): qkv+RoPE
+// 1519 vs 1461 us, gate/up+SwiGLU 2568 vs 2538, o+residual 524 vs 518, down 1294 vs 1271, K = 1280 shapes equal: 1-4 % SLOWER again.
+// 256 accumulator clears, the re-read of the first fragments and the item decode cost what the hidden prologue saves, and the wait
+// for the epilogue's stores moves to barrier B of the next item's first step instead of disappearing.  Removed; the block hand-over
+// of the hardware stays.)
 
 // (A v_mfma_f32_32x32x16_bf16 variant of this kernel measured 6-11 % slower in this structure and was removed;
 // numbers in profiles/r01_gemm_notes.md.)
@@ -1303,8 +1487,18 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
         // ahead at K >= 4096: tools/gemm_smallm.py).  It addresses its DMA pieces with
         // 32-bit offsets from the tile's first row.
         // (An output whose rows are not 16-byte aligned -- lm_head, V = 32011 -- is stored element by element: latency again, 8 waves.)
+        // Which form: the 4-wave kernel whenever its epilogue is register-direct (16-bit output, 16-byte-aligned rows, whole groups of 8
+        // columns, no activation: same test as in the kernel) -- it has the faster K-loop and, since round 3, the cheaper turn-around too
+        // (tools/gemm_shapes.py: +4.5-7 % on the LLaMA layer, +3-13 % on the K = 1024 / 1280 ViT shapes over the 8-wave form).  With an
+        // activation, an fp32 output or unaligned rows (lm_head, V = 32011: element-wise stores) the epilogue goes through the LDS and one
+        // wave per SIMD hides none of its latencies: those keep the 8-wave form below K = 3072.  The 4-wave kernel addresses its DMA
+        // pieces with 32-bit offsets from the tile's first row.
         const bool c_rows_aligned = (flags & EPI_OUT_F32) ? (ldc & 3) == 0 : (ldc & 7) == 0;
-        const bool waves4 = force_waves4 || (!force_waves8 && K >= 3072 && c_rows_aligned && ldx < (1 << 21) && ldw < (1 << 21));
+        const int n_out_cols = (flags & EPI_SWIGLU) ? (int)(N / 2) : (int)N;
+        const bool direct = rope || (!(flags & (EPI_ACT_MASK | EPI_OUT_F32 | EPI_BIAS_ROUNDED | ULL_W4_FORCE_STAGED)) && (ldc & 7) == 0 &&
+                                     (n_out_cols & 7) == 0 && (!(flags & EPI_RESID) || (ldr & 7) == 0));
+        const bool fits32 = ldx < (1 << 21) && ldw < (1 << 21);
+        const bool waves4 = force_waves4 || (!force_waves8 && fits32 && (direct || (K >= 3072 && c_rows_aligned)));
         if (waves4) {
             if (flags & EPI_SWIGLU)
                 hipLaunchKernelGGL(big::gemm256w4_kernel<true>, dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
