@@ -163,6 +163,8 @@ def gemm_roofline(cfg, tokens, device, iters=40, warm=10):
                 traffic = tj["traffic_bytes_per_launch"]
                 detail = {"record": "profiles/" + fn, "kernel": tj["kernel"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
                           "l2_hit_rate": tj.get("l2", {}).get("hit_rate"), "note": tj["note"],
+                          "fabric_read_floor_model_bytes": tj.get("fabric_read_floor_model_bytes"), "ea_request_counters": tj.get("ea"),
+                          "hbm_bytes_bounds": tj.get("hbm_bytes_bounds"),
                           "mfma_pipe_busy_fraction": tj.get("mfma", {}).get("mfma_pipe_busy_fraction_of_simd_cycles")}
             else:
                 detail = {"record": "profiles/" + fn, "stale": True,

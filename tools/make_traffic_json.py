@@ -20,6 +20,7 @@ h = hashlib.sha256()
 for n in ("gemm.hip", "ull_common.h"):
     h.update(open(os.path.join(ROOT, "u-llava_amd", "csrc", n), "rb").read())
 f, w, l2, b, m = means("pmc_fetch"), means("pmc_write"), means("pmc_l2"), means("pmc_busy"), means("pmc_mfma")
+ea, eaw = means("pmc_ea"), means("pmc_eaw")
 M, N, K = 20576, 22016, 4096
 alg = M * K * 2 + N * K * 2 + M * (N // 2) * 2
 fetch_kb, write_kb = f.get("FETCH_SIZE", 0.0), w.get("WRITE_SIZE", 0.0)
@@ -36,5 +37,16 @@ rec = {"kernel": "big::gemm256w4_kernel<true> (gate/up + SwiGLU, M=20576 N=22016
                 "GRBM_GUI_ACTIVE_all_xcds": m.get("GRBM_GUI_ACTIVE"),
                 "mfma_pipe_busy_fraction_of_simd_cycles": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 256 * 4))
                 if m.get("GRBM_GUI_ACTIVE") and m.get("SQ_VALU_MFMA_BUSY_CYCLES") else None},
-       "source": "tools/prof_r02.sh (separate rocprofv3 --pmc passes on tools/gemm_one.py 20576 22016 4096 sw)"}
+       # memory-side (EA) request counters: every read leaves the L2 as a 128-byte request to the DRAM address space; none of them can tell an
+       # Infinity-Cache hit from an HBM access (rocprofv3 -L on gfx950 / ROCm 7.2 lists no DF / UMC block: profiles/r03_counter_list_memory.txt)
+       "ea": {"TCC_EA0_RDREQ": ea.get("TCC_EA0_RDREQ_sum"), "TCC_EA0_RDREQ_DRAM": ea.get("TCC_EA0_RDREQ_DRAM_sum"), "TCC_EA0_RDREQ_128B": ea.get("TCC_EA0_RDREQ_128B_sum"),
+              "read_bytes_128B_requests": (ea.get("TCC_EA0_RDREQ_128B_sum") or 0) * 128, "TCC_EA0_WRREQ": eaw.get("TCC_EA0_WRREQ_sum"),
+              "TCC_EA0_WRREQ_64B": eaw.get("TCC_EA0_WRREQ_64B_sum"), "write_bytes_64B_requests": (eaw.get("TCC_EA0_WRREQ_64B_sum") or 0) * 64},
+       # what the tile geometry alone predicts for the L2 -> fabric reads: an XCD's 32 CUs hold a 4 x 8 patch of 256x256 tiles that walk K
+       # together, so a K-step needs 12 distinct 32-KiB panels for 64 panel loads: miss fraction 12 / 64 of T tiles x 2 x 256 x K x 2 B
+       "fabric_read_floor_model_bytes": 12.0 / 64.0 * ((M + 255) // 256) * ((N + 255) // 256) * 2 * 256 * K * 2,
+       "hbm_bytes_bounds": {"lower_compulsory": alg, "upper_all_fabric_traffic": fetch_kb * 1024 * 2 + write_kb * 1024,
+                            "note": "no post-Infinity-Cache counter exists here; tools/mall_probe.py (profiles/r03_mall_probe.txt) shows re-read working sets "
+                                    "up to 256 MiB served above HBM rate, and the GEMM re-reads each 2-MiB operand panel from all 8 XCDs within one round of tiles"},
+       "source": "tools/prof_r03.sh (separate rocprofv3 --pmc passes on tools/gemm_one.py 20576 22016 4096 sw)"}
 print(json.dumps(rec, indent=1))

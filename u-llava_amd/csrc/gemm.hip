@@ -956,8 +956,9 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
             }
         elem_t* cb = (elem_t*)p.C + nb;
         const elem_t* rb = p.R + nb;
-        auto body = [&](auto with_bias, auto with_res) {
+        auto body = [&](auto with_bias, auto with_res, auto act_kind) {
             constexpr bool WB = decltype(with_bias)::value, WR = decltype(with_res)::value;
+            constexpr int ACT = decltype(act_kind)::value;       // 0 none, 1 QuickGELU, 2 GELU(erf), 3 ReLU: on the rounded Linear output
             uint4 rv[2][2][2], tc[2][2], ts[2][2];               // [buffer][h][pp] residual rows, [buffer][pp] RoPE table rows
             auto fetch = [&](int j, int buf) {
                 const long mc = min(mrow0 + j * 16 + fr, p.M - 1);
@@ -996,6 +997,21 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
                             v[e] = WB ? a + bv[e] : a;
                         }
                         o[h][pp] = pack8(v);                                 // the Linear's 16-bit output
+                        if constexpr (ACT != 0) {
+                            float a[8];
+                            unpack8(o[h][pp], a);
+                            if constexpr (ACT == 2) {
+#pragma unroll
+                                for (int e = 0; e < 8; e += 2) {
+                                    const f32x2_t r = act_gelu_erf2(f32x2_t{a[e], a[e + 1]});
+                                    a[e] = r.x; a[e + 1] = r.y;              // (pack8 rounds)
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) a[e] = ACT == 1 ? act_quick_gelu_e(a[e]) : fmaxf(a[e], 0.f);
+                            }
+                            o[h][pp] = pack8(a);
+                        }
                     }
                 if constexpr (ROPE) {
                     if (rope_on) {
@@ -1030,8 +1046,18 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (has_bias) { if (has_res) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
-        else { if (has_res) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+        using I0 = std::integral_constant<int, 0>;
+        const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+        if constexpr (!ROPE) {
+            if (act) {                                           // (no Linear on the path has an activation AND a residual: host dispatch)
+                if (act == 1) { if (has_bias) body(std::true_type{}, std::false_type{}, std::integral_constant<int, 1>{}); else body(std::false_type{}, std::false_type{}, std::integral_constant<int, 1>{}); }
+                else if (act == 2) { if (has_bias) body(std::true_type{}, std::false_type{}, std::integral_constant<int, 2>{}); else body(std::false_type{}, std::false_type{}, std::integral_constant<int, 2>{}); }
+                else { if (has_bias) body(std::true_type{}, std::false_type{}, std::integral_constant<int, 3>{}); else body(std::false_type{}, std::false_type{}, std::integral_constant<int, 3>{}); }
+                return;
+            }
+        }
+        if (has_bias) { if (has_res) body(std::true_type{}, std::true_type{}, I0{}); else body(std::true_type{}, std::false_type{}, I0{}); }
+        else { if (has_res) body(std::false_type{}, std::true_type{}, I0{}); else body(std::false_type{}, std::false_type{}, I0{}); }
     }
 }
 
@@ -1271,8 +1297,8 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
     {
         // 16-bit output, 16-byte-aligned rows, whole groups of 8 columns, no activation: straight from the accumulators (wave-uniform test)
         const int fl = p.flags;
-        const bool direct = ROPE || (!(fl & (EPI_ACT_MASK | EPI_OUT_F32 | EPI_BIAS_ROUNDED)) && (p.ldc & 7) == 0 && ((SWIGLU ? p.N / 2 : p.N) & 7) == 0 &&
-                                     (!(fl & EPI_RESID) || (p.ldr & 7) == 0) && !(fl & ULL_W4_FORCE_STAGED));
+        const bool direct = ROPE || (!(fl & (EPI_OUT_F32 | EPI_BIAS_ROUNDED)) && (!(fl & EPI_ACT_MASK) || !(fl & EPI_RESID)) && (p.ldc & 7) == 0 &&
+                                     ((SWIGLU ? p.N / 2 : p.N) & 7) == 0 && (!(fl & EPI_RESID) || (p.ldr & 7) == 0) && !(fl & ULL_W4_FORCE_STAGED));
         if (direct) {
             w4_direct_epilogue<SWIGLU, ROPE>(p, acc, lane, mrow0, nw0);
             return;
@@ -1495,8 +1521,8 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
         // pieces with 32-bit offsets from the tile's first row.
         const bool c_rows_aligned = (flags & EPI_OUT_F32) ? (ldc & 3) == 0 : (ldc & 7) == 0;
         const int n_out_cols = (flags & EPI_SWIGLU) ? (int)(N / 2) : (int)N;
-        const bool direct = rope || (!(flags & (EPI_ACT_MASK | EPI_OUT_F32 | EPI_BIAS_ROUNDED | ULL_W4_FORCE_STAGED)) && (ldc & 7) == 0 &&
-                                     (n_out_cols & 7) == 0 && (!(flags & EPI_RESID) || (ldr & 7) == 0));
+        const bool direct = rope || (!(flags & (EPI_OUT_F32 | EPI_BIAS_ROUNDED | ULL_W4_FORCE_STAGED)) && (!(flags & EPI_ACT_MASK) || !(flags & EPI_RESID)) &&
+                                     (ldc & 7) == 0 && (n_out_cols & 7) == 0 && (!(flags & EPI_RESID) || (ldr & 7) == 0));
         const bool fits32 = ldx < (1 << 21) && ldw < (1 << 21);
         const bool waves4 = force_waves4 || (!force_waves8 && fits32 && (direct || (K >= 3072 && c_rows_aligned)));
         if (waves4) {
