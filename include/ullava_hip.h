@@ -153,6 +153,13 @@ int ull_im2col_bf16(const void* img, void* out, int64_t n_img, int64_t C, int64_
 int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_start, int64_t img_end, int64_t vid_start, int64_t vid_end,
                  int64_t vocab, void* spans, void* stream);
 
+/* One greedy decoding step of HF `generate` (the method the reference's models inherit: models/ullava.py:350-361) for the whole batch:
+ * next = argmax(logits[b, 0..V)) with the first index on ties (torch.argmax); rows whose unfinished[b] == 0 get `pad` instead when
+ * has_pad; seq[b*seq_ld + pos] = token (int64); a live row that emitted one of the n_eos ids in `eos` (int64, device) becomes finished;
+ * alive[0] (int32, caller-zeroed) += number of rows still unfinished.  logits: 16-bit, rows row_stride elements apart. */
+int ull_greedy_step_bf16(const void* logits, int64_t row_stride, int64_t B, int64_t V, void* unfinished, const void* eos, int64_t n_eos,
+                         int64_t pad, int has_pad, void* seq, int64_t seq_ld, int64_t pos, void* alive, void* stream);
+
 /* models/ullava_core.py:191,243-245,266-268: token-embedding lookup with the projected visual tokens spliced in after
  * the first start token (the torch.cat of the reference, done as one gather).  Image i's n_img_tok feature rows start
  * at row i*img_pitch + img_off of img_feat (pitch = patches + 1, off = 1 skips the CLS row without a copy).
@@ -400,6 +407,7 @@ int ull_rope_inplace_f16(void* x, int64_t row_stride, const void* positions, con
 int ull_rope_append_f16(void* qkv, int64_t row_stride, const void* positions, const void* inv_freq, int64_t B, int64_t S, int64_t H, int64_t hd, void* k_cache, void* vt_cache, int64_t smax, int64_t past, void* stream);
 int ull_transpose_v_f16(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch, void* stream);
 int ull_im2col_f16(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp, void* stream);
+int ull_greedy_step_f16(const void* logits, int64_t row_stride, int64_t B, int64_t V, void* unfinished, const void* eos, int64_t n_eos, int64_t pad, int has_pad, void* seq, int64_t seq_ld, int64_t pos, void* alive, void* stream);
 int ull_embed_splice_f16(const void* ids, const void* table, const void* img_feat, int64_t n_img_tok, int64_t img_pitch, int64_t img_off, const void* vid_feat, int64_t n_vid_tok, const void* spans, void* out, int64_t B, int64_t S, int64_t D, int64_t vocab, void* stream);
 int ull_video_pool_f16(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch, int64_t tok_off, void* stream);
 int ull_gather_rows_f16(const void* src, int64_t lds, const void* idx, void* dst, int64_t ldd, int64_t n, int64_t D, void* stream);

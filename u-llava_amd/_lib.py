@@ -62,6 +62,7 @@ SIGNATURES = {
     "ull_interp_rows_linear_bf16": [_ptr, _ptr, _i64, _i64, _i64, _ptr],
     "ull_im2col_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_mm_spans": [_ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
+    "ull_greedy_step_bf16": [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _i32, _ptr, _i64, _i64, _ptr, _ptr],
     "ull_embed_splice_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
     "ull_video_pool_bf16": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "ull_gather_rows_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],

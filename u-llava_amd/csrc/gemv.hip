@@ -14,6 +14,16 @@ constexpr int EPI_BIAS = 1, EPI_ACT_SHIFT = 1, EPI_ACT_MASK = 3 << 1, EPI_RESID 
 constexpr int EPI_BIAS_ROUNDED = 256;     // bias added to the already rounded product (at::linear's unfused matmul + add_ path)
 constexpr int MAXM = 4;
 
+typedef uint32_t gv_u32x4_t __attribute__((ext_vector_type(4)));
+// The weight stream is read exactly once per token, by exactly one CU: non-temporal loads (global_load_dwordx4 ... nt; MI355X_MICROARCH.md
+// "nt-weights") keep it from evicting X and the KV cache from the L2.  Measured (tools/gemv_bw.py, tools/decode_bench.py): 1-GB stream
+// 5.82 -> 6.29 TB/s, decode step 3.77 -> 3.61 ms.  (Software-pipelining the batches of a wave across output rows was also tried: 168
+// registers, 3 waves per SIMD instead of 4, 3.85 TB/s on the q|k|v shape against 4.9 -- not shipped.)
+ULL_DEV uint4 w_load16(const elem_t* p) {
+    const gv_u32x4_t v = __builtin_nontemporal_load((const gv_u32x4_t*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 constexpr int XS_MAX_BYTES = 32 * 1024;     // X (optionally RMS-normalised) is staged in LDS when M * K * 2 fits in this
 
 // X staged in LDS (`staged`): every block first copies -- or, with norm_w, RMS-normalises (transformers LlamaRMSNorm:
@@ -90,8 +100,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const elem_t* __restrict__ X,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int c = c0 + 64 * u;
-                wq[u] = c < nchunk ? *(const uint4*)(w0 + c * 8) : make_uint4(0, 0, 0, 0);
-                if (swiglu) uq[u] = c < nchunk ? *(const uint4*)(w1 + c * 8) : make_uint4(0, 0, 0, 0);
+                wq[u] = c < nchunk ? w_load16(w0 + c * 8) : make_uint4(0, 0, 0, 0);
+                if (swiglu) uq[u] = c < nchunk ? w_load16(w1 + c * 8) : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -200,6 +200,62 @@ extern "C" int ULL_FN(ull_im2col_)(const void* img, void* out, int64_t n_img, in
     return ull_check_launch();
 }
 
+
+namespace {
+// ---- one greedy decoding step's bookkeeping (HF GenerationMixin greedy search: argmax, pad fill of finished rows, EOS tracking, append) ----
+// reference: the `generate` the models inherit (models/ullava.py:350-361, inference_ullava_core.py:73-80).  One block per batch row:
+// next = argmax(logits[b]) (first index on ties, as torch.argmax); finished rows get `pad` instead; the token is written to
+// seq[b][pos]; a row that just emitted one of the EOS ids becomes finished; alive[0] += rows still unfinished (the host reads it every
+// few steps instead of synchronising on every token).  Was: argmax, where, cat, isin, bitwise-not, and, any -- seven launches and a
+// device -> host read per token.
+__global__ __launch_bounds__(256) void greedy_step_kernel(const elem_t* __restrict__ logits, long row_stride, int V, int32_t* __restrict__ unfinished,
+                                                          const int64_t* __restrict__ eos, int n_eos, long pad, int has_pad,
+                                                          int64_t* __restrict__ seq, long seq_ld, int pos, int32_t* __restrict__ alive) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int b = blockIdx.x;
+    const elem_t* row = logits + (long)b * row_stride;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int c = threadIdx.x; c < V; c += 256) {
+        const float v = e2f(row[c]);
+        if (v > best || (v == best && c < idx)) { best = v; idx = c; }
+    }
+    if (idx == 0x7fffffff) idx = threadIdx.x < V ? threadIdx.x : 0;   // a row of NaNs: any valid index (torch returns the first NaN)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        int live = unfinished[b];
+        long tok = idx;
+        if (!live && has_pad) tok = pad;
+        seq[(long)b * seq_ld + pos] = tok;
+        if (live) {
+            for (int e = 0; e < n_eos; ++e)
+                if (eos[e] == tok) live = 0;
+            unfinished[b] = live;
+        }
+        if (live) atomicAdd(alive, 1);
+    }
+}
+
+}  // namespace
+
+extern "C" int ULL_FN(ull_greedy_step_)(const void* logits, int64_t row_stride, int64_t B, int64_t V, void* unfinished, const void* eos, int64_t n_eos,
+                                    int64_t pad, int has_pad, void* seq, int64_t seq_ld, int64_t pos, void* alive, void* stream) {
+    if (!logits || !unfinished || !seq || !alive || B <= 0 || V <= 0 || pos < 0 || pos >= seq_ld || (n_eos > 0 && !eos)) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(greedy_step_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, (const elem_t*)logits, (long)row_stride, (int)V,
+                       (int32_t*)unfinished, (const int64_t*)eos, (int)n_eos, (long)pad, has_pad, (int64_t*)seq, (long)seq_ld, (int)pos, (int32_t*)alive);
+    return ull_check_launch();
+}
+
 #ifndef ULL_ELEM_F16      // integer work: exists once (bf16 build of this file)
 extern "C" int ull_mm_spans(const void* ids, int64_t B, int64_t S, int64_t img_start, int64_t img_end, int64_t vid_start, int64_t vid_end,
                             int64_t vocab, void* spans, void* stream) {

@@ -782,7 +782,6 @@ class UllavaCoreForCausalLM(nn.Module):
         pad = pad_token_id if pad_token_id is not None else getattr(self.config, "pad_token_id", None)
         if pad is None and eos_ids is not None:
             pad = int(eos_ids[0])
-        unfinished = torch.ones(B, dtype=torch.bool, device=seq.device)
         steps_hidden = []
         cache = None
         self._cache_headroom = max_new_tokens + 1
@@ -790,7 +789,27 @@ class UllavaCoreForCausalLM(nn.Module):
         # are the same (position_ids = cumsum(ones) - 1 = arange; every key attended) and the attention kernels skip their per-key
         # mask loads, which sit on the latency chain of every decode step.
         no_pad = attention_mask is None or bool(attention_mask.ne(0).all())
+        sampling = bool(do_sample and temperature and temperature > 0)
+        crit = [] if stopping_criteria is None else (list(stopping_criteria) if isinstance(stopping_criteria, (list, tuple)) else [stopping_criteria])
+        # Greedy decoding keeps the whole step on the device: the tokens land in a pre-sized [B, L0 + max_new_tokens] buffer, the
+        # argmax / pad-fill / EOS bookkeeping is ONE kernel (ops.greedy_step), and the host looks at the "rows still unfinished"
+        # counters only every CHECK steps (every step when a stopping criterion needs the ids on the host anyway).  Steps that run past
+        # the point where every row had finished only produce pad tokens; the result is trimmed to what a per-step check returns.
+        fused = not sampling and ngram == 0 and seq.is_cuda
+        L0 = seq.shape[1]
+        CHECK = 1 if crit else 8
+        if fused:
+            buf = torch.empty(B, L0 + max_new_tokens, dtype=torch.int64, device=seq.device)
+            buf[:, :L0] = seq
+            live = torch.ones(B, dtype=torch.int32, device=seq.device)
+            alive = torch.zeros(max_new_tokens, dtype=torch.int32, device=seq.device)
+        else:
+            unfinished = torch.ones(B, dtype=torch.bool, device=seq.device)
+        n_done = 0                                              # tokens appended so far
+        stop_at = None                                          # fused: number of tokens after which every row had finished
         for step in range(max_new_tokens):
+            if fused:
+                seq = buf[:, :L0 + step]
             mask = None if no_pad else torch.cat(
                 [attention_mask, attention_mask.new_ones(B, seq.shape[1] - attention_mask.shape[1])], dim=1)
             inputs = self.prepare_inputs_for_generation(input_ids=seq, attention_mask=mask, images=images, videos=videos,
@@ -809,6 +828,19 @@ class UllavaCoreForCausalLM(nn.Module):
                         steps_hidden = [out.hidden_states]      # evaluate() only reads hidden_states[-1] (the last step)
                     else:
                         steps_hidden.append(out.hidden_states)
+            if fused:
+                ops.greedy_step(out.logits[:, -1], live, eos_ids, pad, buf, L0 + step, alive[step:step + 1])
+                n_done = step + 1
+                if crit:
+                    if any(bool(torch.as_tensor(c(buf[:, :L0 + n_done], None)).all()) for c in crit):
+                        break
+                if eos_ids is not None and (n_done % CHECK == 0 or n_done == max_new_tokens):
+                    a_host = alive[:n_done].cpu()               # the only device -> host read: every CHECK steps
+                    dead = (a_host == 0).nonzero()
+                    if dead.numel():
+                        stop_at = int(dead[0]) + 1
+                        break
+                continue
             logits = out.logits[:, -1].float()
             if ngram > 0:
                 # HF NoRepeatNGramLogitsProcessor (logits processors run before the sampling warpers): tokens that would complete an
@@ -816,7 +848,7 @@ class UllavaCoreForCausalLM(nn.Module):
                 for b_, banned in enumerate(no_repeat_ngram_banned_tokens(seq.tolist(), ngram)):
                     if banned:
                         logits[b_, torch.as_tensor(banned, device=logits.device)] = float("-inf")
-            if do_sample and temperature and temperature > 0:
+            if sampling:
                 probs = torch.softmax(logits / temperature, dim=-1)
                 if top_p is not None and top_p < 1.0:
                     sp, si = probs.sort(dim=-1, descending=True)
@@ -834,10 +866,22 @@ class UllavaCoreForCausalLM(nn.Module):
                 unfinished = unfinished & ~torch.isin(nxt.squeeze(1), eos_ids)
                 if not bool(unfinished.any()):
                     break
-            if stopping_criteria is not None:
-                crit = stopping_criteria if isinstance(stopping_criteria, (list, tuple)) else [stopping_criteria]
+            if crit:
                 if any(bool(torch.as_tensor(c(seq, None)).all()) for c in crit):
                     break
+        if fused:
+            n_tok = n_done if stop_at is None else stop_at
+            seq = buf[:, :L0 + n_tok].contiguous()
+            if stop_at is not None and stop_at < n_done:
+                # steps that ran after every row had finished (at most CHECK - 1): drop their states so that the outputs equal a per-step check's
+                if cache is not None:
+                    del cache.last_hidden[n_tok:]
+                    cache.length = L0 + n_tok - 1
+                if steps_hidden and not keep_last_step_only:
+                    del steps_hidden[n_tok:]
+                elif steps_hidden and keep_last_step_only and not use_cache:
+                    # the kept step saw L0 + n_done - 1 positions; the reference's last step L0 + n_tok - 1
+                    steps_hidden = [tuple(h[:, :L0 + n_tok - 1] for h in steps_hidden[0])]
         if output_hidden_states and use_cache and cache is not None:
             # same tensor the no-cache path returns at its last step: last-layer states of ALL positions fed so far, joined once
             steps_hidden = [(torch.cat(cache.last_hidden, dim=1),)]

@@ -476,6 +476,22 @@ def embed_splice(ids: torch.Tensor, table: torch.Tensor, img_feat: Optional[torc
     return out
 
 
+def greedy_step(logits_last: torch.Tensor, unfinished: torch.Tensor, eos_ids: Optional[torch.Tensor], pad: Optional[int], seq: torch.Tensor,
+                pos: int, alive: torch.Tensor) -> None:
+    """One greedy step's bookkeeping in one launch (see ull_greedy_step_*): logits_last [B, V] (rows may be strided), unfinished int32 [B]
+    (updated), eos_ids int64 [n] or None, seq int64 [B, L] (column `pos` written), alive int32 [1] (+= rows still unfinished)."""
+    _chk(logits_last, "logits"); _chk(unfinished, "unfinished", torch.int32); _chk(seq, "seq", torch.int64); _chk(alive, "alive", torch.int32)
+    B, V = logits_last.shape
+    if seq.stride(1) != 1 or not unfinished.is_contiguous():
+        raise RuntimeError("u-llava_amd.greedy_step: seq rows / unfinished must be contiguous")
+    n_eos = 0
+    if eos_ids is not None:
+        _chk(eos_ids, "eos_ids", torch.int64)
+        n_eos = eos_ids.numel()
+    _lib.call("ull_greedy_step_" + _SFX[logits_last.dtype], _p(logits_last), logits_last.stride(0), B, V, _p(unfinished), _p(eos_ids), n_eos,
+              int(pad) if pad is not None else 0, int(pad is not None), _p(seq), seq.stride(0), int(pos), _p(alive), _stream())
+
+
 def video_pool(f: torch.Tensor, B: int, T: int, N: int, tok_pitch: Optional[int] = None, tok_off: int = 0) -> torch.Tensor:
     """f [B*T, tok_pitch, D]; patches are tokens tok_off..tok_off+N of every frame."""
     _chk(f, "f")
