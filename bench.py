@@ -38,7 +38,10 @@ WORKLOADS = {
     "res": (224, 120, 8, "C3: full RES forward (ViT-L/14-224 + LLaMA-7B + SAM ViT-H 1024x1024 + MaskDecoder, 3 [SEG]/[LOC] per image), batch 8"),
     "c5": (224, 32, 8, "C5: video forward, 8-frame 224x224 clips (per-frame ViT-L, 8+256 pooled tokens) + 32-token prompt (S=299), 8 clips/GPU"),
     # forward with labels + loss.backward() + gradient exchange, the reference's stage-2 trainable set (train_ullava.py:229-261)
-    "train": (224, 64, 8, "F4: training step, ViT-L/14-224 + LLaMA-7B (S=323), trainable lm_head + embed_tokens + projector + q/v projections, batch 8/GPU"),
+    # forward with labels + loss.backward() + gradient exchange at the reference's stage-2 settings; --train-config picks
+    # full (train_ullava.py:239-245, configs/train/ullava.yaml: every llm.model / lm_head / projector weight trainable, 16 samples per GPU),
+    # lora (configs/train/ullava_lora.yaml: r = 8 adapters on q_proj / v_proj + lm_head + embed_tokens, 32 per GPU) or qv (round 2's set)
+    "train": (224, 64, 16, "F4: training step (forward + backward + gradient exchange), ViT-L/14-224 + LLaMA-7B (S=323)"),
 }
 PEAK_BF16_TFLOPS = 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 SEG, LOC = 32007, 32008
@@ -425,9 +428,14 @@ def timed_steps(step, steps, warmup, dist, batch, device):
     return D.global_rate(float(batch * steps), elapsed, device=device)        # (images/s whole job, images, max elapsed)
 
 
-def workload_step(name, dev, rank, batch_override=None):
+TRAIN_CONFIGS = {"full": 16, "lora": 32, "qv": 8}          # per-GPU batch (configs/train/ullava.yaml:148, ullava_lora.yaml:148)
+
+
+def workload_step(name, dev, rank, batch_override=None, train_config="full"):
     """Build model + inputs of a workload; returns (step callable, per-GPU batch, S, cfg, description, flops per image)."""
     image_size, prompt, batch, desc = WORKLOADS[name]
+    if name == "train":
+        batch = TRAIN_CONFIGS[train_config]
     batch = batch_override or batch
     res, video = name == "res", name == "c5"
     model, cfg = build_model(image_size, dev, seed=rank, with_sam=res)
@@ -453,19 +461,21 @@ def workload_step(name, dev, rank, batch_override=None):
         labels = ids.clone()
         labels[:, :P + 3] = -100
         trainable = []
-        lora_r = int(os.environ.get("ULL_BENCH_LORA_R", "0"))       # > 0: configs/train/ullava_lora.yaml (r = 8 adapters on q_proj, v_proj)
-        if lora_r > 0:
-            model.add_lora(lora_r, 16.0, 0.05, ("q_proj", "v_proj"))
+        if train_config == "lora":                               # train_ullava.py:217-237 + :248-261
+            model.add_lora(8, 16.0, 0.05, ("q_proj", "v_proj"))
             model.train()
         for n, p_ in model.named_parameters():
-            if lora_r > 0:
-                p_.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or n.startswith("vision_projector") or ".lora_" in n)
+            if train_config == "lora":
+                p_.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or ".lora_" in n)
+            elif train_config == "full":                         # train_ullava.py:239-245: llm.model, lm_head, vision_projector
+                p_.requires_grad = n.startswith("model.") or n.startswith("lm_head") or n.startswith("vision_projector")
             else:
                 p_.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or n.startswith("vision_projector") or
                                     (n.startswith("model.") and (".q_proj." in n or ".v_proj." in n)))
             if p_.requires_grad:
                 trainable.append(p_)
-        flops_img *= 3                                           # forward + ~2x backward (dW only for the trainable set: an upper bound)
+        desc += f", --train-config {train_config} ({sum(p_.numel() for p_ in trainable) / 1e9:.2f} G trainable parameters), batch {batch}/GPU"
+        flops_img *= 3 if train_config == "full" else 2.0        # forward + dX (+ dW for every Linear with the full set)
 
         def step():
             for p_ in trainable:
@@ -511,6 +521,7 @@ def main():
     ap.add_argument("--init-pg", action="store_true", help="initialise the process group (RCCL) even at --gpus 1, so that the barrier and the "
                     "two scalar all-reduces of the aggregation run through RCCL on a single-GPU box")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to CPU sets")
+    ap.add_argument("--train-config", default="full", choices=sorted(TRAIN_CONFIGS), help="--workload train: which trainable set / batch")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -564,7 +575,7 @@ def main():
         return
 
     with (torch.enable_grad() if a.workload == "train" else torch.no_grad()):
-        step, batch, S, cfg, desc, flops_img, model = workload_step(a.workload, dev, rank, a.batch)
+        step, batch, S, cfg, desc, flops_img, model = workload_step(a.workload, dev, rank, a.batch, a.train_config)
         value, total_images, elapsed = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
         image_size, prompt = WORKLOADS[a.workload][:2]
         res_rec = None

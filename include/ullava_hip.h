@@ -315,8 +315,11 @@ int ull_rmsnorm_bwd_bf16(const void* x, int64_t ldx, const void* w, const void* 
 
 /* hf LlamaMLP activation on the UNFUSED gate/up projection kept in ULL_EPI_SWIGLU's interleaved column order (groups of 16 gate |
  * 16 up): a [M, I] = silu(gate) * up with the reference's two roundings; backward: dgu [M, 2I] from da [M, I]. */
-int ull_swiglu_fwd_bf16(const void* gu, void* a, int64_t M, int64_t I, void* stream);
-int ull_swiglu_bwd_bf16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream);
+int ull_swiglu_fwd_bf16(const void* gu, void* a, int64_t M, int64_t I, int halves, void* stream);
+int ull_swiglu_bwd_bf16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, int halves, void* stream);
+
+/* ReLU backward as a selection (seg / det projector MLPs, the mask decoder's MLPs): dx[i] = y[i] > 0 ? dy[i] : 0 over n elements. */
+int ull_relu_mask_bf16(const void* y, const void* dy, void* dx, int64_t n, void* stream);
 
 /* Backward of ull_rope_inplace_bf16 (the rotation is orthogonal: the transposed rotation of the gradient), in place. */
 int ull_rope_bwd_inplace_bf16(void* dx, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads,
@@ -429,8 +432,9 @@ int ull_sam_small_mlps_f16(const void* hs, int64_t n, int64_t T, const void* con
 int ull_sam_t2i_attention_f16(const void* qproj, const void* keys, const void* pos, int64_t n, int64_t T, int64_t P, const void* wk, const void* bk, const void* wv, const void* bv, int late_bias_kv, void* scores_ws, void* vproj_ws, void* att, void* stream);
 int ull_sam_i2t_attention_ln_f16(const void* keys, const void* pos, const void* kproj, const void* vproj, int64_t n, int64_t T, int64_t P, const void* wq, const void* bq, const void* wo, const void* bo, int late_bias_q, const void* ln_w, const void* ln_b, float eps, void* out, void* stream);
 int ull_rmsnorm_bwd_f16(const void* x, int64_t ldx, const void* w, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw, int64_t rows, int64_t D, float eps, void* stream);
-int ull_swiglu_fwd_f16(const void* gu, void* a, int64_t M, int64_t I, void* stream);
-int ull_swiglu_bwd_f16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream);
+int ull_swiglu_fwd_f16(const void* gu, void* a, int64_t M, int64_t I, int halves, void* stream);
+int ull_swiglu_bwd_f16(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, int halves, void* stream);
+int ull_relu_mask_f16(const void* y, const void* dy, void* dx, int64_t n, void* stream);
 int ull_rope_bwd_inplace_f16(void* dx, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads, int64_t hd, void* stream);
 int ull_attention_bwd_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);
 int ull_attention_bwd_mfma_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* Qt, const void* Kt, const void* dOt, int64_t pitch, void* dQ, void* dK, void* dV, const int64_t* strides, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, float mult, void* scratch, void* stream);

@@ -381,14 +381,28 @@ def test_weight_caches_are_keyed_by_tensor_object_not_address():
     assert A._t_frozen(p) is t0
     p.mul_(2)
     assert torch.equal(A._t_frozen(p), p.t().contiguous())
-    # frozen packs of the training path: built once per parameter set, rebuilt after an update
-    a_, b_ = torch.nn.Parameter(p.clone(), requires_grad=False), torch.nn.Parameter(p.clone() + 1, requires_grad=False)
-    k0 = M_._frozen_pack("t", (a_, b_), lambda: torch.cat((a_, b_), dim=0))
-    assert M_._frozen_pack("t", (a_, b_), lambda: torch.cat((a_, b_), dim=0)) is k0
+    # shared q|k|v / gate|up buffers of the training path: the parameters become row slices of ONE buffer (values and names unchanged), the
+    # kept transposed copy of a FROZEN buffer follows an in-place update of a parameter, and state_dict() hands out tensors that own
+    # their storage (safetensors / HF Trainer._save refuse shared memory)
+    holder = torch.nn.Module()
+    for i_, n_ in enumerate(("q_proj", "k_proj", "v_proj")):
+        lin = M_.Linear(32, 64, bias=False, device=DEV)
+        lin.weight.data.copy_(torch.randn(64, 32, generator=g).to(torch.bfloat16))
+        setattr(holder, n_, lin)
+    before = [getattr(holder, n_).weight.detach().clone() for n_ in ("q_proj", "k_proj", "v_proj")]
+    packed, ws = M_.UllavaCoreForCausalLM._alias_pack(holder, ("q_proj", "k_proj", "v_proj"), "_qkv_pack")
+    assert packed.shape == (192, 32) and all(torch.equal(w, b) for w, b in zip(ws, before)) and torch.equal(packed, torch.cat(before))
+    assert ws[1].data_ptr() == packed.data_ptr() + 64 * 32 * 2
+    assert M_.UllavaCoreForCausalLM._alias_pack(holder, ("q_proj", "k_proj", "v_proj"), "_qkv_pack")[0] is packed      # still aliased: kept
+    x = torch.randn(16, 32, generator=g).to(torch.bfloat16).to(DEV).requires_grad_(True)
+    A.linear_packed(x, packed, *ws).sum().backward()
+    t_first = A._T_CACHE[id(packed)][2]
     with torch.no_grad():
-        a_.add_(1)
-    k1 = M_._frozen_pack("t", (a_, b_), lambda: torch.cat((a_, b_), dim=0))
-    assert k1 is not k0 and torch.equal(k1, torch.cat((a_, b_), dim=0))
+        holder.k_proj.weight.add_(1)
+    x.grad = None
+    A.linear_packed(x, packed, *ws).sum().backward()
+    assert A._T_CACHE[id(packed)][2] is not t_first and torch.equal(A._T_CACHE[id(packed)][2], packed.t().contiguous())
+    assert "_qkv_pack" not in dict(holder.named_buffers()) and "_qkv_pack" not in holder.state_dict()
 
 
 def test_lora_adapters_on_the_training_path():

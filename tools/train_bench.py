@@ -7,12 +7,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = "cuda:0"
-B = int(os.environ.get("BATCH", 8))
+B = int(os.environ.get("BATCH", 16))
 model, cfg = bench.build_model(224, dev, seed=0, with_sam=False)
 vis, ids, mask = bench.make_inputs(cfg, B, 64, dev, 0)
 labels = ids.clone(); labels[:, :259] = -100
+CFG = os.environ.get("TRAIN_CONFIG", "full")          # full (train_ullava.py:239-245) | qv (round 2's set)
 for n, p in model.named_parameters():
-    p.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or n.startswith("vision_projector") or ".q_proj." in n or ".v_proj." in n)
+    if CFG == "full":
+        p.requires_grad = n.startswith("model.") or n.startswith("lm_head") or n.startswith("vision_projector")
+    else:
+        p.requires_grad = (n.startswith("lm_head") or "embed_tokens" in n or n.startswith("vision_projector") or ".q_proj." in n or ".v_proj." in n)
 ntrain = sum(p.numel() for p in model.parameters() if p.requires_grad)
 print(f"trainable parameters: {ntrain / 1e6:.1f} M; batch {B}, S = {ids.shape[1]}")
 def step():

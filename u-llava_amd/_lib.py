@@ -25,8 +25,9 @@ SIGNATURES = {
     "ull_sam_t2i_attention_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr],
     "ull_sam_i2t_attention_ln_bf16": [_ptr] * 4 + [_i64] * 3 + [_ptr] * 4 + [_i32, _ptr, _ptr, _f32, _ptr, _ptr],
     "ull_rmsnorm_bwd_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _f32, _ptr],
-    "ull_swiglu_fwd_bf16": [_ptr, _ptr, _i64, _i64, _ptr],
-    "ull_swiglu_bwd_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _ptr],
+    "ull_swiglu_fwd_bf16": [_ptr, _ptr, _i64, _i64, _i32, _ptr],
+    "ull_swiglu_bwd_bf16": [_ptr, _ptr, _ptr, _i64, _i64, _i32, _ptr],
+    "ull_relu_mask_bf16": [_ptr, _ptr, _ptr, _i64, _ptr],
     "ull_rope_bwd_inplace_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "ull_attention_bwd_bf16": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.POINTER(_i64), _ptr, _i64, _i64, _i64, _i64, _i64, _i32,
                                _f32, _ptr, _ptr],

@@ -25,21 +25,22 @@ def _t(x: torch.Tensor) -> torch.Tensor:
 _T_CACHE: dict = {}           # id(weight) -> (weakref(weight), version, W^T): only the very same tensor object may hit
 
 
-def _t_frozen(w: torch.Tensor) -> torch.Tensor:
+def _t_frozen(w: torch.Tensor, tag=None) -> torch.Tensor:
     """Transposed copy of a FROZEN weight (dX = dY @ W needs W^T as the GEMM's row-major operand), kept across steps: the reference's
     stage-2 recipe freezes every LLaMA Linear but the LoRA targets, so the 13 GB of transposes are paid once, not per backward.
     Kept per tensor OBJECT (weak reference + version counter), never per address: the allocator hands a freed temporary's storage
     to the next one, so an address says nothing about the contents.  Callers therefore pass persistent tensors (parameters, or the
-    frozen packs of modeling_core._frozen_pack)."""
+    shared q|k|v / gate|up buffers of modeling_core._alias_pack)."""
     if w.requires_grad or w.grad_fn is not None:
         return _t(w)
+    ver = (w._version, tag)          # tag: version counters of parameters that alias `w`'s storage (their updates do not bump w._version)
     hit = _T_CACHE.get(id(w))
-    if hit is not None and hit[0]() is w and hit[1] == w._version:
+    if hit is not None and hit[0]() is w and hit[1] == ver:
         return hit[2]
     wt = _t(w)
     for k in [k for k, v in _T_CACHE.items() if v[0]() is None]:
         del _T_CACHE[k]
-    _T_CACHE[id(w)] = (weakref.ref(w), w._version, wt)
+    _T_CACHE[id(w)] = (weakref.ref(w), ver, wt)
     return wt
 
 
@@ -63,7 +64,7 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
-        g = torch.where(y > 0, dy, torch.zeros_like(dy)) if ctx.relu else dy          # selection, no arithmetic
+        g = ops.relu_mask(y, dy) if ctx.relu else dy                                   # selection (HIP kernel)
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -78,6 +79,64 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, w, bias=None, residual=None, relu: bool = False, bias_after_rounding: bool = False):
     return _Linear.apply(x, w, bias, residual, relu, bias_after_rounding)
+
+
+class _LinearPacked(torch.autograd.Function):
+    """y = x @ packed.T where `packed` [sum(N_i), K] is ONE buffer whose row slices ARE the parameters ws (q|k|v, gate|up: storage shared,
+    see modeling_core._alias_for_training).  One forward GEMM, one dX GEMM, one dW GEMM for the whole pack; the parameters' gradients are
+    row slices (views) of that one dW -- no torch.cat of the weights per step and no split / copy of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, packed, *ws):
+        y = ops.linear(x, packed)
+        ctx.save_for_backward(x, packed)
+        ctx.rows = [w.shape[0] for w in ws]
+        ctx.frozen = not any(w.requires_grad for w in ws)
+        ctx.wver = tuple(w._version for w in ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, packed = ctx.saved_tensors
+        g2, x2 = dy.contiguous().reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(g2, _t_frozen(packed, ctx.wver) if ctx.frozen else _t(packed)).view(x.shape)
+        dws = [None] * len(ctx.rows)
+        if any(ctx.needs_input_grad[2:]):
+            dwp = ops.linear(_t(g2), _t(x2))                                             # [sum(N_i), K]
+            o = 0
+            for i, n in enumerate(ctx.rows):
+                if ctx.needs_input_grad[2 + i]:
+                    dws[i] = dwp[o:o + n]
+                o += n
+        return (dx, None, *dws)
+
+
+def linear_packed(x, packed, *ws):
+    return _LinearPacked.apply(x, packed, *ws)
+
+
+class _Fork(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (the residual stream: the norm and the residual add).  Autograd would sum the two
+    gradients with a torch add; here the sum is the HIP add (rnd(a + b), the same 16-bit arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        if d1 is None:
+            return d2
+        if d2 is None:
+            return d1
+        return ops.add_rows(d1.contiguous(), d2.contiguous())
+
+
+def fork(x):
+    return _Fork.apply(x)
 
 
 class _RMSNorm(torch.autograd.Function):
@@ -99,21 +158,22 @@ def rmsnorm(x, w, eps):
 
 
 class _SwiGLU(torch.autograd.Function):
-    """gu [M, 2I] (interleaved gate/up columns) -> silu(gate) * up."""
+    """gu [M, 2I] (interleaved gate/up columns, or with halves [gate | up]) -> silu(gate) * up."""
 
     @staticmethod
-    def forward(ctx, gu):
+    def forward(ctx, gu, halves):
         ctx.save_for_backward(gu)
-        return ops.swiglu_fwd(gu)
+        ctx.halves = halves
+        return ops.swiglu_fwd(gu, halves)
 
     @staticmethod
     def backward(ctx, da):
         (gu,) = ctx.saved_tensors
-        return ops.swiglu_bwd(gu, da.contiguous())
+        return ops.swiglu_bwd(gu, da.contiguous(), ctx.halves), None
 
 
-def swiglu(gu):
-    return _SwiGLU.apply(gu)
+def swiglu(gu, halves: bool = False):
+    return _SwiGLU.apply(gu, bool(halves))
 
 
 class _Rope(torch.autograd.Function):

@@ -147,32 +147,36 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_wave_kernel(const elem_t* __r
 // ---- LlamaMLP activation on the interleaved gate/up layout (groups of 16 gate | 16 up columns, ULL_EPI_SWIGLU's weight order) -----
 // forward: a[m, 16g + j] = rnd(rnd(silu(gate)) * up);  backward: d_gate = da * up * silu'(gate), d_up = da * silu(gate).
 // (16-byte accesses: a chunk of 8 outputs 16g + 8h .. +7 reads the gate chunk at column 32g + 8h and the up chunk 16 columns on)
-__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const elem_t* __restrict__ gu, elem_t* __restrict__ a, long M, int I) {
+// halves: gu = [gate (I columns) | up (I columns)] (the training path's gate_proj / up_proj share one [2I, K] buffer as row slices);
+// otherwise the 16-column interleave of the inference pack.
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const elem_t* __restrict__ gu, elem_t* __restrict__ a, long M, int I, int halves) {
     const int cpr = I >> 3;                                  // output chunks per row
     const long total = M * cpr;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long m = i / cpr;
         const int oc = (int)(i % cpr), g = oc >> 1, hh = oc & 1;
-        const elem_t* src = gu + m * 2 * I + g * 32 + hh * 8;
+        const elem_t* src = gu + m * 2 * I + (halves ? oc * 8 : g * 32 + hh * 8);
+        const int up_off = halves ? I : 16;
         float gate[8], up[8], o[8];
         unpack8(*(const uint4*)src, gate);
-        unpack8(*(const uint4*)(src + 16), up);
+        unpack8(*(const uint4*)(src + up_off), up);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rnd(act_silu(gate[e])) * up[e];
         *(uint4*)(a + m * I + oc * 8) = pack8(o);
     }
 }
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const elem_t* __restrict__ gu, const elem_t* __restrict__ da, elem_t* __restrict__ dgu,
-                                                         long M, int I) {
+                                                         long M, int I, int halves) {
     const int cpr = I >> 3;
     const long total = M * cpr;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long m = i / cpr;
         const int oc = (int)(i % cpr), g = oc >> 1, hh = oc & 1;
-        const long ig = m * 2 * I + g * 32 + hh * 8;
+        const long ig = m * 2 * I + (halves ? oc * 8 : g * 32 + hh * 8);
+        const int up_off = halves ? I : 16;
         float gate[8], up[8], d[8], og[8], ou[8];
         unpack8(*(const uint4*)(gu + ig), gate);
-        unpack8(*(const uint4*)(gu + ig + 16), up);
+        unpack8(*(const uint4*)(gu + ig + up_off), up);
         unpack8(*(const uint4*)(da + m * I + oc * 8), d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const elem_t* __restric
             ou[e] = d[e] * (gate[e] * s);
         }
         *(uint4*)(dgu + ig) = pack8(og);
-        *(uint4*)(dgu + ig + 16) = pack8(ou);
+        *(uint4*)(dgu + ig + up_off) = pack8(ou);
     }
 }
 
@@ -1126,18 +1130,44 @@ extern "C" int ULL_FN(ull_rmsnorm_bwd_)(const void* x, int64_t ldx, const void* 
     return ull_check_launch();
 }
 
-extern "C" int ULL_FN(ull_swiglu_fwd_)(const void* gu, void* a, int64_t M, int64_t I, void* stream) {
+extern "C" int ULL_FN(ull_swiglu_fwd_)(const void* gu, void* a, int64_t M, int64_t I, int halves, void* stream) {
     if (!gu || !a || M <= 0 || I <= 0) return ULL_ERR_ARG;
     if (I & 15) return ULL_ERR_SHAPE;
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(nblk(M * I)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)gu, (elem_t*)a, (long)M, (int)I);
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(nblk(M * I)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)gu, (elem_t*)a, (long)M, (int)I, halves);
     return ull_check_launch();
 }
 
-extern "C" int ULL_FN(ull_swiglu_bwd_)(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, void* stream) {
+extern "C" int ULL_FN(ull_swiglu_bwd_)(const void* gu, const void* da, void* dgu, int64_t M, int64_t I, int halves, void* stream) {
     if (!gu || !da || !dgu || M <= 0 || I <= 0) return ULL_ERR_ARG;
     if (I & 15) return ULL_ERR_SHAPE;
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(nblk(M * I)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)gu, (const elem_t*)da, (elem_t*)dgu,
-                       (long)M, (int)I);
+                       (long)M, (int)I, halves);
+    return ull_check_launch();
+}
+
+// ReLU backward as a selection: dx = y > 0 ? dy : 0 (y = the Linear's activated output).  n % 8 == 0 elements are taken 8 at a time.
+namespace {
+__global__ __launch_bounds__(256) void relu_mask_kernel(const elem_t* __restrict__ y, const elem_t* __restrict__ dy, elem_t* __restrict__ dx, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (long)gridDim.x * 256 * 8) {
+        if (i + 8 <= n) {
+            float a[8], d[8];
+            unpack8(*(const uint4*)(y + i), a);
+            const uint4 dv = *(const uint4*)(dy + i);
+            const uint16_t* dh = (const uint16_t*)&dv;
+            uint4 o;
+            uint16_t* oh = (uint16_t*)&o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oh[e] = a[e] > 0.f ? dh[e] : (uint16_t)0;
+            *(uint4*)(dx + i) = o;
+        } else {
+            for (long j = i; j < n; ++j) dx[j] = e2f(y[j]) > 0.f ? dy[j] : (elem_t)0;
+        }
+    }
+}
+}  // namespace
+extern "C" int ULL_FN(ull_relu_mask_)(const void* y, const void* dy, void* dx, int64_t n, void* stream) {
+    if (!y || !dy || !dx || n <= 0) return ULL_ERR_ARG;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(nblk(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, (const elem_t*)y, (const elem_t*)dy, (elem_t*)dx, (long)n);
     return ull_check_launch();
 }
 

@@ -35,29 +35,19 @@ def _param(*shape, device=None, dtype=BF16):
 
 
 
-_FROZEN_PACKS: dict = {}      # (kind, id(src0), ...) -> (weakrefs, versions, packed): re-layouts of FROZEN weights for the training path
-
-
 def _clear_transposes():
     from .autograd_ops import clear_transpose_cache
     clear_transpose_cache()
-    _FROZEN_PACKS.clear()
 
 
-def _frozen_pack(kind: str, srcs, build):
-    """The training path re-packs weights under autograd (fused q|k|v, interleaved gate|up) so that gradients reach the parameters.
-    Where every source is frozen there is no gradient to route, and the pack -- and its transposed copy for dX, cached per tensor
-    object by autograd_ops._t_frozen -- is built once and kept, keyed by the parameter objects and their version counters."""
-    if any(t.requires_grad for t in srcs):
-        return build()
-    key = (kind,) + tuple(id(t) for t in srcs)
-    hit = _FROZEN_PACKS.get(key)
-    if hit is not None and all(r() is t for r, t in zip(hit[0], srcs)) and hit[1] == tuple(t._version for t in srcs):
-        return hit[2]
-    with torch.no_grad():
-        packed = build()
-    _FROZEN_PACKS[key] = (tuple(weakref.ref(t) for t in srcs), tuple(t._version for t in srcs), packed)
-    return packed
+def _dealias_state_dict(module, state_dict, prefix, local_metadata):
+    """state-dict hook: the training path makes q|k|v and gate|up row slices of one buffer each (_alias_pack); a state dict must hold
+    tensors that own their storage (safetensors refuses shared memory; HF Trainer._save writes state_dict() as it is)."""
+    for k in list(state_dict.keys()):
+        v = state_dict[k]
+        if k.startswith(prefix) and isinstance(v, torch.Tensor) and v.untyped_storage().nbytes() > v.numel() * v.element_size() + 64:
+            state_dict[k] = v.clone()
+    return state_dict
 
 
 class Linear(nn.Module):
@@ -229,6 +219,7 @@ class UllavaCoreForCausalLM(nn.Module):
         self.strict_checks = True          # reproduce the reference's start/end-count assert (one tiny D2H read)
         self._packed = None
         self._inv_freq = None
+        self._register_state_dict_hook(_dealias_state_dict)
 
     # -- construction helpers ----------------------------------------------------------------------------
     @staticmethod
@@ -534,6 +525,29 @@ class UllavaCoreForCausalLM(nn.Module):
     def gradient_checkpointing_disable(self):
         self.config.gradient_checkpointing = False
 
+    @staticmethod
+    def _alias_pack(holder, names, slot):
+        """Make the parameters `names` of `holder` row slices of ONE [sum(N_i), K] buffer (storage shared; values, shapes, names and
+        state-dict entries unchanged) and return that buffer.  Re-done whenever the aliasing was lost (.to(), a fresh Parameter)."""
+        ws = [getattr(holder, n).weight for n in names]
+        packed = getattr(holder, slot, None)
+        ok = packed is not None and packed.device == ws[0].device and packed.dtype == ws[0].dtype
+        if ok:
+            o = 0
+            for w in ws:
+                ok = ok and w.data_ptr() == packed.data_ptr() + o * packed.shape[1] * packed.element_size() and w.is_contiguous()
+                o += w.shape[0]
+            ok = ok and o == packed.shape[0]
+        if not ok:
+            with torch.no_grad():
+                packed = torch.cat([w.data for w in ws], dim=0).contiguous()
+                o = 0
+                for w in ws:
+                    w.data = packed[o:o + w.shape[0]]
+                    o += w.shape[0]
+            object.__setattr__(holder, slot, packed)             # a plain attribute: not a Parameter, not a buffer, not in the state dict
+        return packed, ws
+
     def _llama_train(self, inputs_embeds, attention_mask, position_ids, output_hidden_states):
         """LlamaModel.forward with an autograd graph: the same HIP forward kernels (SwiGLU un-fused, RoPE stand-alone, weights
         re-packed under autograd so gradients reach q/k/v/gate/up_proj), HIP backward kernels (autograd_ops.py)."""
@@ -554,10 +568,12 @@ class UllavaCoreForCausalLM(nn.Module):
             if output_hidden_states:
                 all_h.append(x.view(B, S, D))
             a, m = l.self_attn, l.mlp
-            qkv_w = (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
-            w_qkv = _frozen_pack("qkv", qkv_w, lambda: torch.cat(qkv_w, dim=0))
+            # q|k|v and gate|up are each ONE buffer whose row slices are the parameters (no per-step torch.cat / interleave of trainable
+            # weights, one dW GEMM per pack whose row slices are the parameters' gradients)
+            w_qkv, qkv_w = self._alias_pack(a, ("q_proj", "k_proj", "v_proj"), "_qkv_pack")
+            x, x_res = A.fork(x)                                 # two consumers: the norm and the residual add of o_proj
             h = A.rmsnorm(x, l.input_layernorm.weight, cfg.rms_norm_eps)
-            qkv_lin = A.linear(h, w_qkv)
+            qkv_lin = A.linear_packed(h, w_qkv, *qkv_w)
             if getattr(self, "_lora", None) is not None:
                 # PEFT's Linear.forward: result += lora_B(lora_A(dropout(x))) * scaling -- here as two skinny GEMMs for the whole q|k|v row,
                 # the base projection riding along as the second one's residual operand
@@ -566,11 +582,12 @@ class UllavaCoreForCausalLM(nn.Module):
                 qkv_lin = A.linear(A.linear(hd_in, a_cat), b_cat, residual=qkv_lin)
             qkv = A.rope(qkv_lin, pos, inv_freq, 2 * H, hd)
             att = A.self_attention(qkv, key_mask, B, S, H, hd, True)
-            x = A.linear(att, a.o_proj.weight, residual=x)
+            x = A.linear(att, a.o_proj.weight, residual=x_res)
+            x, x_res = A.fork(x)
             h = A.rmsnorm(x, l.post_attention_layernorm.weight, cfg.rms_norm_eps)
-            gu_w = (m.gate_proj.weight, m.up_proj.weight)
-            gu = A.linear(h, _frozen_pack("gate_up", gu_w, lambda: interleave_gate_up(*gu_w)))
-            x = A.linear(A.swiglu(gu), m.down_proj.weight, residual=x)
+            w_gu, gu_w = self._alias_pack(m, ("gate_proj", "up_proj"), "_gu_pack")
+            gu = A.linear_packed(h, w_gu, *gu_w)                 # columns [gate | up]
+            x = A.linear(A.swiglu(gu, halves=True), m.down_proj.weight, residual=x_res)
         x = A.rmsnorm(x, self.model.norm.weight, cfg.rms_norm_eps)
         last = x.view(B, S, D)
         if output_hidden_states:

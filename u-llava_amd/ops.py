@@ -624,21 +624,30 @@ def rmsnorm_bwd(x: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, 
     return dx, dw
 
 
-def swiglu_fwd(gu: torch.Tensor) -> torch.Tensor:
-    """gu [M, 2I] in the interleaved gate/up column order -> silu(gate) * up [M, I]."""
+def swiglu_fwd(gu: torch.Tensor, halves: bool = False) -> torch.Tensor:
+    """gu [M, 2I] -> silu(gate) * up [M, I].  Columns: the 16-wide gate/up interleave of the inference pack, or (halves) [gate | up]."""
     _chk(gu, "gu")
     M, I = gu.numel() // gu.shape[-1], gu.shape[-1] // 2
     a = torch.empty(*gu.shape[:-1], I, device=gu.device, dtype=gu.dtype)
-    _lib.call("ull_swiglu_fwd_" + _SFX[gu.dtype], _p(gu.contiguous()), _p(a), M, I, _stream())
+    _lib.call("ull_swiglu_fwd_" + _SFX[gu.dtype], _p(gu.contiguous()), _p(a), M, I, int(halves), _stream())
     return a
 
 
-def swiglu_bwd(gu: torch.Tensor, da: torch.Tensor) -> torch.Tensor:
+def swiglu_bwd(gu: torch.Tensor, da: torch.Tensor, halves: bool = False) -> torch.Tensor:
     _chk(gu, "gu"); _chk(da, "da", gu.dtype)
     M, I = gu.numel() // gu.shape[-1], gu.shape[-1] // 2
     dgu = torch.empty_like(gu)
-    _lib.call("ull_swiglu_bwd_" + _SFX[gu.dtype], _p(gu.contiguous()), _p(da.contiguous()), _p(dgu), M, I, _stream())
+    _lib.call("ull_swiglu_bwd_" + _SFX[gu.dtype], _p(gu.contiguous()), _p(da.contiguous()), _p(dgu), M, I, int(halves), _stream())
     return dgu
+
+
+def relu_mask(y: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """dx = y > 0 ? dy : 0 (ReLU backward as a selection)."""
+    _chk(y, "y"); _chk(dy, "dy", y.dtype)
+    y, dy = y.contiguous(), dy.contiguous()
+    dx = torch.empty_like(dy)
+    _lib.call("ull_relu_mask_" + _SFX[y.dtype], _p(y), _p(dy), _p(dx), y.numel(), _stream())
+    return dx
 
 
 def rope_bwd_inplace(dx: torch.Tensor, row_stride: int, positions: torch.Tensor, inv_freq: torch.Tensor, tokens: int, n_heads: int, hd: int):
