@@ -321,3 +321,50 @@ def test_generate_rejects_unknown_options():
         m.generate(input_ids=ids, num_beams=4)
     with pytest.raises(ValueError):
         m.generate(input_ids=ids, no_repeat_ngram_size=-1)
+
+
+def test_hf_trainer_constructs_optimises_and_saves_the_shim_model(tmp_path):
+    """train_ullava.py:273-293 hands the model to a transformers Trainer (SegmentationTrainer): construction, create_optimizer() over the
+    reference's trainable set and Trainer._save() must work on these plain nn.Modules -- including after the training path has made the
+    q|k|v / gate|up parameters row slices of shared buffers (the state-dict hook hands out tensors that own their storage; safetensors
+    refuses shared memory).  The saved file loads back to the same values."""
+    from safetensors.torch import load_file
+    from transformers import Trainer, TrainingArguments
+    C, M = pkg("configuration"), pkg("modeling_ullava")
+    cfg = C.UllavaConfig(llm_config=dict(vision_config=dict(hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64, image_size=28,
+                                                            patch_size=14), vocab_size=120, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                         num_attention_heads=4), seg_token_idx=101, loc_token_idx=102, out_dim=256,
+                         sam_config=dict(embed_dim=32, depth=2, num_heads=2, global_attn_indexes=[1]))
+    m = M.UllavaForCausalLM(cfg)
+    g = torch.Generator().manual_seed(0)
+    for p in m.parameters():
+        p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.dtype))
+    # the reference's stage-2 switches (train_ullava.py:207-261, no LoRA)
+    for p in m.parameters():
+        p.requires_grad = False
+    for p in list(m.llm.model.parameters()) + list(m.llm.lm_head.parameters()) + list(m.llm.vision_projector.parameters()):
+        p.requires_grad = True
+    for n, p in m.named_parameters():
+        if any(x in n for x in ["lm_head", "embed_tokens", "seg_projector", "mask_decoder", "det_projector", "det_decoder"]):
+            p.requires_grad = "mask_decoder.iou_prediction_head" not in n
+    n_train = sum(p.requires_grad for p in m.parameters())
+    # what a training forward does to the attention / MLP projections of every LLaMA layer
+    for l in m.llm.model.layers:
+        m.llm._alias_pack(l.self_attn, ("q_proj", "k_proj", "v_proj"), "_qkv_pack")
+        m.llm._alias_pack(l.mlp, ("gate_proj", "up_proj"), "_gu_pack")
+    assert m.llm.model.layers[0].self_attn.k_proj.weight.untyped_storage().nbytes() == 3 * 64 * 64 * 2
+    want = {k: v.clone() for k, v in m.state_dict().items()}
+    assert all(v.untyped_storage().nbytes() <= v.numel() * v.element_size() + 64 for v in m.state_dict().values())
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, learning_rate=2e-5, weight_decay=0.0, report_to=[], use_cpu=True)
+    trainer = Trainer(model=m, args=args, train_dataset=None)
+    opt = trainer.create_optimizer()
+    assert sum(len(gr["params"]) for gr in opt.param_groups) == n_train
+    trainer._save(str(tmp_path))
+    back = load_file(str(tmp_path / "model.safetensors"))
+    assert set(back) == set(want) and all(torch.equal(back[k], want[k]) for k in want)
+    # an optimizer step through the aliased parameters moves the shared buffer (the GEMMs of the next forward read the new weights)
+    q = m.llm.model.layers[0].self_attn.q_proj.weight
+    q.grad = torch.ones_like(q)
+    before = m.llm.model.layers[0].self_attn._qkv_pack[:64].clone()
+    opt.step()
+    assert not torch.equal(m.llm.model.layers[0].self_attn._qkv_pack[:64], before) and torch.equal(m.llm.model.layers[0].self_attn._qkv_pack[:64], q.data)
