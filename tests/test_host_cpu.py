@@ -337,7 +337,7 @@ def test_hf_trainer_constructs_optimises_and_saves_the_shim_model(tmp_path):
                          sam_config=dict(embed_dim=32, depth=2, num_heads=2, global_attn_indexes=[1]))
     m = M.UllavaForCausalLM(cfg)
     g = torch.Generator().manual_seed(0)
-    for p in m.parameters():
+    for p in list(m.parameters()) + list(m.buffers()):          # (holders are torch.empty: buffers too, or NaN garbage breaks torch.equal)
         p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.dtype))
     # the reference's stage-2 switches (train_ullava.py:207-261, no LoRA)
     for p in m.parameters():
