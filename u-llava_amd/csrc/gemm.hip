@@ -1333,6 +1333,135 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
 // for the epilogue's stores moves to barrier B of the next item's first step instead of disappearing.  Removed; the block hand-over
 // of the hardware stays.)
 
+// ---- fused ViT patchify, one round of strips (round 3) -------------------------------------------------------------------------
+// The 128x128 form above runs B = 32 at 336^2 (M = 18432 patches, N = 1024, K' = 704) as 1152 tiles = 2.25 rounds of two blocks per CU and
+// moves 415 MB from L2 to LDS for 61 MB of algorithmic bytes: 47 us, and every plain GEMM kernel of this library and the vendor's lands at
+// 40-50 us on the same M x N x K' (profiles/r02_patchify_ceiling.txt): the op is bound by tile quantisation and L2 -> LDS bytes, not HBM.
+// This form fits the TILE to the problem instead: (32 * WMB) x 256 with 8 waves of (16 * WMB) x 64 -- WMB = 9: 288 x 256, exactly
+// 64 x 4 = 256 tiles for the C4 batch (one per CU, one round, no padded rows); WMB = 4: 128 x 256 for 224^2 -- which also halves the
+// L2 -> LDS traffic (196 MB).  Same A-tile DMA from the pixels, permuted W rows + register-direct stores as in the 4-wave GEMM.
+// Measured (tools/patchify_bench.py, same box): 38.5 us against 42.4 at 336^2 = 19.7 % of the 8 TB/s the north-star target counts
+// against.  Per CU the tile needs 765 KB through the L1 (~9 us at the ~85 GB/s a CU sustains) and 12.7 us of MFMA time, so ~15-19 us
+// would be the floor of ANY single-round GEMM form of this op (= 40-50 % of HBM peak: the 60 % target, 12.6 us, is below the MFMA time
+// alone); what is left between 19 and 38 us is the 11-step loop waiting for HBM-sourced pixel tiles at a prefetch distance of one
+// step (two 68-KiB stages are all the LDS holds).  0.02 % of a C4 step.
+template <int WMB>
+__global__ __launch_bounds__(512) void patchify_strip_kernel(GemmArgs p, PatchArgs q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 32 * WMB, TN = 256;
+    constexpr int A_BYTES = TM * 128, W_BYTES = TN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int NPIECE = (TM + TN) / 8;                  // 1-KiB DMA pieces per stage (8 rows each)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bn = blockIdx.x % p.nbn, bm = blockIdx.x / p.nbn;     // the 4 N-tiles of a strip on neighbouring CUs: they share its pixels in L2
+    const int m0 = bm * TM, n0 = bn * TN;
+    const int srow = lane >> 3;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    constexpr int PPW = (NPIECE + 7) / 8;                  // pieces per wave
+    // piece pc (0 .. NPIECE): pc < TM / 8 -> A rows 8 pc .. + 8, else W rows
+    const elem_t* src[PPW];                                // A: pixel (b, c = 0, y = py * ps, x = px * ps) + half * 8;  W: row start + chunk
+    int aseg[PPW];                                         // A: (c, ky) segment of this lane's chunk within the K-tile (0..3), -1 for a W piece
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + 8 * i;
+        src[i] = nullptr; aseg[i] = -1;
+        if (pc < TM / 8) {
+            const int r = pc * 8 + srow;
+            const int schunk = (lane & 7) ^ srow;          // X tile swizzle: row & 7
+            const int m = min(m0 + r, p.M - 1);
+            const int px = m % q.gw, py = (m / q.gw) % q.gh, b = m / (q.gw * q.gh);
+            src[i] = q.img + (((long)b * q.C * q.H + (long)py * q.ps) * q.W + px * q.ps) + (schunk & 1) * 8;
+            aseg[i] = schunk >> 1;
+        } else if (pc < NPIECE) {
+            const int r = (pc - TM / 8) * 8 + srow;
+            const int wchunk = (lane & 7) ^ w4_row_swizzle<false>(r);
+            src[i] = p.W + (long)min(n0 + r, p.N - 1) * p.ldw + wchunk * 8;
+        }
+    }
+    auto stage = [&](int buf, int kt) {
+        const uint32_t sb = lds_base + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + 8 * i;
+            if (pc >= NPIECE) continue;
+            if (pc < TM / 8) {
+                const int idx = kt * 4 + aseg[i];          // global (c, ky) segment of this lane's chunk
+                const int c = idx / q.ps, ky = idx - c * q.ps;
+                const bool real = idx < q.nseg;
+                const elem_t* sp = real ? src[i] + ((long)c * q.H + ky) * q.W : q.zeros;
+                if (real && sp + 8 > q.img_end) {          // the one chunk that would read past the image buffer: through registers
+                    const uint32_t* s32 = (const uint32_t*)sp;
+                    *(uint4*)(smem + buf * STAGE + pc * 1024 + lane * 16) = make_uint4(s32[0], s32[1], s32[2], 0u);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    glds16(sp, sb + pc * 1024);
+                }
+            } else {
+                glds16(src[i] + (long)kt * BK, sb + A_BYTES + (pc - TM / 8) * 1024);
+            }
+        }
+    };
+    int swz[2], wswz[2];
+    swz[0] = ((0 + fg) ^ (lane & 7)) << 4;
+    swz[1] = ((4 + fg) ^ (lane & 7)) << 4;
+    wswz[0] = ((0 + fg) ^ (fr >> 1)) << 4;
+    wswz[1] = ((4 + fg) ^ (fr >> 1)) << 4;
+    const int xoff = (wm * 16 * WMB + fr) * 128;
+    const int woff = A_BYTES + (wn * 64 + w4_lane_row<false>(fr)) * 128;
+
+    f32x4_t acc[4][WMB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WMB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nk = p.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* base = smem + cur * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 wf[4], xf[WMB];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *(const uint4*)(base + wswz[kk] + woff + w4_frag_row<false>(i) * 128);
+#pragma unroll
+            for (int j = 0; j < WMB; ++j) xf[j] = *(const uint4*)(base + swz[kk] + xoff + j * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < WMB; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(wf[i], xf[j], acc[i][j]);
+        }
+    }
+    // epilogue: acc[i][j][r] = D[n = n0 + wn*64 + 32*(i>>1) + 8*fg + 4*(i&1) + r][m = m0 + wm*16*WMB + j*16 + fr]: 16-byte stores
+    const int nb = n0 + wn * 64 + 8 * fg;
+    float bv[2][8];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        if ((p.flags & EPI_BIAS) && nb + pp * 32 + 8 <= p.N) unpack8(*(const uint4*)(p.bias + nb + pp * 32), bv[pp]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[pp][e] = -0.0f;
+        }
+    }
+    elem_t* cb = (elem_t*)p.C + nb;
+#pragma unroll
+    for (int j = 0; j < WMB; ++j) {
+        const int m = m0 + wm * 16 * WMB + j * 16 + fr;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[2 * pp + (e >> 2)][j][e & 3] + bv[pp][e];
+            if (m < p.M && nb + pp * 32 + 8 <= p.N) *(uint4*)(cb + (long)m * p.ldc + pp * 32) = pack8(v);
+        }
+    }
+}
+
 // (A v_mfma_f32_32x32x16_bf16 variant of this kernel measured 6-11 % slower in this structure and was removed;
 // numbers in profiles/r01_gemm_notes.md.)
 
@@ -1445,6 +1574,8 @@ static int gemm_device_state(int* n_cu_out) {
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)patchify_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)big::patchify_strip_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (288 + 256) * 128);
+        (void)hipFuncSetAttribute((const void*)big::patchify_strip_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128);
         n_cu[dev] = n;                   // last: a racing first call on another thread repeats the (idempotent) attribute calls
     }
     *n_cu_out = n_cu[dev];
@@ -1596,6 +1727,21 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
     a.rope_cos = a.rope_sin = nullptr; a.rope_cols = 0;
     int n_cu = 0;
     if (const int rc = gemm_device_state(&n_cu)) return rc;
+    // one round of problem-sized strips when the batch allows it (C4: 32 x 576 patches = 64 strips of 288 x 4 column tiles = 256 blocks)
+    if ((N & 255) == 0 && (ldc & 7) == 0 && !getenv("ULL_PATCHIFY_TILES")) {
+        const int nbn = (int)(N / 256);
+        for (const int wmb : {9}) {          // (WMB = 4, 128 x 256 strips for 224^2 at B = 32, measured 20.9 us against 19.6 for the 128x128 form: not used)
+            const int tm = 32 * wmb;
+            if (M % tm) continue;
+            const long tiles = (M / tm) * nbn;
+            if (tiles > n_cu || tiles * 2 <= n_cu) continue;
+            a.nbm = (int)(M / tm); a.nbn = nbn;
+            const int lds = 2 * (tm + 256) * 128;
+            if (wmb == 9) hipLaunchKernelGGL(big::patchify_strip_kernel<9>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a, q);
+            else hipLaunchKernelGGL(big::patchify_strip_kernel<4>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a, q);
+            return ull_check_launch();
+        }
+    }
     hipLaunchKernelGGL(patchify_gemm_kernel<0>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a, q);
     return ull_check_launch();
 }
