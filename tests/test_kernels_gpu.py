@@ -716,3 +716,54 @@ def test_sum_slabs_against_fp32_sum(dt, R, n, scale):
     assert torch.equal(got.cpu(), want), float((got.cpu().float() - want.float()).abs().max())
     with pytest.raises(RuntimeError):
         ops.sum_slabs(x.float().to(DEV), scale)              # no fp32 build: allreduce_gradients routes fp32 buckets to all_reduce
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_greedy_step_kernel_matches_torch_bookkeeping(dt):
+    """ull_greedy_step (one launch per generated token) against the torch ops it replaces in HF-style greedy search: argmax with the
+    FIRST index on ties (16-bit logits tie often), pad fill of finished rows, EOS tracking, append, the unfinished-row counter."""
+    ops = pkg("ops")
+    g = torch.Generator().manual_seed(9)
+    B, V, L = 7, 32011, 12
+    logits = (torch.randn(B, 3, V, generator=g) * 2).to(dt)
+    logits[0, -1, 100] = logits[0, -1].max() + 1                 # a clear winner
+    logits[1, -1, [5, 17000, 32010]] = logits[1, -1].float().max().item() + 2   # a three-way tie: index 5 wins
+    logits[2, -1, :] = 0.5                                        # every entry ties: index 0
+    eos = torch.tensor([2, 100], dtype=torch.int64)
+    unfinished = torch.tensor([1, 1, 0, 1, 1, 0, 1], dtype=torch.int32)
+    seq = torch.full((B, L), -7, dtype=torch.int64)
+    want_tok = logits[:, -1].float().argmax(-1)
+    assert int(want_tok[1]) == 5 and int(want_tok[2]) == 0
+    pad = 31999
+    want_tok = torch.where(unfinished.bool(), want_tok, torch.full_like(want_tok, pad))
+    want_unf = unfinished.bool() & ~torch.isin(want_tok, eos)
+    ld = logits.to(DEV)
+    u_d, s_d, alive = unfinished.to(DEV), seq.to(DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.greedy_step(ld[:, -1], u_d, eos.to(DEV), pad, s_d, 4, alive)
+    assert torch.equal(s_d[:, 4].cpu(), want_tok) and torch.equal(u_d.cpu().bool(), want_unf) and int(alive) == int(want_unf.sum())
+    assert bool((s_d.cpu()[:, :4] == -7).all()) and bool((s_d.cpu()[:, 5:] == -7).all())       # only column `pos` is written
+    # no pad id: finished rows keep the argmax; no EOS list: nothing finishes
+    u2, s2, a2 = unfinished.to(DEV), seq.to(DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.greedy_step(ld[:, -1], u2, None, None, s2, 0, a2)
+    assert torch.equal(s2[:, 0].cpu(), logits[:, -1].float().argmax(-1)) and torch.equal(u2.cpu(), unfinished) and int(a2) == int(unfinished.sum())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_relu_mask_and_swiglu_halves(dt):
+    """The two small kernels the full-parameter training path added: ReLU backward as a selection, and SwiGLU on [gate | up] column halves
+    (the layout of the shared gate|up buffer) -- bit-identical to the 16-column interleave of the inference pack, forward and backward."""
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    g = torch.Generator().manual_seed(4)
+    y, dy = torch.randn(37, 129, generator=g).to(dt), torch.randn(37, 129, generator=g).to(dt)
+    y[0, :5] = 0
+    got = ops.relu_mask(y.to(DEV), dy.to(DEV)).cpu()
+    assert torch.equal(got, torch.where(y > 0, dy, torch.zeros_like(dy)))
+    Mr, I = 19, 64
+    gate, up, da = (torch.randn(Mr, I, generator=g).to(dt) for _ in range(3))
+    halves = torch.cat([gate, up], dim=1).to(DEV)
+    inter = M_.interleave_gate_up(gate.t().contiguous(), up.t().contiguous()).t().contiguous().to(DEV)      # columns in 16-wide [gate | up] groups
+    a_h, a_i = ops.swiglu_fwd(halves, halves=True), ops.swiglu_fwd(inter)
+    assert torch.equal(a_h, a_i)
+    d_h, d_i = ops.swiglu_bwd(halves, da.to(DEV), halves=True).cpu(), ops.swiglu_bwd(inter, da.to(DEV)).cpu()
+    dg_i = d_i.view(Mr, I // 16, 2, 16)
+    assert torch.equal(d_h[:, :I], dg_i[:, :, 0].reshape(Mr, I)) and torch.equal(d_h[:, I:], dg_i[:, :, 1].reshape(Mr, I))
