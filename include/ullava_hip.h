@@ -58,6 +58,7 @@ extern "C" {
 #define ULL_GEMM_TUNE_SMALL_KERNEL (1 << 20)        /* force the 128x128 kernel */
 #define ULL_GEMM_TUNE_WAVES8 (1 << 21)              /* 256x256 tile on 8 waves of 128x64, whatever the shape */
 #define ULL_GEMM_TUNE_WAVES4 (1 << 22)              /* 256x256 tile on 4 waves of 128x128, whatever the shape */
+#define ULL_GEMM_TUNE_STAGED_EPILOGUE 512           /* 4-wave kernel: LDS-staged epilogue where the register-direct one would run (tests / tools) */
 int ull_gemm_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R,
                   int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream);
 
