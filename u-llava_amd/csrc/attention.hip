@@ -279,6 +279,16 @@ ULL_DEV void lds_tr_wait(u32x2_t (&a)[N], u32x2_t (&b)[N]) {      // ties the va
                      : "n"(LEFT) : "memory");
 }
 
+// tile buffers of attn_reg_kernel: EXACT keeps every K and V tile; the prefill form of LLaMA / CLIP (VROW, every wave issuing the same number
+// of DMA pieces per tile) streams through a ring of ULL_ATTN_RING (2: measured best); everything else through two
+template <int HDP, int NT, int NWV, bool EXACT, bool VROW>
+constexpr int attn_reg_nbuf() {
+#ifndef ULL_ATTN_RING
+#define ULL_ATTN_RING 2
+#endif
+    return EXACT ? 2 * NT : ((VROW && (HDP / 8) % NWV == 0 && NT >= 2) ? ULL_ATTN_RING : 2);
+}
+
 //   VROW (LLaMA / CLIP prefill): the V tiles are DMA'd ROW-major from V itself ([64 keys][head dim], like the K tiles) and the V^T
 //   operand of P*V comes out of them through ds_read_b64_tr_b16: no V^T pass in front of the attention.
 template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false, bool VROW = false>
@@ -310,7 +320,8 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     const int koff = p.Sk - p.Sq;
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    constexpr int NBUF = EXACT ? 2 * NT : 2;                     // EXACT: [K tiles 0..NT) [V^T tiles 0..NT)
+    constexpr int NBUF = attn_reg_nbuf<HDP, NT, NWV, EXACT, VROW>();   // EXACT: [K tiles 0..NT) [V^T tiles 0..NT); else a ring of tile buffers
+    constexpr int PPW = (CPR + NWV - 1) / NWV;                   // DMA pieces a wave issues per streamed tile
     char* maskb = smem + NBUF * TILE;     // one byte per key: 1 attend, 0 masked (finfo.min), 2 out of range (-inf)
     elem_t* biasb = (elem_t*)(smem + NBUF * TILE + NT * KT);
 
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
     // stream step s: s < nkt -> K tile s ; else V^T tile s - nkt.   Buffer = s & 1.
     auto issue = [&](int s) {
-        const uint32_t dst = lds_base + (EXACT ? s : (s & 1)) * TILE;
+        const uint32_t dst = lds_base + (EXACT ? s : (s % NBUF)) * TILE;
         if (s < nkt) {
             const int kt = s;
 #pragma unroll
@@ -447,20 +458,32 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) issue(NT + kt);          // V^T tiles land during phases 1 and 2
     } else {
-        issue(0);
+#pragma unroll
+        for (int s0 = 0; s0 < NBUF - 1; ++s0)
+            if (s0 < 2 * nkt) issue(s0);                         // the ring runs NBUF - 1 tiles ahead
     }
+    // Streamed tiles (not EXACT): step s = K tile s, then V tile s - nkt, in buffer s % NBUF.  Before step s is consumed: wait until only
+    // the pieces of the (at most NBUF - 2) later steps are still in flight, barrier (tile s visible to every wave, buffer (s - 1) % NBUF
+    // free), then issue step s + NBUF - 1 into that buffer.  Two buffers = one tile ahead is what ships: rings of three and four tiles
+    // (-DULL_ATTN_RING) measured 362 / 433 us against 364 on the LLaMA C4 shape (tools/attn_prefill_bench.py) -- the DMA latency is
+    // already covered by the four blocks a CU holds at 34 KB of LDS each, and a fourth buffer costs two of them.
+    auto stream_step = [&](int s) {
+        const int total = 2 * nkt;
+        const int later = min(NBUF - 2, total - 1 - s);
+        if (NBUF >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW) : "memory");
+        else if (NBUF >= 3 && later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + NBUF - 1 < total) issue(s + NBUF - 1);
+    };
 
     // ---- phase 1: S = bf16(K Q^T) (+scale, +mask), kept in registers -----------------------------------
 #pragma clang loop unroll(full)
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
-            if constexpr (!EXACT) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                issue(kt + 1);                                   // next K tile, or V^T tile 0
-            }
+            if constexpr (!EXACT) stream_step(kt);
             if (kt < nkt_w) {
-                const char* tb = smem + (EXACT ? kt : (kt & 1)) * TILE;
+                const char* tb = smem + (EXACT ? kt : (kt % NBUF)) * TILE;
 #pragma unroll
                 for (int ns = 0; ns < 4; ++ns) {
                     if (WIN16 && kt * 4 + ns >= NBLK) continue;   // blocks past the last window row hold no key
@@ -569,11 +592,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 #pragma clang loop unroll(full)
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
-            if constexpr (!EXACT) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (kt + 1 < nkt) issue(nkt + kt + 1);
-            }
+            if constexpr (!EXACT) stream_step(nkt + kt);
             if constexpr (WIN16) {
                 if (kt < nkt_w) {
                     // row-major V tile: lane (fr, fg) asks for slots 4 * fg + fr / 4 (and 16 below), head dims 16 * ds + 4 * (fr % 4) .. +3,
@@ -602,7 +621,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
             } else if constexpr (VROW) {
                 if (kt < nkt_w) {
                     const int swr = (4 * (fg & 1) + (fr >> 2)) & PM;
-                    const uint32_t vb = lds_base + (EXACT ? NT + kt : ((nkt + kt) & 1)) * TILE + (4 * fg + (fr >> 2)) * KROW + ((fr & 2) << 3) +
+                    const uint32_t vb = lds_base + (EXACT ? NT + kt : ((nkt + kt) % NBUF)) * TILE + (4 * fg + (fr >> 2)) * KROW + ((fr & 2) << 3) +
                                         ((fr & 1) << 3);
                     // four head-dim blocks at a time (8 reads in flight, 16 registers): more would cost the third wave per SIMD
 #pragma unroll
@@ -626,7 +645,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                 }
             } else
             if (kt < nkt_w) {
-                const char* tb = smem + (EXACT ? NT + kt : ((nkt + kt) & 1)) * TILE;
+                const char* tb = smem + (EXACT ? NT + kt : ((nkt + kt) % NBUF)) * TILE;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     if (2 * (kt * 2 + kk) >= NBLK) continue;
@@ -1464,7 +1483,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restri
 template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false, bool WIN16 = false, bool VROW = false>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
-    const int lds = (EXACT ? 2 * NT : 2) * TILE + NT * KT +
+    const int lds = attn_reg_nbuf<HDP, NT, NWV, EXACT, VROW>() * TILE + NT * KT +
                     (a.rel_h ? NWV * 16 * (((a.rel_mode == 2 ? 2 * (a.KH + a.KW) - 2 : a.KH + a.KW) | 1)) * 2 + 16 : 0);
     if (lds > 160 * 1024) return ULL_ERR_LDS;
     static UllOncePerDevice once;
