@@ -959,7 +959,11 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
         auto body = [&](auto with_bias, auto with_res, auto act_kind) {
             constexpr bool WB = decltype(with_bias)::value, WR = decltype(with_res)::value;
             constexpr int ACT = decltype(act_kind)::value;       // 0 none, 1 QuickGELU, 2 GELU(erf), 3 ReLU: on the rounded Linear output
-            uint4 rv[2][2][2], tc[2][2], ts[2][2];               // [buffer][h][pp] residual rows, [buffer][pp] RoPE table rows
+            // residual rows / RoPE table rows of ALL eight groups are requested up front (128 registers: the fragments are dead, the
+            // accumulators sit in AGPRs): one burst with every load in flight instead of eight round trips to HBM
+            // (the RoPE tables keep a one-group-ahead double buffer: all eight groups up front spilled 424 B per lane in that kernel)
+            constexpr int NB_ = ROPE ? 2 : 8;
+            uint4 rv[NB_][2][2], tc[NB_][2], ts[NB_][2];         // [group][h][pp] residual rows, [group][pp] RoPE table rows
             auto fetch = [&](int j, int buf) {
                 const long mc = min(mrow0 + j * 16 + fr, p.M - 1);
                 if constexpr (WR) {
@@ -978,11 +982,16 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
                     }
                 }
             };
-            fetch(0, 0);
+            if constexpr (ROPE) fetch(0, 0);
+            else if constexpr (WR) {
+#pragma clang loop unroll(full)
+                for (int j = 0; j < 8; ++j) fetch(j, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma clang loop unroll(full)
             for (int j = 0; j < 8; ++j) {
                 const int m = mrow0 + j * 16 + fr;
-                if (j + 1 < 8) fetch(j + 1, (j + 1) & 1);
+                if constexpr (ROPE) { if (j + 1 < 8) fetch(j + 1, (j + 1) & 1); }
                 uint4 o[2][2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -1019,7 +1028,7 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
                         for (int pp = 0; pp < 2; ++pp) {
                             float x0[8], x1[8], cs[8], sn[8];
                             unpack8(o[0][pp], x0); unpack8(o[1][pp], x1);
-                            unpack8(tc[j & 1][pp], cs); unpack8(ts[j & 1][pp], sn);
+                            unpack8(tc[j % NB_][pp], cs); unpack8(ts[j % NB_][pp], sn);
                             float y0[8], y1[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
@@ -1036,7 +1045,7 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
                     for (int pp = 0; pp < 2; ++pp) {
                         if constexpr (WR) {
                             float a[8], b[8];
-                            unpack8(o[h][pp], a); unpack8(rv[j & 1][h][pp], b);
+                            unpack8(o[h][pp], a); unpack8(rv[j % NB_][h][pp], b);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
                             o[h][pp] = pack8(a);
