@@ -212,6 +212,12 @@ ULL_DEV uint4 scale_q8(const uint4& v, float sc) {
 }
 
 // LDS-DMA of 64 x 16 B (see gemm_bf16.hip: issued via inline asm so hipcc does not drain it before the next ds_read).
+// the same with a wave-uniform base and a 32-bit per-lane byte offset (saddr form): the per-lane part is computed once per kernel
+ULL_DEV void glds16s(const void* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_byte_addr /* wave-uniform */) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
 ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */) {
     uint32_t keep;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);   // make uniformity provable to the compiler
@@ -335,9 +341,37 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 
     const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
     const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    // VROW flavors (LLaMA / CLIP prefill: hd == HDP, token strides that fit 32 bits): the per-lane part of every DMA source address -- row
+    // within the tile x token stride + swizzled chunk -- is the same for every tile and is computed ONCE; a tile then costs one scalar
+    // base and PPW loads.  (Recomputed per piece it was ~15 vector instructions of 64-bit address arithmetic, a quarter of the
+    // kernel's VALU work, which is what bounds it.)  Only the tile that holds the last key clamps its rows and takes the general path.
+    constexpr bool FASTDMA = VROW && (HDP / 8) % NWV == 0;
+    uint32_t kvo[FASTDMA ? 2 * PPW : 1];
+    if constexpr (FASTDMA) {
+#pragma unroll
+        for (int i0 = 0; i0 < PPW; ++i0) {
+            const int i = i0 * NWV + wave;
+            const int row = i * (64 / CPR) + lane / CPR;
+            const int ck = (lane % CPR) ^ swz<CPR>(row);
+            const int cpos = lane % CPR;
+            const int cv = ((((cpos >> 1) ^ (row & PM)) << 1) | (cpos & 1));
+            kvo[i0] = (uint32_t)(((long)row * p.k_ss + ck * 8) * 2);
+            kvo[PPW + i0] = (uint32_t)(((long)row * p.vt_ds + cv * 8) * 2);
+        }
+    }
+    const bool fast_dma_ok = FASTDMA && 64 * p.k_ss * 2 < (1L << 31) && 64 * p.vt_ds * 2 < (1L << 31);
     // stream step s: s < nkt -> K tile s ; else V^T tile s - nkt.   Buffer = s & 1.
     auto issue = [&](int s) {
         const uint32_t dst = lds_base + (EXACT ? s : (s % NBUF)) * TILE;
+        if constexpr (FASTDMA) {
+            const int kt = s < nkt ? s : s - nkt;
+            if (fast_dma_ok && kt * KT + KT <= p.Sk) {              // every row of the tile is a real key: no clamp
+                const elem_t* tb = s < nkt ? kbase + (long)kt * KT * p.k_ss : vbase + (long)kt * KT * p.vt_ds;
+#pragma unroll
+                for (int i0 = 0; i0 < PPW; ++i0) glds16s(tb, s < nkt ? kvo[i0] : kvo[PPW + i0], dst + (i0 * NWV + wave) * 1024);
+                return;
+            }
+        }
         if (s < nkt) {
             const int kt = s;
 #pragma unroll
