@@ -912,8 +912,10 @@ ULL_DEV f32x4_t w4_acc_to_vgpr(const f32x4_t& a) {
     return t;
 }
 
-template <bool SWIGLU, bool ROPE>
-ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int lane, int mrow0, int nw0) {
+// NH: 64-column halves a wave owns (2: the 4-wave kernel; 1: the 8-wave direct form, gemm256d_kernel)
+template <bool SWIGLU, bool ROPE, int NH = 2>
+ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[NH][4][8], int lane, int mrow0, int nw0) {
+    static_assert(NH == 2 || (!SWIGLU && !ROPE), "SwiGLU and RoPE pair columns across the two halves");
     // One group of 16 token rows (j) at a time, fenced by sched_barriers: left to itself the scheduler hoists every accumulator read
     // and every load of the 8 groups to the top (~250 live registers, spilled around the K-loop).  Loads of group j + 1 (residual rows,
     // RoPE table rows) are issued before the arithmetic of group j.
@@ -946,9 +948,9 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
         const bool has_bias = flags & EPI_BIAS, has_res = flags & EPI_RESID;
         const bool rope_on = ROPE && nw0 < p.rope_cols;          // the wave's 128 columns are one head
         const int nb = nw0 + 8 * fg;                             // + h*64 + pp*32: the lane's 8 columns
-        uint4 bvp[2][2];                                         // the lane's 32 bias values, packed (unpacked at use: 16 registers held, not 32)
+        uint4 bvp[NH][2];                                         // the lane's 32 bias values, packed (unpacked at use: 16 registers held, not 32)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 const int n = nb + h * 64 + pp * 32;
@@ -963,12 +965,12 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
             // accumulators sit in AGPRs): one burst with every load in flight instead of eight round trips to HBM
             // (the RoPE tables keep a one-group-ahead double buffer: all eight groups up front spilled 424 B per lane in that kernel)
             constexpr int NB_ = ROPE ? 2 : 8;
-            uint4 rv[NB_][2][2], tc[NB_][2], ts[NB_][2];         // [group][h][pp] residual rows, [group][pp] RoPE table rows
+            uint4 rv[NB_][NH][2], tc[NB_][2], ts[NB_][2];         // [group][h][pp] residual rows, [group][pp] RoPE table rows
             auto fetch = [&](int j, int buf) {
                 const long mc = min(mrow0 + j * 16 + fr, p.M - 1);
                 if constexpr (WR) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < NH; ++h)
 #pragma unroll
                         for (int pp = 0; pp < 2; ++pp) rv[buf][h][pp] = *(const uint4*)(rb + mc * p.ldr + h * 64 + pp * 32);   // (columns past N: masked at the store)
                 }
@@ -992,9 +994,9 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
             for (int j = 0; j < 8; ++j) {
                 const int m = mrow0 + j * 16 + fr;
                 if constexpr (ROPE) { if (j + 1 < 8) fetch(j + 1, (j + 1) & 1); }
-                uint4 o[2][2];
+                uint4 o[NH][2];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp) {
                         float v[8], bv[8];
@@ -1040,7 +1042,7 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[2][4][8], int 
                     }
                 }
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NH; ++h)
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp) {
                         if constexpr (WR) {
@@ -1471,6 +1473,196 @@ __global__ __launch_bounds__(512) void patchify_strip_kernel(GemmArgs p, PatchAr
     }
 }
 
+// ---- 8 waves, permuted W rows, register-direct epilogue ----------------------------------------------------------------------------
+// The 8-wave K-loop with the 4-wave kernel's W-row permutation and direct epilogue (one 64-column half per wave).  For launches whose
+// epilogue is VALU-heavy -- QuickGELU / erf-GELU -- two waves per SIMD issue the activation at the full VALU rate (one wave per SIMD gets
+// every other issue slot), which outweighs this form's 4 % slower K-loop at K = 1024 / 1280.
+__global__ __launch_bounds__(512) void gemm256d_kernel(GemmArgs p) {
+    constexpr bool SWIGLU = false, ROPE = false;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+    // Blocks [0, t_full) own one whole tile each (t_full is a multiple of the CU count, so those rounds are full); the
+    // remaining tiles -- which would otherwise occupy a few CUs for one more whole round -- are split `sk` ways along K.
+    int bid = blockIdx.x;
+    int slice = 0;
+    const bool split = bid >= p.t_full;
+    if (!split) {
+        const int nwg = p.t_full;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective for any nwg
+    } else {
+        const int r = bid - p.t_full;
+        bid = p.t_full + r / p.sk;
+        slice = r % p.sk;
+    }
+    const int per_group = p.group_m * p.nbn;
+    const int gid = bid / per_group;
+    const int first_m = gid * p.group_m;
+    const int gsz = min(p.nbm - first_m, p.group_m);
+    const int bm = first_m + (bid % per_group) % gsz;
+    const int bn = (bid % per_group) / gsz;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nk_total = p.K / BK;
+    const bool w_tiled = p.flags & EPI_W_TILED, x_tiled = p.flags & EPI_X_TILED;
+
+    // DMA: a 1-KiB piece = 8 rows x 128 B; wave w stages pieces 4w..4w+3 of X and of W.
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const elem_t* xsrc[4];
+    const elem_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + srow;
+        xsrc[i] = x_tiled ? p.X + (((long)bm * nk_total) * BM + r) * BK + schunk * 8
+                          : p.X + (long)min(m0 + r, p.M - 1) * p.ldx + schunk * 8;
+        const int wchunk = (lane & 7) ^ w4_row_swizzle<false>(r);           // permuted W rows: the W tile's own swizzle
+        wsrc[i] = w_tiled ? p.W + (((long)bn * nk_total) * BN + r) * BK + wchunk * 8
+                          : p.W + (long)min(n0 + r, p.N - 1) * p.ldw + wchunk * 8;
+    }
+    const long xstep = x_tiled ? BM * BK : BK, wstep = w_tiled ? BN * BK : BK;    // elements between consecutive K-tiles
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    const uint32_t piece_off = wave * 4 * 1024;
+    auto stage = [&](int kt) {
+        const uint32_t bx = lds_base + (kt & 1) * SLOT_BYTES + piece_off;
+        const long kox = (long)kt * xstep, kow = (long)kt * wstep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(xsrc[i] + kox, bx + i * 1024);
+            glds16(wsrc[i] + kow, bx + OP_BYTES + i * 1024);
+        }
+    };
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int swz[2];
+    swz[0] = ((0 + fg) ^ (lane & 7)) << 4;
+    swz[1] = ((4 + fg) ^ (lane & 7)) << 4;
+    int wswz[2];
+    wswz[0] = ((0 + fg) ^ (fr >> 1)) << 4;
+    wswz[1] = ((4 + fg) ^ (fr >> 1)) << 4;
+    const int xoff = (wm * 128 + fr) * (BK * 2);
+    const int woff = OP_BYTES + (wn * 64 + w4_lane_row<false>(fr)) * (BK * 2);
+    auto read_frags = [&](int kt, int kk, Frags& f) {
+        const char* base = smem + (kt & 1) * SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.w[i] = *(const uint4*)(base + wswz[kk] + woff + w4_frag_row<false>(i) * (BK * 2));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.x[j] = *(const uint4*)(base + swz[kk] + xoff + j * 16 * (BK * 2));
+    };
+
+    f32x4_t acc[1][4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[0][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int nk = p.K / BK;                                // >= 2 (host dispatch, also per K-slice)
+    if (split) {
+        const int kt0 = (int)((long)nk * slice / p.sk), kt1 = (int)((long)nk * (slice + 1) / p.sk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xsrc[i] += (long)kt0 * xstep; wsrc[i] += (long)kt0 * wstep; }
+        nk = kt1 - kt0;
+    }
+    // Same step schedule as the 4-wave kernel (see there), 64 MFMA slots per wave and step: the 12 fragment reads of the tile's second
+    // half first, barrier A, the 8 DMA pieces of tile kt+2 dealt out one per 6 slots (a burst of all 64 pieces of a CU right behind
+    // the barrier measured 3-7 % slower end to end: the memory pipe wants an even stream), barrier B with the newest pieces still in
+    // flight, then the first-half fragments of tile kt+1.  The last two steps re-fetch the last tile into a 16-KiB dump.
+#ifndef ULL_W8_BAR_A
+#define ULL_W8_BAR_A 14
+#endif
+#ifndef ULL_W8_DMA_STRIDE
+#define ULL_W8_DMA_STRIDE 6
+#endif
+#ifndef ULL_W8_BAR_B
+#define ULL_W8_BAR_B 40
+#endif
+#ifndef ULL_W8_FA_STRIDE
+#define ULL_W8_FA_STRIDE 2
+#endif
+    constexpr int W8_BAR_A = ULL_W8_BAR_A, W8_DMA_STRIDE = ULL_W8_DMA_STRIDE, W8_BAR_B = ULL_W8_BAR_B, W8_FA_STRIDE = ULL_W8_FA_STRIDE;
+    constexpr int W8_ISSUED = (W8_BAR_B - W8_BAR_A + W8_DMA_STRIDE - 1) / W8_DMA_STRIDE;
+    constexpr int W8_INFLIGHT = W8_ISSUED > 8 ? 8 : W8_ISSUED;
+    static_assert(W8_BAR_A >= 12 && W8_BAR_B >= W8_BAR_A && W8_BAR_A + 7 * W8_DMA_STRIDE < 64 && W8_BAR_B + 11 * W8_FA_STRIDE < 64, "schedule");
+    constexpr int USE_ORDER[12] = {0, 4, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11};    // w0, x0, w1..w3, x1..x7
+    auto read1 = [&](int kt, int kk, Frags& f, int r) {
+        const char* base = smem + (kt & 1) * SLOT_BYTES;
+        if (r < 4) f.w[r] = *(const uint4*)(base + wswz[kk] + woff + w4_frag_row<false>(r) * (BK * 2));
+        else f.x[r - 4] = *(const uint4*)(base + swz[kk] + xoff + (r - 4) * 16 * (BK * 2));
+    };
+    auto mma1 = [&](const Frags& f, int s) {
+        const int j = s >> 2, i = s & 3;
+#if !defined(ULL_ABL_NOMMA)
+        acc[0][i][j] = mfma16(f.w[i], f.x[j], acc[0][i][j]);
+#endif
+    };
+    stage(0);
+    stage(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 landed, tile 1 in flight
+    __builtin_amdgcn_s_barrier();
+    Frags fa, fb;                                     // fa: half 0 of the current tile, fb: half 1
+    read_frags(0, 0, fa);
+    const uint32_t dump = lds_base + LDS_BYTES;
+#pragma clang loop unroll(disable)
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool with_dma = kt + 2 < nk;
+        const int ktd = with_dma ? kt + 2 : nk - 1;
+        const long kox = (long)ktd * xstep, kow = (long)ktd * wstep;
+        const uint32_t bx = with_dma ? lds_base + (kt & 1) * SLOT_BYTES + piece_off : dump;
+        const uint32_t bw = with_dma ? bx + OP_BYTES : dump + 4096;
+#pragma clang loop unroll(full)
+        for (int s = 0; s < 64; ++s) {
+            if (s == W8_BAR_A) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (s == W8_BAR_B) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W8_INFLIGHT) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (s < 12) read1(kt, 1, fb, s);
+            if (s >= W8_BAR_B && (s - W8_BAR_B) % W8_FA_STRIDE == 0 && (s - W8_BAR_B) / W8_FA_STRIDE < 12)
+                read1(kt + 1, 0, fa, USE_ORDER[(s - W8_BAR_B) / W8_FA_STRIDE]);
+#if !defined(ULL_ABL_NODMA)
+            if (s >= W8_BAR_A && (s - W8_BAR_A) % W8_DMA_STRIDE == 0 && (s - W8_BAR_A) / W8_DMA_STRIDE < 8) {
+                const int pc = (s - W8_BAR_A) / W8_DMA_STRIDE;
+                if (pc < 4) glds16(xsrc[pc] + kox, bx + pc * 1024);
+                else glds16(wsrc[pc - 4] + kow, bw + (pc - 4) * 1024);
+            }
+#endif
+            mma1(s < 32 ? fa : fb, s & 31);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // (the dump's pieces may still be landing: they touch nothing the epilogue uses, and s_endpgm waits for them)
+
+#if defined(ULL_ABL_NOEPI)
+    if (p.M > 0) return;
+#endif
+    // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
+    if (split) {
+        float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 8; ++j)
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 4; ++i)
+                *(f32x4_t*)(slab + (wm * 128 + j * 16 + fr) * BN + wn * 64 + w4_acc_row<false>(0, i, fg)) = acc[0][i][j];
+        return;
+    }
+    {
+        const int fl = p.flags;
+        const bool direct = !(fl & (EPI_OUT_F32 | EPI_BIAS_ROUNDED)) && (!(fl & EPI_ACT_MASK) || !(fl & EPI_RESID)) && (p.ldc & 7) == 0 && (p.N & 7) == 0 &&
+                            (!(fl & EPI_RESID) || (p.ldr & 7) == 0) && !(fl & ULL_W4_FORCE_STAGED);
+        if (direct) {
+            w4_direct_epilogue<false, false, 1>(p, acc, lane, m0 + wm * 128, n0 + wn * 64);
+            return;
+        }
+    }
+    __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
+    staged_epilogue<false, 8, false, 0, false, 2, false, 1>(p, acc[0], smem + wave * (128 * 144), lane, m0 + wm * 128, n0 + wn * 64);
+}
+
+
+
 // (A v_mfma_f32_32x32x16_bf16 variant of this kernel measured 6-11 % slower in this structure and was removed;
 // numbers in profiles/r01_gemm_notes.md.)
 
@@ -1576,6 +1768,7 @@ static int gemm_device_state(int* n_cu_out) {
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)big::gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
+        (void)hipFuncSetAttribute((const void*)big::gemm256d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
         (void)hipFuncSetAttribute((const void*)big::gemm256w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big::LDS_BYTES_W4);
@@ -1665,7 +1858,11 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
                                      (ldc & 7) == 0 && (n_out_cols & 7) == 0 && (!(flags & EPI_RESID) || (ldr & 7) == 0));
         const bool fits32 = ldx < (1 << 21) && ldw < (1 << 21);
         const bool waves4 = force_waves4 || (!force_waves8 && fits32 && (direct || (K >= 3072 && c_rows_aligned)));
-        if (waves4) {
+        const bool waves8_direct = !force_waves4 && !force_waves8 && direct && !rope && !(flags & EPI_SWIGLU) && (flags & EPI_ACT_MASK) &&
+                                   ((flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT) != 3 && K < 3072;
+        if (waves8_direct) {
+            hipLaunchKernelGGL(big::gemm256d_kernel, dim3(grid), dim3(512), big::LDS_BYTES_W4, (hipStream_t)stream, a);
+        } else if (waves4) {
             if (flags & EPI_SWIGLU)
                 hipLaunchKernelGGL(big::gemm256w4_kernel<true>, dim3(grid), dim3(256), big::LDS_BYTES_W4, (hipStream_t)stream, a);
             else if (rope)
