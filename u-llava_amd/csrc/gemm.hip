@@ -913,7 +913,8 @@ ULL_DEV f32x4_t w4_acc_to_vgpr(const f32x4_t& a) {
 }
 
 // NH: 64-column halves a wave owns (2: the 4-wave kernel; 1: the 8-wave direct form, gemm256d_kernel)
-template <bool SWIGLU, bool ROPE, int NH = 2>
+// RPF: groups of residual rows requested ahead (8 = all up front; 2 = one group ahead, for callers short of registers)
+template <bool SWIGLU, bool ROPE, int NH = 2, int RPF = 8>
 ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[NH][4][8], int lane, int mrow0, int nw0) {
     static_assert(NH == 2 || (!SWIGLU && !ROPE), "SwiGLU and RoPE pair columns across the two halves");
     // One group of 16 token rows (j) at a time, fenced by sched_barriers: left to itself the scheduler hoists every accumulator read
@@ -964,7 +965,7 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[NH][4][8], int
             // residual rows / RoPE table rows of ALL eight groups are requested up front (128 registers: the fragments are dead, the
             // accumulators sit in AGPRs): one burst with every load in flight instead of eight round trips to HBM
             // (the RoPE tables keep a one-group-ahead double buffer: all eight groups up front spilled 424 B per lane in that kernel)
-            constexpr int NB_ = ROPE ? 2 : 8;
+            constexpr int NB_ = ROPE ? 2 : RPF;
             uint4 rv[NB_][NH][2], tc[NB_][2], ts[NB_][2];         // [group][h][pp] residual rows, [group][pp] RoPE table rows
             auto fetch = [&](int j, int buf) {
                 const long mc = min(mrow0 + j * 16 + fr, p.M - 1);
@@ -984,7 +985,7 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[NH][4][8], int
                     }
                 }
             };
-            if constexpr (ROPE) fetch(0, 0);
+            if constexpr (ROPE || NB_ < 8) fetch(0, 0);
             else if constexpr (WR) {
 #pragma clang loop unroll(full)
                 for (int j = 0; j < 8; ++j) fetch(j, j);
@@ -993,7 +994,7 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[NH][4][8], int
 #pragma clang loop unroll(full)
             for (int j = 0; j < 8; ++j) {
                 const int m = mrow0 + j * 16 + fr;
-                if constexpr (ROPE) { if (j + 1 < 8) fetch(j + 1, (j + 1) & 1); }
+                if constexpr (ROPE || NB_ < 8) { if (j + 1 < 8) fetch(j + 1, (j + 1) % NB_); }
                 uint4 o[NH][2];
 #pragma unroll
                 for (int h = 0; h < NH; ++h)
@@ -1342,7 +1343,14 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
 // 1519 vs 1461 us, gate/up+SwiGLU 2568 vs 2538, o+residual 524 vs 518, down 1294 vs 1271, K = 1280 shapes equal: 1-4 % SLOWER again.
 // 256 accumulator clears, the re-read of the first fragments and the item decode cost what the hidden prologue saves, and the wait
 // for the epilogue's stores moves to barrier B of the next item's first step instead of disappearing.  Removed; the block hand-over
-// of the hardware stays.)
+// of the hardware stays.
+// A fourth build fixed the one real flaw of the third -- stores and loads share the vmcnt counter and complete out of order with respect
+// to each other, so the next item's first step had been waiting for the epilogue's 32 stores: the item now drained its prefetched K-tiles
+// BEFORE issuing the stores and the next first step passed its barrier without a vmcnt wait -- and measured the same: SAM qkv 267.6 vs
+// 270.7 us, CLIP qkv 111 vs 115, gate/up 2558 vs 2519, down 1283 vs 1251.  The K-loop-only ablation explains it: what a round of tiles
+// pays behind its last MFMA is not instructions but a 33-MB store burst from 256 CUs that finish together (~5 us at HBM write rate);
+// in flight under the next item's loop it delays that loop's operand loads instead.  Only CUs that are OUT OF PHASE would hide it
+// (a stream-K split of every CU's first tile), and the fp32 slabs + finalize that costs are about what it would save.)
 
 // ---- fused ViT patchify, one round of strips (round 3) -------------------------------------------------------------------------
 // The 128x128 form above runs B = 32 at 336^2 (M = 18432 patches, N = 1024, K' = 704) as 1152 tiles = 2.25 rounds of two blocks per CU and
