@@ -189,23 +189,6 @@ def _cpu_model_name():
     return platform.processor() or "unknown"
 
 
-def _pick_threads():
-    """thread count on a probe matmul (256-thread hosts are often slower with every hardware thread in use); returns (n, table)."""
-    probe_x, probe_w = torch.randn(643, 4096).to(torch.bfloat16), torch.randn(4096, 4096).to(torch.bfloat16)
-    best_n, best_t, table = 1, float("inf"), {}
-    for n in sorted({min(os.cpu_count(), c) for c in (8, 32, 64, 128, os.cpu_count())}):
-        torch.set_num_threads(n)
-        torch.nn.functional.linear(probe_x, probe_w)
-        t0 = time.perf_counter()
-        torch.nn.functional.linear(probe_x, probe_w)
-        dt = time.perf_counter() - t0
-        table[n] = round(dt * 1e3, 2)
-        if dt < best_t:
-            best_n, best_t = n, dt
-    torch.set_num_threads(best_n)
-    return best_n, table
-
-
 def _c1_state_dict(device, n_llama=32, n_clip=24, P=256, V=32011):
     """Random-init weights of ViT-L/14-224 + LLaMA-7B in the reference's state-dict layout, generated on the GPU (seconds, instead of
     minutes of host RNG: BASELINE.md section 3 "do not use HF random init") and copied to host memory as bf16 (13.9 GB)."""
@@ -248,10 +231,25 @@ def cpu_baseline(device, c4_image=336, c4_prompt=64):
     3 timed forwards, median; thread count and CPU model stated.  Secondary record: the same oracle at the C4 shape (the GPU headline's
     shape) from ONE and TWO CLIP / LLaMA layers, extrapolated linearly in layer count, with the 1- vs 2-layer check of that linearity."""
     from oracle import ullava_oracle as O
-    best_n, probe = _pick_threads()
     t_build = time.perf_counter()
     sd = _c1_state_dict(device)
     t_build = time.perf_counter() - t_build
+    # thread count: whatever runs TWO LLaMA layers of the oracle itself fastest (a bare matmul probe picked 128 threads on a 256-thread
+    # EPYC where the whole forward then ran 2.5x slower than on 64: the oracle is many mid-sized ops, not one GEMM)
+    probe_emb = torch.randn(1, 291, 4096).to(torch.bfloat16)
+    probe_cfg = dict(hidden_size=4096, num_hidden_layers=2, num_attention_heads=32, rms_norm_eps=1e-6, rope_theta=10000.0)
+    best_n, best_t, probe = 1, float("inf"), {}
+    with torch.no_grad():
+        for n in sorted({min(os.cpu_count(), c) for c in (8, 16, 32, 64, 128, os.cpu_count())}):
+            torch.set_num_threads(n)
+            O.llama_model(sd, probe_cfg, probe_emb)
+            t0 = time.perf_counter()
+            O.llama_model(sd, probe_cfg, probe_emb)
+            dt = time.perf_counter() - t0
+            probe[n] = round(dt * 1e3, 1)
+            if dt < best_t:
+                best_n, best_t = n, dt
+    torch.set_num_threads(best_n)
     V, D = sd["lm_head.weight"].shape
     vcfg = dict(hidden_size=1024, num_attention_heads=16, num_hidden_layers=24, intermediate_size=4096, image_size=224, patch_size=14,
                 num_channels=3, layer_norm_eps=1e-5)
@@ -296,7 +294,7 @@ def cpu_baseline(device, c4_image=336, c4_prompt=64):
                 host_threads=os.cpu_count(), seconds_per_image=round(t_c1, 3), logits_finite=finite,
                 sample=f"oracle (torch-CPU bf16 restatement of the reference path), WHOLE C1 forward: 1 image 224x224 + 32-token prompt, S=291, "
                        f"ViT-L/14 (23 layers used) + projector + 32 LLaMA-7B layers + lm_head (V={V}), random-init weights, 1 warm-up + 3 timed "
-                       f"forwards, median {t_c1:.2f} s; {best_n} of {os.cpu_count()} host threads (fastest on a probe matmul: {probe} ms); "
+                       f"forwards, median {t_c1:.2f} s; {best_n} of {os.cpu_count()} host threads (fastest on two LLaMA layers of the oracle: {probe} ms); "
                        f"weights generated on `{device.type}` and held in host memory, {t_build:.0f} s (not timed)",
                 c4_shape_extrapolated=dict(value=round(1.0 / c4_s, 4), unit="images/sec", seconds_per_image=round(c4_s, 3),
                                            sample=f"same oracle, C4 shape ({c4_image}x{c4_image}, S={S4}): (2-layer - 0-layer)/2 per CLIP / LLaMA "
