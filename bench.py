@@ -474,14 +474,17 @@ def workload_step(name, dev, rank, batch_override=None, train_config="full"):
                 trainable.append(p_)
         desc += f", --train-config {train_config} ({sum(p_.numel() for p_ in trainable) / 1e9:.2f} G trainable parameters), batch {batch}/GPU"
         flops_img *= 3 if train_config == "full" else 2.0        # forward + dX (+ dW for every Linear with the full set)
+        # the optimizer step is part of a training step: ZeRO-2 AdamW (configs/deepspeed/bf16_zero2.json; lr / weight decay of
+        # configs/train/ullava.yaml:141,156 resp. ullava_lora.yaml), gradient reduce-scatter and parameter all-gather inside it
+        O_ = importlib.import_module("u-llava_amd.optim")
+        opt = O_.ShardedAdamW(trainable, lr=2e-4 if train_config == "lora" else 2e-5, weight_decay=0.0, max_grad_norm=1.0)
+        desc += f", AdamW with ZeRO-2 sharded fp32 state ({opt.state_bytes() / 2**30:.1f} GiB on this rank)"
 
         def step():
-            for p_ in trainable:
-                p_.grad = None
+            opt.zero_grad()
             out = model.forward(input_ids=ids, attention_mask=mask, images=vis, labels=labels)
             out.loss.backward()
-            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-                Dm.allreduce_gradients(trainable)
+            opt.step()
             return out.loss
     elif video:
         def step():

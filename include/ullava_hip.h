@@ -392,6 +392,16 @@ int ull_box_losses_bwd_f32(const void* pred, int pred_dtype, const void* gt, int
 int ull_bilinear_bwd_f32(const void* dout, void* din, int64_t in_img_stride, int64_t in_row_stride, int64_t in_h, int64_t in_w, int64_t n,
                          int64_t out_h, int64_t out_w, void* stream);
 
+/* AdamW on a shard of the flattened parameters (the optimizer transformers.Trainer builds for train_ullava.py:273-293, under ZeRO stage 2
+ * with bf16: configs/deepspeed/bf16_zero2.json): fp32 master / first / second moments updated in place, torch's single-tensor AdamW
+ * arithmetic in fp32 (decoupled weight decay, bias correction with `step` = the count after this update).  grad (dtype code ULL_DT_*) is
+ * multiplied by grad_scale first; param_out (dtype code) receives the updated parameters, or NULL. */
+int ull_adamw_step_f32(void* master, void* m, void* v, const void* grad, int grad_dtype, void* param_out, int param_dtype, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* out[0] (fp32 on the device, caller-zeroed) += sum of squares of n gradient elements: the local part of clip_grad_norm_'s total norm. */
+int ull_sumsq_f32(const void* g, int grad_dtype, int64_t n, void* out, void* stream);
+
 /* ==== BEGIN fp16 twins (generated by tools/gen_header_f16.py) ==== */
 /* IEEE binary16 build of every dtype-dependent entry point: same arguments, layouts, flags and rounding points as the *_bf16
  * function of the same name; every 16-bit element is an fp16 instead of a bf16 (the reference's `--dtype fp16`,

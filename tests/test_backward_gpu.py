@@ -492,3 +492,48 @@ def test_lora_adapters_on_the_training_path():
     assert 0.70 < float(kept.float().mean()) < 0.80 and torch.allclose(y[kept].float(), torch.full((), 1 / 0.75).to(torch.bfloat16).float())
     y.sum().backward()
     assert torch.equal(x.grad != 0, kept)
+
+
+def test_sharded_adamw_matches_torch_adamw_on_fp32_masters():
+    """optim.ShardedAdamW (ZeRO-2's cycle at world size 1: flat gradient buffer -> ull_adamw_step_f32 on fp32 master / moments -> 16-bit
+    parameters) against torch.optim.AdamW run on fp32 copies of the same parameters with the same gradients: four steps with weight decay
+    and with gradient clipping active; the fp32 masters agree to fp32 rounding, the 16-bit parameters are the rounded masters, a parameter
+    without a gradient counts as zero, and parameters that alias a shared q|k|v buffer are updated through it."""
+    O_, M_ = pkg("optim"), pkg("modeling_core")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(257, 64), (64,), (33, 128), (5,)]
+    ps = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.1).to(torch.bfloat16).to(DEV)) for s in shapes]
+    holder = torch.nn.Module()
+    for n_ in ("q_proj", "k_proj", "v_proj"):
+        lin = M_.Linear(32, 64, bias=False, device=DEV)
+        lin.weight.data.copy_((torch.randn(64, 32, generator=g) * 0.1).to(torch.bfloat16))
+        lin.weight.requires_grad = True
+        setattr(holder, n_, lin)
+    packed, ws = M_.UllavaCoreForCausalLM._alias_pack(holder, ("q_proj", "k_proj", "v_proj"), "_qkv_pack")
+    params = ps + list(ws)
+    refs = [torch.nn.Parameter(p.detach().float().cpu().clone()) for p in params]
+    lr, wd, clip = 1e-2, 0.01, 0.5
+    opt = O_.ShardedAdamW(params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, max_grad_norm=clip, bucket_bytes=20000)
+    assert len(opt.buckets) >= 2
+    ref_opt = torch.optim.AdamW(refs, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, foreach=False)
+    for step in range(4):
+        for i, (p, r) in enumerate(zip(params, refs)):
+            if i == 1 and step == 2:
+                p.grad, r.grad = None, torch.zeros_like(r)                    # a parameter this step's batch never touched
+                continue
+            gr = (torch.randn(p.shape, generator=g) * (3.0 if step == 1 else 0.05)).to(torch.bfloat16)
+            p.grad, r.grad = gr.to(DEV), gr.float()
+        want_norm = float(torch.nn.utils.clip_grad_norm_(refs, clip))
+        ref_opt.step()
+        got_norm = opt.step()
+        assert abs(got_norm - want_norm) <= 1e-3 * want_norm, (step, got_norm, want_norm)
+        o = 0
+        for b in opt.buckets:
+            oo = 0
+            for p in b["params"]:
+                r = refs[[id(q) for q in params].index(id(p))]
+                mst = b["master"][oo:oo + p.numel()].cpu().view_as(r)
+                assert float((mst - r.detach()).abs().max()) <= 2e-6 * max(1.0, float(r.detach().abs().max())) + 1e-7, (step, tuple(p.shape))
+                assert torch.equal(p.detach().cpu(), mst.to(torch.bfloat16))                # the 16-bit parameter IS the rounded master
+                oo += p.numel()
+    assert torch.equal(packed[64:128], holder.k_proj.weight.detach())                          # the shared buffer moved with the parameters

@@ -142,6 +142,20 @@ for p, b in zip(params, before):
         assert p.grad is not None and float(p.grad.abs().max()) == 0.0
     else:
         assert torch.equal(p.grad, b), "world-1 direct exchange must be the identity"
+# ZeRO-2 optimizer cycle through RCCL at world 1 (all_to_all_single -> sum_slabs -> AdamW on the shard -> all_gather_into_tensor): must equal
+# the collective-free path bit for bit
+O_ = importlib.import_module("u-llava_amd.optim")
+def run(force):
+    gg = torch.Generator(device="cuda").manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev, generator=gg).to(torch.bfloat16)) for s in [(300, 41), (77,), (64, 64)]]
+    opt = O_.ShardedAdamW(ps, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, bucket_bytes=30000, force_collectives=force)
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn(p.shape, device=dev, generator=gg).to(torch.bfloat16)
+        opt.step()
+    return [p.detach().clone() for p in ps]
+a_, b_ = run(True), run(False)
+assert all(torch.equal(x, y) for x, y in zip(a_, b_)), "ZeRO-2 step through RCCL at world 1 differs from the local path"
 torch.cuda.synchronize()
 dist.barrier()
 dist.destroy_process_group()

@@ -81,6 +81,8 @@ SIGNATURES = {
     "ull_mask_iou_counts": [_ptr, _ptr, _i64, _i64, _i32, _ptr, _ptr],
     "ull_mask_loss_sums_f32": [_ptr, _ptr, _i64, _i64, _f32, _ptr, _ptr],
     "ull_box_losses_f32": [_ptr, _i32, _ptr, _i64, _ptr, _ptr],
+    "ull_adamw_step_f32": [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _i32, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _ptr],
+    "ull_sumsq_f32": [_ptr, _i32, _i64, _ptr, _ptr],
 }
 
 # every dtype-dependent entry point exists twice: ull_*_bf16 (bfloat16 build) and ull_*_f16 (IEEE binary16 build), same signature

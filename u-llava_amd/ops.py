@@ -919,3 +919,29 @@ def sam_i2t_attention_ln(keys, pos, kproj, vproj, a, ln, late_bias_q: bool, eps:
     _lib.call("ull_sam_i2t_attention_ln_" + _SFX[keys.dtype], _p(keys), _p(pos), _p(kproj), _p(vproj), n, T, P, *_lin_ptrs(a.q_proj, a.out_proj),
               int(late_bias_q), _p(ln.weight), _p(ln.bias), float(eps), _p(out), _stream())
     return out
+
+
+# ---- optimizer kernels (csrc/optim.hip; host: optim.py) --------------------------------------------------------------------------------
+def adamw_step(master: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Tensor, param_out: Optional[torch.Tensor], lr: float,
+               beta1: float, beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0) -> None:
+    """One AdamW step on a flat shard: master / m / v fp32 (in place), grad any of fp32 / bf16 / fp16, param_out 16-bit or fp32 or None."""
+    for t, n in ((master, "master"), (m, "m"), (v, "v")):
+        _chk(t, n, torch.float32)
+    if not grad.is_cuda or grad.dtype not in DT_CODE or not grad.is_contiguous() or grad.numel() != master.numel():
+        raise RuntimeError("u-llava_amd.adamw_step: grad must be a contiguous GPU tensor of the shard's size (fp32 / bf16 / fp16)")
+    pd = 0
+    if param_out is not None:
+        if not param_out.is_cuda or param_out.dtype not in DT_CODE or not param_out.is_contiguous() or param_out.numel() != master.numel():
+            raise RuntimeError("u-llava_amd.adamw_step: param_out must be a contiguous GPU tensor of the shard's size")
+        pd = DT_CODE[param_out.dtype]
+    _lib.call("ull_adamw_step_f32", _p(master), _p(m), _p(v), _p(grad), DT_CODE[grad.dtype], _p(param_out), pd, master.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+
+
+def sumsq(g: torch.Tensor, out: torch.Tensor) -> None:
+    """out[0] (fp32) += sum of squares of g."""
+    _chk(out, "out", torch.float32)
+    if not g.is_cuda or g.dtype not in DT_CODE or not g.is_contiguous():
+        raise RuntimeError("u-llava_amd.sumsq: contiguous GPU tensor (fp32 / bf16 / fp16) required")
+    if g.numel():
+        _lib.call("ull_sumsq_f32", _p(g), DT_CODE[g.dtype], g.numel(), _p(out), _stream())
