@@ -361,9 +361,13 @@ class UllavaCoreForCausalLM(nn.Module):
         return tuple(p_._version for l in self.model.layers for t in ("q_proj", "k_proj", "v_proj") if hasattr(getattr(l.self_attn, t), "lora_A")
                      for p_ in (getattr(l.self_attn, t).lora_A.weight, getattr(l.self_attn, t).lora_B.weight))
 
-    def _pk(self):
-        if self._packed is None or self._packed.get("lora_versions") != self._lora_versions():
-            self.pack_weights()              # (adapters attached and changed since the pack was made: an optimizer step bumps ._version)
+    def _pk(self, for_llama: bool = False):
+        """The packed weights.  for_llama (the inference LLaMA path): with un-merged LoRA adapters attached the q|k|v packs hold W + s B A,
+        so they are rebuilt when the adapters have changed since (an optimizer step bumps ._version).  The CLIP tower asks without the
+        check: a LoRA TRAINING forward needs only the CLIP packs, and re-packing 13.5 GB of LLaMA weights on every step because the
+        adapters moved cost 94 ms of device copies per step (profile of bench.py --workload train --train-config lora)."""
+        if self._packed is None or (for_llama and self._packed.get("lora_versions") != self._lora_versions()):
+            self.pack_weights()
         return self._packed
 
     # -- CLIP ----------------------------------------------------------------------------------------------
@@ -647,7 +651,7 @@ class UllavaCoreForCausalLM(nn.Module):
         """LlamaModel.forward.  cache=None: plain prefill.  cache empty: prefill that also fills the cache.  cache filled:
         incremental step(s) -- the new tokens' q attend to cached K / V^T plus their own."""
         cfg = self.config
-        pk = self._pk()
+        pk = self._pk(for_llama=True)
         B, S, D = inputs_embeds.shape
         H = cfg.num_attention_heads
         hd = D // H
