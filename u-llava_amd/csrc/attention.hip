@@ -97,9 +97,20 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
 
 // The same for a quad whose four keys are all attendable for every lane of the wave (no padding, below the causal diagonal, no
 // bias): only the scale + the two roundings remain.  ~85 % of the LLaMA / CLIP score quads take this path.
+// LLaMA / CLIP (S * scale): rnd(acc) two at a time through one packed convert, the scale as one packed multiply, and -- rounding to 16
+// bits is monotone, so max_i rnd(x_i) = rnd(max_i x_i) -- the row maximum is fed with the UNROUNDED products (one v_max3 per pair instead
+// of two unpacks and two v_max); the caller rounds the row maximum once.  11 vector instructions per quad instead of 26, same bits.
 template <int FL>
 ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& lo, uint32_t& hi, float* row_max = nullptr) {
-    const bool do_mul = FL == FL_RUNTIME ? p.scale_mode == 1 : (FL == FL_LLAMA || FL == FL_CLIP);
+    if constexpr (FL == FL_LLAMA || FL == FL_CLIP) {
+        const uint32_t a01 = pack2e(acc[0], acc[1]), a23 = pack2e(acc[2], acc[3]);
+        const f32x2_t x01 = f32x2_t{pk_lo(a01), pk_hi(a01)} * p.scale, x23 = f32x2_t{pk_lo(a23), pk_hi(a23)} * p.scale;
+        if (row_max) *row_max = fmaxf(fmaxf(fmaxf(*row_max, x01.x), x01.y), fmaxf(x23.x, x23.y));
+        lo = pack2e(x01.x, x01.y);
+        hi = pack2e(x23.x, x23.y);
+        return;
+    }
+    const bool do_mul = FL == FL_RUNTIME ? p.scale_mode == 1 : false;
     const bool do_div = FL == FL_RUNTIME ? p.scale_mode == 2 : (FL == FL_SAM_DEC);
     float o[4];
 #pragma unroll
@@ -215,8 +226,9 @@ ULL_DEV uint4 scale_q8(const uint4& v, float sc) {
 // the same with a wave-uniform base and a 32-bit per-lane byte offset (saddr form): the per-lane part is computed once per kernel
 ULL_DEV void glds16s(const void* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_byte_addr /* wave-uniform */) {
     uint32_t keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);   // make uniformity provable to the compiler
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
 }
 ULL_DEV void glds16(const void* gsrc, uint32_t lds_byte_addr /* wave-uniform */) {
     uint32_t keep;
@@ -298,8 +310,8 @@ constexpr int attn_reg_nbuf() {
 //   VROW (LLaMA / CLIP prefill): the V tiles are DMA'd ROW-major from V itself ([64 keys][head dim], like the K tiles) and the V^T
 //   operand of P*V comes out of them through ds_read_b64_tr_b16: no V^T pass in front of the attention.
 template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false, bool VROW = false>
-__global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)) ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];     // (256: the V fragment addresses below XOR bits 5..7)
     static_assert(!WIN16 || (EXACT && FL == FL_SAM_ENC && NT == 4), "WIN16 is the 14 x 14 window form of the exact kernel");
     static_assert(!VROW || (!WIN16 && (FL == FL_LLAMA || FL == FL_CLIP) && HDP >= 64), "VROW: flavors that pin hd = HDP");
     constexpr int PM = HDP / 16 >= 8 ? 7 : HDP / 16 - 1;      // VROW: XOR mask of the 32-byte pair index (pairs per row - 1, at most 7)
@@ -442,9 +454,15 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     if constexpr (EXACT) {                // all K tiles in flight while Q / mask / bias tables are prepared
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) issue(kt);
+    } else {
+        // the ring runs NBUF - 1 tiles ahead; its first tiles are requested BEFORE the Q rows so that a block pays one memory latency at its
+        // start, not two in a row (a block lives for ~12 tile steps: the start-up is a visible share of it)
+#pragma unroll
+        for (int s0 = 0; s0 < NBUF - 1; ++s0)
+            if (s0 < 2 * nkt) issue(s0);
     }
 
-    // ---- Q fragments + key-mask bytes (ordinary loads; drained before any DMA is issued) ---------------
+    // ---- Q fragments + key-mask bytes (ordinary loads, drained together with the first DMA'd tiles) -------
     uint4 qf[NKS];
     const int qi = q0 + wave * 16 + fr;
     long q_tok = 0;                       // WIN16: this lane's query token, -1 = a padding position
@@ -479,6 +497,11 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = scale_q8(qf[ks], p.q_scale);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The compiler does not see the wait above (nor the DMA's share of vmcnt): left alone it guards the first use of the Q fragments in
+    // EVERY tile (the tiles sit behind run-time branches) with its own s_waitcnt vmcnt(0) -- which also waits for the tile that was
+    // just requested, i.e. no DMA ever overlapped with the MFMAs.  Redefining the fragments here ends its bookkeeping of those loads.
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
     float wv[4] = {0.f, 0.f, 0.f, 0.f};   // WIN16: rel_w of this lane's four window columns kw = 4 * fg + r (same for every block)
     float mrow = -INFINITY;               // running maximum of this lane's scores
     if constexpr (WIN16) {
@@ -487,14 +510,22 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
     }
 
     uint32_t sp[NT][8];                   // [tile][2*ns + half]: bf16 pairs for keys kt*64 + ns*16 + 4*fg + {0,1 | 2,3}
+    // LDS fragment addressing, per lane and ONCE: the K fragment of k-step ks sits at kfo[ks] inside rows fr, fr + 16, ... of a tile (the
+    // swizzle term of row 16 * ns + fr does not depend on ns), so tile, buffer and ns are immediate offsets of the ds_read; the V fragment
+    // of head-dim block d sits at (tile base + vfo) ^ (d << 5).  Recomputed per read these were 3 vector instructions each, 48 + 48 per
+    // key tile of a kernel that is bound by its vector-issue slots.
+    uint32_t kfo[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        kfo[ks] = fr * KROW + (((ks * 4 + fg) ^ swz<CPR>(fr)) << 4);
+        asm volatile("" : "+v"(kfo[ks]));
+    }
+    uint32_t vfo = (4 * fg + (fr >> 2)) * KROW + ((fr & 2) << 3) + ((fr & 1) << 3) + (((4 * (fg & 1) + (fr >> 2)) & PM) << 5);
+    asm volatile("" : "+v"(vfo));
     if constexpr (EXACT) {
         __builtin_amdgcn_s_barrier();     // (vmcnt(0) above) every K tile, the mask bytes and the bias rows are in LDS
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) issue(NT + kt);          // V^T tiles land during phases 1 and 2
-    } else {
-#pragma unroll
-        for (int s0 = 0; s0 < NBUF - 1; ++s0)
-            if (s0 < 2 * nkt) issue(s0);                         // the ring runs NBUF - 1 tiles ahead
     }
     // Streamed tiles (not EXACT): step s = K tile s, then V tile s - nkt, in buffer s % NBUF.  Before step s is consumed: wait until only
     // the pieces of the (at most NBUF - 2) later steps are still in flight, barrier (tile s visible to every wave, buffer (s - 1) % NBUF
@@ -526,7 +557,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
                         if (ks * 32 < hd) {                    // k-steps that are pure head-dim padding are skipped
-                            const uint4 kf = *(const uint4*)(tb + row * KROW + (((ks * 4 + fg) ^ swz<CPR>(row)) << 4));
+                            const uint4 kf = *(const uint4*)(tb + ns * 16 * KROW + kfo[ks]);
                             acc = mfma16(kf, qf[ks], acc);
                         }
                     }
@@ -561,7 +592,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 
     // ---- phase 2: exact fp32 row softmax over the bf16 scores, P = bf16(softmax) (registers only) --------
     {
-        float m = mrow;
+        float m = rnd(mrow);                  // (score_quad_clean feeds it unrounded products: see the note there)
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float sum = 0.f;
@@ -590,8 +621,10 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (kt * 4 + i / 2 >= NBLK) continue;
-                    sum += __expf(pk_lo(sp[kt][i]) - m);
-                    sum += __expf(pk_hi(sp[kt][i]) - m);
+                    // __expf(x) = v_exp_f32(x * log2(e)), written out so that the subtraction and the multiply pair up (v_pk_*_f32)
+                    const f32x2_t t = (f32x2_t{pk_lo(sp[kt][i]), pk_hi(sp[kt][i])} - m) * 1.4426950408889634f;
+                    sum += __builtin_amdgcn_exp2f(t.x);
+                    sum += __builtin_amdgcn_exp2f(t.y);
                 }
                 if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
@@ -604,9 +637,9 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (kt * 4 + i / 2 >= NBLK) continue;
-                    const float lo = __expf(pk_lo(sp[kt][i]) - m) * inv;
-                    const float hi = __expf(pk_hi(sp[kt][i]) - m) * inv;
-                    sp[kt][i] = pack2e(lo, hi);
+                    const f32x2_t t = (f32x2_t{pk_lo(sp[kt][i]), pk_hi(sp[kt][i])} - m) * 1.4426950408889634f;
+                    const f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * inv;
+                    sp[kt][i] = pack2e(e.x, e.y);
                 }
                 if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
@@ -654,9 +687,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                 }
             } else if constexpr (VROW) {
                 if (kt < nkt_w) {
-                    const int swr = (4 * (fg & 1) + (fr >> 2)) & PM;
-                    const uint32_t vb = lds_base + (EXACT ? NT + kt : ((nkt + kt) % NBUF)) * TILE + (4 * fg + (fr >> 2)) * KROW + ((fr & 2) << 3) +
-                                        ((fr & 1) << 3);
+                    const uint32_t vb = lds_base + (EXACT ? NT + kt : ((nkt + kt) % NBUF)) * TILE + vfo;
                     // four head-dim blocks at a time (8 reads in flight, 16 registers): more would cost the third wave per SIMD
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
@@ -666,7 +697,7 @@ __global__ __launch_bounds__(NWV * 64, EXACT ? 4 : 2) void attn_reg_kernel(AttnA
                             u32x2_t va[4], vc[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const uint32_t ad = vb + (((d0 + j) ^ swr) << 5);
+                                const uint32_t ad = vb ^ ((d0 + j) << 5);
                                 if (kk == 0) { va[j] = lds_tr_b64<0>(ad); vc[j] = lds_tr_b64<16 * KROW>(ad); }
                                 else { va[j] = lds_tr_b64<32 * KROW>(ad); vc[j] = lds_tr_b64<48 * KROW>(ad); }
                             }
