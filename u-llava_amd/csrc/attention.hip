@@ -574,6 +574,13 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
                         __builtin_amdgcn_sched_barrier(0);
                         continue;
                     }
+                    if constexpr (FL == FL_LLAMA || FL == FL_CLIP) {
+                        // a whole tile of real keys, no key mask, entirely below the diagonal for each of the wave's queries: nothing to look up
+                        if (p.key_mask == nullptr && kt * KT + KT <= p.Sk && (FL != FL_LLAMA || kt * KT + KT - 1 <= q0 + wave * 16 + koff)) {
+                            score_quad_clean<FL>(p, acc, sp[kt][ns * 2], sp[kt][ns * 2 + 1], &mrow);
+                            continue;
+                        }
+                    }
                     const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
                     const int j0 = kt * KT + ns * 16 + fg * 4;
                     bool fast = false;
