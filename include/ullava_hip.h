@@ -94,6 +94,15 @@ int ull_gemm_skinny_bf16(const void* X, int64_t ldx, const void* W, int64_t ldw,
 int ull_gemv_rmsnorm_bf16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C, int64_t ldc,
                           const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 
+/* Decode-step q|k|v projection with RoPE and the KV-cache append in its epilogue (M = B * S <= 4 tokens): one launch for
+ * hf LlamaAttention.forward's q/k/v_proj + apply_rotary_pos_emb + cache update (models/ullava_core.py:357-395 feeds one token per step).
+ * W = [3 * H * hd, K] (q | k | v rows); norm_w (may be null) = the preceding LlamaRMSNorm; cos_tab / sin_tab = ull_rope_table_bf16 of the
+ * step's positions [B * S, hd / 2].  Q_out [B * S, H * hd] (row pitch ldq) receives the rotated queries, k_cache[b, h, past + s, :] the
+ * rotated keys, vt_cache[b, h, :, slot(past + s)] the values.  Same bits as ull_gemv_rmsnorm_bf16 followed by ull_rope_append_bf16. */
+int ull_gemv_qkv_rope_append_bf16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* Q_out, int64_t ldq,
+                                  const void* cos_tab, const void* sin_tab, void* k_cache, void* vt_cache, int64_t B, int64_t S, int64_t H,
+                                  int64_t hd, int64_t K, int64_t smax, int64_t past, void* stream);
+
 /* y = w * bf16(x * rsqrt(mean(x^2) + eps)).  hf: LlamaRMSNorm.forward. */
 int ull_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
 
@@ -412,6 +421,7 @@ int ull_rope_table_f16(const void* positions, const void* inv_freq, int64_t toke
 int ull_gemv_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 int ull_gemm_skinny_f16(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
 int ull_gemv_rmsnorm_f16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* stream);
+int ull_gemv_qkv_rope_append_f16(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* Q_out, int64_t ldq, const void* cos_tab, const void* sin_tab, void* k_cache, void* vt_cache, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t K, int64_t smax, int64_t past, void* stream);
 int ull_rmsnorm_f16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
 int ull_shifted_cross_entropy_f16(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, void* out, void* stream);
 int ull_layernorm_f16(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);

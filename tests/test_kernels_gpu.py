@@ -239,6 +239,34 @@ def test_rope_append_matches_rope_plus_copies():
     assert bool((vtc[:, :, :, cols.to(DEV)] == 7.0).all())
 
 
+@pytest.mark.parametrize("B,S,H,hd,K,dt", [(1, 1, 32, 128, 4096, BF), (2, 2, 4, 128, 512, BF), (3, 1, 6, 64, 256, torch.float16),
+                                            (1, 3, 5, 32, 160, BF)])
+def test_qkv_gemv_with_fused_rope_append_is_bit_equal(B, S, H, hd, K, dt):
+    """decode step: ull_gemv_qkv_rope_append (RMSNorm prologue, RoPE + KV-cache append in the epilogue) == the three-launch path
+    (linear with fused RMSNorm, rope_append): queries, K-cache rows and V^T-cache columns bit for bit; nothing else in the caches touched."""
+    ops, M_ = pkg("ops"), pkg("modeling_core")
+    D, T, smax, past = H * hd, B * S, 128, 45
+    x = _rand(T, K, seed=47).to(dt).to(DEV)
+    w = _rand(3 * D, K, seed=48, scale=K ** -0.5).to(dt).to(DEV)
+    ln = (1.0 + 0.1 * _rand(K, seed=49).float()).to(dt).to(DEV)
+    pos = (torch.arange(S)[None] + past + torch.arange(B)[:, None] * 3).reshape(-1).to(DEV)
+    inv = (1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(DEV)
+    for rms in (ln, None):
+        kc0 = torch.full((B, H, smax, hd), 7.0, device=DEV, dtype=dt)
+        vt0 = torch.full((B, H, hd, smax), 7.0, device=DEV, dtype=dt)
+        qkv = ops.linear(x, w, rms_w=rms, rms_eps=1e-5) if rms is not None else ops.linear(x, w)
+        ops.rope_append(qkv, 3 * D, pos, inv, B, S, H, hd, kc0, vt0, smax, past)
+        kc1, vt1 = torch.full_like(kc0, 7.0), torch.full_like(vt0, 7.0)
+        cs, sn = ops.rope_table(pos, inv, dt)
+        q = ops.linear_qkv_rope_append(x, w, cs, sn, B, S, H, hd, kc1, vt1, smax, past, rms_w=rms, rms_eps=1e-5)
+        assert torch.equal(q, qkv[:, :D]), "rotated queries"
+        assert torch.equal(kc1, kc0), "K cache"
+        assert torch.equal(vt1, vt0), "V^T cache"
+        assert bool((kc1[:, :, past:past + S] != 7.0).any()) and bool((vt1[:, :, :, M_.KVCache.vt_slot(past)] != 7.0).any())
+    with pytest.raises(RuntimeError):
+        ops.linear_qkv_rope_append(x, w, cs, sn, B, S, H, hd, kc1, vt1, smax, smax, rms_w=None)       # past + S > smax
+
+
 def _attn_ref(q, k, v, scale, causal, key_mask):
     """eager attention on bf16 tensors: q,k,v [B,H,S,hd]."""
     w = torch.matmul(q, k.transpose(2, 3)) * scale

@@ -50,6 +50,8 @@ SIGNATURES = {
     "ull_dropout_apply_bf16": [_ptr, _ptr, _ptr, _i64, _f32, _ptr],
     "ull_gemm_skinny_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
     "ull_gemv_rmsnorm_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr],
+    "ull_gemv_qkv_rope_append_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                      _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "ull_shifted_cross_entropy_bf16": [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr],
     "ull_layernorm_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],

@@ -12,7 +12,19 @@ namespace {
 
 constexpr int EPI_BIAS = 1, EPI_ACT_SHIFT = 1, EPI_ACT_MASK = 3 << 1, EPI_RESID = 8, EPI_SWIGLU = 16, EPI_OUT_F32 = 32;
 constexpr int EPI_BIAS_ROUNDED = 256;     // bias added to the already rounded product (at::linear's unfused matmul + add_ path)
+constexpr int EPI_ROPE_APPEND = 1 << 20;  // (internal) q|k|v projection of a decode step: RoPE + KV-cache append in the epilogue, see RopeAppend
 constexpr int MAXM = 4;
+
+// Decode-step q|k|v projection (hf LlamaAttention.forward: q/k/v_proj, apply_rotary_pos_emb, cache update) in ONE launch: a wave owns the
+// output pair (i, i + hd/2) of one head -- the two elements a rotation mixes -- so after the dot products
+//   q: both rotated elements go to the query buffer;  k: to row `past + s` of the K cache;  v (no rotation): to its V^T cache columns,
+// with exactly the operations of rope_append_kernel on the rounded projection outputs (same bits), from the cos / sin table of the
+// step's positions (rope_table: one launch per step instead of 32 x 16 lanes evaluating sinf / cosf per layer).
+struct RopeAppend {
+    const elem_t* cs; const elem_t* sn;      // [tokens][hd / 2], 16-bit rounded
+    elem_t* kc; elem_t* vtc;                 // K cache [B, H, smax, hd]; V^T cache [B, H, hd, smax] (32-key permutation of transpose_v_kernel)
+    int S, H, hd, smax, past;
+};
 
 typedef uint32_t gv_u32x4_t __attribute__((ext_vector_type(4)));
 // The weight stream is read exactly once per token, by exactly one CU: non-temporal loads (global_load_dwordx4 ... nt; MI355X_MICROARCH.md
@@ -33,14 +45,15 @@ constexpr int XS_MAX_BYTES = 32 * 1024;     // X (optionally RMS-normalised) is 
 template <int M, int U>
 __global__ __launch_bounds__(256) void gemv_kernel(const elem_t* __restrict__ X, long ldx, const elem_t* __restrict__ W, long ldw, void* C,
                                                    long ldc, const elem_t* __restrict__ bias, const elem_t* __restrict__ R, long ldr, int N, int K,
-                                                   int flags, int n_out, const elem_t* __restrict__ norm_w, float eps, int staged) {
+                                                   int flags, int n_out, const elem_t* __restrict__ norm_w, float eps, int staged, RopeAppend ra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     elem_t* xs = (elem_t*)smem;                                   // [M][K] when staged
     __shared__ float red[4][MAXM];
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
     const int gw = blockIdx.x * 4 + wv_id;                        // global wave id
     const int nwaves = gridDim.x * 4;
-    const bool swiglu = flags & EPI_SWIGLU;
+    const bool rope = flags & EPI_ROPE_APPEND;
+    const bool swiglu = (flags & EPI_SWIGLU) || rope;             // two weight rows per output unit
     const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
     const int nchunk = K >> 3;
     if (staged) {
@@ -89,9 +102,20 @@ __global__ __launch_bounds__(256) void gemv_kernel(const elem_t* __restrict__ X,
     }
     for (int o = gw; o < n_out; o += nwaves) {
         // SwiGLU pack: output o <- gate row (o/16)*32 + o%16 and up row 16 below it
-        const int row0 = swiglu ? (o >> 4) * 32 + (o & 15) : o;
+        int row0 = swiglu ? (o >> 4) * 32 + (o & 15) : o;
+        int row1_off = 16;
+        int r_sec = 0, r_head = 0, r_i = 0;                       // RoPE unit o -> section (q / k / v), head, element i < hd / 2
+        if (rope) {
+            const int half = ra.hd >> 1, per_sec = ra.H * half;
+            r_sec = o / per_sec;
+            const int rem = o - r_sec * per_sec;
+            r_head = rem / half;
+            r_i = rem - r_head * half;
+            row0 = (r_sec * ra.H + r_head) * ra.hd + r_i;
+            row1_off = half;
+        }
         const elem_t* w0 = W + (long)row0 * ldw;
-        const elem_t* w1 = w0 + 16 * ldw;
+        const elem_t* w1 = w0 + (long)row1_off * ldw;
         float a0[M], a1[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) a0[m] = a1[m] = 0.f;
@@ -133,6 +157,26 @@ __global__ __launch_bounds__(256) void gemv_kernel(const elem_t* __restrict__ X,
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 float t;
+                if (rope) {
+                    const int half = ra.hd >> 1;
+                    const float x0 = rnd(a0[m]), x1 = rnd(a1[m]);              // what the q | k | v buffer would hold
+                    const int b = m / ra.S, slot = ra.past + (m - b * ra.S);
+                    if (r_sec < 2) {
+                        const float cs = e2f(ra.cs[(long)m * half + r_i]), sn = e2f(ra.sn[(long)m * half + r_i]);
+                        const float o1 = rnd(rnd(x0 * cs) + rnd(-x1 * sn)), o2 = rnd(rnd(x1 * cs) + rnd(x0 * sn));
+                        elem_t* dst = r_sec == 0 ? (elem_t*)C + (long)m * ldc + r_head * ra.hd + r_i
+                                                 : ra.kc + (((long)b * ra.H + r_head) * ra.smax + slot) * ra.hd + r_i;
+                        dst[0] = f2e(o1);
+                        dst[half] = f2e(o2);
+                    } else {
+                        const int w = slot & 31;
+                        const int slot_v = (slot & ~31) + 8 * ((w >> 2) & 3) + 4 * (w >> 4) + (w & 3);
+                        elem_t* dst = ra.vtc + (((long)b * ra.H + r_head) * ra.hd + r_i) * ra.smax + slot_v;
+                        dst[0] = f2e(x0);
+                        dst[(long)half * ra.smax] = f2e(x1);
+                    }
+                    continue;
+                }
                 if (swiglu) {
                     t = rnd(rnd(act_silu(rnd(a0[m]))) * rnd(a1[m]));
                 } else {
@@ -256,8 +300,10 @@ int launch_skinny(const void* X, int64_t ldx, const void* W, int64_t ldw, void* 
 }
 
 int launch_gemv(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr,
-                int64_t M, int64_t N, int64_t K, int flags, const void* norm_w, float eps, void* stream) {
+                int64_t M, int64_t N, int64_t K, int flags, const void* norm_w, float eps, void* stream, const RopeAppend* rope = nullptr) {
     if (!X || !W || !C || M <= 0 || N <= 0 || K <= 0) return ULL_ERR_ARG;
+    if ((flags & EPI_ROPE_APPEND) && (!rope || flags != EPI_ROPE_APPEND || (N & 1))) return ULL_ERR_ARG;   // (not part of the public flags)
+    const RopeAppend ra = rope ? *rope : RopeAppend{};
     if (M > MAXM || (K & 7) || (ldx & 7) || (ldw & 7)) return ULL_ERR_SHAPE;
     if ((flags & EPI_BIAS) && !bias) return ULL_ERR_ARG;
     if ((flags & EPI_RESID) && !R) return ULL_ERR_ARG;
@@ -265,7 +311,7 @@ int launch_gemv(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C,
     const int staged = M * K * 2 <= XS_MAX_BYTES;
     if (norm_w && !staged) return ULL_ERR_SHAPE;
     const int lds = staged ? (int)(M * K * 2) : 0;
-    const int n_out = (int)((flags & EPI_SWIGLU) ? N / 2 : N);
+    const int n_out = (int)((flags & (EPI_SWIGLU | EPI_ROPE_APPEND)) ? N / 2 : N);
     // every block pays the X staging once, so give a block several output rows per wave: ~2 blocks per CU
     int blocks = (n_out + 3) / 4;
     if (staged && blocks > 1024) blocks = 1024;
@@ -273,7 +319,7 @@ int launch_gemv(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C,
     hipStream_t st = (hipStream_t)stream;
 #define ULL_GV(MM, UU)                                                                                                                    \
     hipLaunchKernelGGL((gemv_kernel<MM, UU>), dim3(blocks), dim3(256), lds, st, (const elem_t*)X, ldx, (const elem_t*)W, ldw, C, ldc,     \
-                       (const elem_t*)bias, (const elem_t*)R, ldr, (int)N, (int)K, flags, n_out, (const elem_t*)norm_w, eps, staged)
+                       (const elem_t*)bias, (const elem_t*)R, ldr, (int)N, (int)K, flags, n_out, (const elem_t*)norm_w, eps, staged, ra)
     switch ((int)M) {
         case 1: ULL_GV(1, 8); break;
         case 2: ULL_GV(2, 4); break;
@@ -298,6 +344,21 @@ extern "C" int ULL_FN(ull_gemv_rmsnorm_)(const void* X, int64_t ldx, const void*
                                      void* stream) {
     if (!norm_w) return ULL_ERR_ARG;
     return launch_gemv(X, ldx, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, norm_w, eps, stream);
+}
+
+// Decode-step q | k | v projection with RoPE and the KV-cache append in its epilogue (see RopeAppend): W = [3 * H * hd, K] (q | k | v rows),
+// M = B * S tokens (<= 4), optional fused RMSNorm (norm_w may be null).  Q_out [M, H * hd] receives the rotated queries; the rotated keys
+// go to k_cache[b, h, past + s, :], the values to vt_cache[b, h, :, slot(past + s)].  Same bits as ull_gemv_rmsnorm_ + ull_rope_append_.
+extern "C" int ULL_FN(ull_gemv_qkv_rope_append_)(const void* X, int64_t ldx, const void* norm_w, float eps, const void* W, int64_t ldw, void* Q_out,
+                                             int64_t ldq, const void* cos_tab, const void* sin_tab, void* k_cache, void* vt_cache, int64_t B,
+                                             int64_t S, int64_t H, int64_t hd, int64_t K, int64_t smax, int64_t past, void* stream) {
+    if (!cos_tab || !sin_tab || !k_cache || !vt_cache || B <= 0 || S <= 0 || H <= 0) return ULL_ERR_ARG;
+    if (hd <= 0 || (hd & 1) || past < 0 || past + S > smax || ldq < H * hd) return ULL_ERR_SHAPE;
+    RopeAppend ra;
+    ra.cs = (const elem_t*)cos_tab; ra.sn = (const elem_t*)sin_tab; ra.kc = (elem_t*)k_cache; ra.vtc = (elem_t*)vt_cache;
+    ra.S = (int)S; ra.H = (int)H; ra.hd = (int)hd; ra.smax = (int)smax; ra.past = (int)past;
+    return launch_gemv(X, ldx, W, ldw, Q_out, ldq, nullptr, nullptr, 0, B * S, 3 * H * hd, K, EPI_ROPE_APPEND, norm_w, norm_w ? eps : 0.f, stream,
+                       &ra);
 }
 
 // The same contract for 2 <= M <= 16 on the matrix cores (batched decode steps); K % 32 == 0.

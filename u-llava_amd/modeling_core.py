@@ -670,12 +670,26 @@ class UllavaCoreForCausalLM(nn.Module):
         # prefill with LLaMA's head_dim: RoPE runs inside the QKV GEMM's epilogue from one cos / sin table per forward (the
         # positions are the same for every layer); other shapes (tiny test models, decode steps) use the stand-alone kernels
         fuse_rope = hd == 128 and T > 4 and D % 64 == 0 and not (cache is not None and past > 0)
-        rope_cs = ops.rope_table(pos, inv_freq, x.dtype) if fuse_rope else None
+        # generation steps of at most 4 tokens (the GEMV shapes): RoPE and the cache append run in the q|k|v GEMV's epilogue, from the
+        # same per-forward table
+        fuse_append = cache is not None and past > 0 and T <= 4 and hd % 2 == 0 and D % 8 == 0
+        rope_cs = ops.rope_table(pos, inv_freq, x.dtype) if (fuse_rope or fuse_append) else None
         all_h = []
         for li, w in enumerate(pk["llama"]):
             if output_hidden_states:
                 all_h.append(x.view(B, S, D))
             decode = cache is not None and past > 0
+            if fuse_append:
+                kc, vtc = cache.k[li], cache.vt[li]
+                q = ops.linear_qkv_rope_append(x, w["w_qkv"], rope_cs[0], rope_cs[1], B, S, H, hd, kc, vtc, cache.smax, past, rms_w=w["ln1"],
+                                               rms_eps=cfg.rms_norm_eps)
+                att = torch.empty(T, D, device=dev, dtype=x.dtype)
+                ops.attention(q, kc, vtc, att, B, H, S, past + S, hd, (S * D, hd, D), (H * cache.smax * hd, cache.smax * hd, hd), (S * D, hd, D),
+                              key_mask, causal=True, scale_mode=1, scale=hd ** -0.5)
+                x = ops.linear(att, w["w_o"], residual=x)
+                a = ops.linear(x, w["w_gu"], swiglu=True, rms_w=w["ln2"], rms_eps=cfg.rms_norm_eps)
+                x = ops.linear(a, w["w_down"], residual=x)
+                continue
             if fuse_rope:
                 qkv = ops.linear_qkv_rope(ops.rmsnorm(x, w["ln1"], cfg.rms_norm_eps), w["w_qkv"], rope_cs[0], rope_cs[1], 2 * D, hd)
             else:

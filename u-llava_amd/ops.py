@@ -403,6 +403,27 @@ def rope_append(qkv: torch.Tensor, row_stride: int, positions: torch.Tensor, inv
               _stream())
 
 
+def linear_qkv_rope_append(x: torch.Tensor, w_qkv: torch.Tensor, rope_cos: torch.Tensor, rope_sin: torch.Tensor, B: int, S: int, H: int, hd: int,
+                           k_cache: torch.Tensor, vt_cache: torch.Tensor, smax: int, past: int, rms_w: Optional[torch.Tensor] = None,
+                           rms_eps: float = 0.0) -> torch.Tensor:
+    """decode step (B * S <= 4 tokens): q | k | v projection of x (optionally RMS-normalised first) with RoPE and the KV-cache append in the
+    GEMV's epilogue.  Returns the rotated queries [B * S, H * hd]; the rotated keys / the values land in the caches.  Same bits as
+    `linear(x, w_qkv, rms_w=...)` followed by `rope_append`."""
+    _chk(x, "x"); _chk(w_qkv, "w_qkv", x.dtype); _chk(rope_cos, "rope_cos", x.dtype); _chk(rope_sin, "rope_sin", x.dtype)
+    _chk(k_cache, "k_cache", x.dtype); _chk(vt_cache, "vt_cache", x.dtype)
+    T, K = x.shape
+    if T != B * S or T > 4 or w_qkv.shape != (3 * H * hd, K) or rope_cos.shape != (T, hd // 2) or rope_sin.shape != (T, hd // 2):
+        raise RuntimeError("u-llava_amd.linear_qkv_rope_append: shapes (at most 4 tokens; w [3 * H * hd, K]; cos / sin [tokens, hd / 2])")
+    if x.stride(1) != 1 or w_qkv.stride(1) != 1 or not (rope_cos.is_contiguous() and rope_sin.is_contiguous()):
+        raise RuntimeError("u-llava_amd.linear_qkv_rope_append: rows must be contiguous")
+    if rms_w is not None:
+        _chk(rms_w, "rms_w", x.dtype)
+    q = torch.empty(T, H * hd, device=x.device, dtype=x.dtype)
+    _lib.call("ull_gemv_qkv_rope_append_" + _SFX[x.dtype], _p(x), x.stride(0), _p(rms_w), float(rms_eps), _p(w_qkv), w_qkv.stride(0), _p(q),
+              q.stride(0), _p(rope_cos), _p(rope_sin), _p(k_cache), _p(vt_cache), B, S, H, hd, K, smax, past, _stream())
+    return q
+
+
 def transpose_v(v: torch.Tensor, v_bs: int, v_ss: int, B: int, S: int, H: int, hd: int, pitch: Optional[int] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(v, "v")
