@@ -153,9 +153,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     lead = tuple(x.shape[:-1])
     if x.shape[-1] != K:
         raise RuntimeError(f"u-llava_amd.linear: K mismatch {x.shape[-1]} vs {K}")
-    # batched decode steps against LLaMA-sized weights: the weight stream on the matrix cores (the GEMV is FMA-bound from M = 4 on,
-    # the tiled GEMM's grid is a few dozen blocks at these M).  Small weights stay where they were.
-    skinny = 2 <= M <= 16 and K % 32 == 0 and N * K >= (1 << 22) and w.stride(0) % 8 == 0 and w.stride(1) == 1 and tune == 0
+    # batched decode steps against LLaMA-sized weights: the weight stream on the matrix cores (the GEMV is FMA-bound from M = 4 on and
+    # measured slower from M = 3 on (decode step at batch 3: 4.47 vs 4.24 ms; at batch 2 the GEMV wins, 4.00 vs 4.08); the tiled GEMM's grid
+    # is a few dozen blocks at these M).  Small weights stay where they were.
+    skinny = 3 <= M <= 16 and K % 32 == 0 and N * K >= (1 << 22) and w.stride(0) % 8 == 0 and w.stride(1) == 1 and tune == 0
     if rms_w is not None and (skinny or not (M <= 4 and K % 8 == 0 and M * K <= 16384)):
         x = rmsnorm(x, rms_w, rms_eps)
         rms_w = None
