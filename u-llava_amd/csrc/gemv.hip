@@ -30,7 +30,11 @@ typedef uint32_t gv_u32x4_t __attribute__((ext_vector_type(4)));
 // The weight stream is read exactly once per token, by exactly one CU: non-temporal loads (global_load_dwordx4 ... nt; MI355X_MICROARCH.md
 // "nt-weights") keep it from evicting X and the KV cache from the L2.  Measured (tools/gemv_bw.py, tools/decode_bench.py): 1-GB stream
 // 5.82 -> 6.29 TB/s, decode step 3.77 -> 3.61 ms.  (Software-pipelining the batches of a wave across output rows was also tried: 168
-// registers, 3 waves per SIMD instead of 4, 3.85 TB/s on the q|k|v shape against 4.9 -- not shipped.)
+// registers, 3 waves per SIMD instead of 4, 3.85 TB/s on the q|k|v shape against 4.9 -- not shipped.  Requesting the wave's first weight
+// batch before the activations are staged -- the weights do not depend on them -- was tried in two forms in the decode loop: held in the
+// real buffers across the staging code (151 registers, the fourth wave per SIMD gone: 3.79 vs 3.38 ms per token) and as loads into one
+// scratch register quad that only warm the L2 (3.40 vs 3.37): neither shipped; the launch's first memory round trip is not what a
+// 20-us GEMV loses against the 1-GB stream rate.)
 ULL_DEV uint4 w_load16(const elem_t* p) {
     const gv_u32x4_t v = __builtin_nontemporal_load((const gv_u32x4_t*)p);
     return make_uint4(v.x, v.y, v.z, v.w);
