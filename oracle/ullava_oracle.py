@@ -487,7 +487,7 @@ def two_way_transformer(sd, p: str, image_embedding: Tensor, image_pe: Tensor, p
         queries = tr(f"l{i}.norm3", layer_norm(queries + m, sd, lp + "norm3", 1e-5))
         q = queries + point_embedding
         k = keys + image_pe
-        keys = keys + tr(f"l{i}.i2t", _sam_attn(sd, lp + "cross_attn_image_to_token.", k, q, queries, n_heads))
+        keys = keys + tr(f"l{i}.i2t", _sam_attn(sd, lp + "cross_attn_image_to_token.", k, q, queries, n_heads, trace, f"l{i}.i2t"))
         keys = tr(f"l{i}.norm4", layer_norm(keys, sd, lp + "norm4", 1e-5))
     q = queries + point_embedding
     k = keys + image_pe

@@ -289,9 +289,9 @@ def gen_sam_decoder(name, dtype, seed, n_list=(1, 3, 10)):
             # stage outputs of the two-way transformer's first block (the oracle's, whose final output was just checked bit-exact
             # against the reference): small tensors whole, the 4096-row ones every 16th row
             keep = {}
-            for k in ("l0.norm1", "l0.t2i.q", "l0.t2i.att", "l0.norm2", "l0.norm3", "l1.norm1"):
+            for k in ("l0.norm1", "l0.t2i.q", "l0.t2i.att", "l0.norm2", "l0.norm3", "l1.norm1", "l0.i2t.k", "l0.i2t.v"):
                 keep[k] = otrace[k]
-            for k in ("l0.t2i.k", "l0.t2i.v", "l0.norm4"):
+            for k in ("l0.t2i.k", "l0.t2i.v", "l0.i2t.q", "l0.i2t.att", "l0.norm4"):          # the image side (4096 rows): every 16th row
                 keep[k] = otrace[k][:, ::16].contiguous()
             fx["cases"][-1]["trace"] = keep
     save(name, fx)

@@ -528,22 +528,29 @@ def test_mask_decoder_stage_trace_bf16_layer0_bit_exact():
     case = fx["cases"][0]
     tr = {}
     eng.decode(emb_tm, case["text_embeds"][:, 0].to(DEV), trace=tr)
+    # the same stages from the reference restatement run on THIS host's CPU: how far the reference moves between hosts (the fixture was
+    # made on the build container's CPU; torch's vectorised exp / reductions differ by ISA)
+    sdo = fixture_sd(fx, BF)
+    osp, ode = O.prompt_encoder_text(sdo, case["text_embeds"], (64, 64))
+    host = {}
+    O.mask_decoder(sdo, emb, O.dense_pe(sdo, (64, 64)), osp.to(BF), ode, False, trace=host)
     rows = []
     for k, ref in case["trace"].items():
         if k not in tr:
             continue
         got = tr[k].cpu()
         got = got.reshape(1, -1, ref.shape[-1])
+        hst = host[k].reshape(1, -1, ref.shape[-1])
         if got.shape[1] != ref.shape[1]:
-            got = got[:, ::16]
-        flips = float((got != ref).float().mean())
+            got, hst = got[:, ::16], hst[:, ::16]
+        flips, cross = float((got != ref).float().mean()), float((hst != ref).float().mean())
         dmax = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())
         rows.append((k, flips, dmax))
-        print(f"{k:12s} differing elements {flips:.5f}  max|d|/max {dmax:.2e}")
-        RESULTS.append(dict(test="g7_trace_bf16", stage=k, frac_differing=flips, max_rel=dmax))
+        print(f"{k:12s} differing elements HIP {flips:.5f} / reference cross-host {cross:.5f}  max|d|/max {dmax:.2e}")
+        RESULTS.append(dict(test="g7_trace_bf16", stage=k, frac_differing=flips, reference_cross_host=cross, max_rel=dmax))
         if k.startswith("l0."):
             assert flips <= (3e-3 if k == "l0.norm4" else 1e-3) and dmax <= 2.0 ** -7, (k, flips, dmax)
-    assert len(rows) >= 8
+    assert len(rows) >= 12
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])

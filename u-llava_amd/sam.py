@@ -353,7 +353,8 @@ class SamEngine:
             queries = ops.linear(m, l.mlp.lin2.weight, l.mlp.lin2.bias, residual=queries)
             queries = rec(f"l{i}.norm3", ops.layernorm(queries, l.norm3.weight, l.norm3.bias, 1e-5), (n, T, D))
             q = ops.add_rows(queries, qpe)
-            keys = self._attn(l.cross_attn_image_to_token, k, q, queries, n, P, T, residual=keys, unfused_bias=("q",) if i == 0 else ())
+            keys = self._attn(l.cross_attn_image_to_token, k, q, queries, n, P, T, residual=keys, trace=trace, tag=f"l{i}.i2t",
+                              unfused_bias=("q",) if i == 0 else ())
             keys = rec(f"l{i}.norm4", ops.layernorm(keys, l.norm4.weight, l.norm4.bias, 1e-5), (n, P, D))
         q = ops.add_rows(queries, qpe)
         k = ops.add_rows(keys, pos)
