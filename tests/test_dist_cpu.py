@@ -167,3 +167,89 @@ def test_rank_cpu_sets_partition_the_host():
     assert sets[0] == list(range(0, 32)) and sets[1] == list(range(32, 64)) and sets[2] == list(range(64, 96))
     assert bench.rank_cpu_set(0, 1, list(range(16)), None) == list(range(16))
     assert bench.rank_cpu_set(2, 3, [0, 1], None) == [0, 1]         # fewer CPUs than ranks: no pinning
+
+
+def _zero2_worker(rank, world, port, q):
+    """ShardedAdamW's N > 1 cycle on CPU ranks.  The three HIP kernels it calls are replaced by test-local torch restatements (this
+    process only: the product refuses CPU tensors), so what runs here is the package's own bucket / shard layout, gradient exchange,
+    clipping all-reduce, owner update, all-gather and scatter back -- over gloo, which has no all_to_all: fp32 parameters take the
+    all_reduce form of the exchange."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D = importlib.import_module("u-llava_amd.dist")
+    OPT = importlib.import_module("u-llava_amd.optim")
+    D.init_from_env(backend="gloo")
+
+    class _TorchKernels:
+        @staticmethod
+        def sumsq(g, out):
+            out += g.float().pow(2).sum()
+
+        @staticmethod
+        def sum_slabs(x, scale):
+            return (x.float().sum(0) * scale).to(x.dtype)
+
+        @staticmethod
+        def adamw_step(master, m, v, grad, param_out, lr, b1, b2, eps, wd, step, grad_scale):
+            g = grad.float() * grad_scale                      # torch.optim.AdamW (single-tensor form), fp32
+            master.mul_(1 - lr * wd)
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / (1 - b2 ** step) ** 0.5).add_(eps)
+            master.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))
+            param_out.copy_(master)
+    OPT.ops = _TorchKernels
+
+    class _CpuShardedAdamW(OPT.ShardedAdamW):
+        def _check_device(self):
+            pass
+    g0 = torch.Generator().manual_seed(7)
+    shapes = ((7, 5), (33,), (4, 4, 3), (1,), (6, 2))
+    params = [torch.nn.Parameter(torch.randn(s, generator=g0)) for s in shapes]
+    opt = _CpuShardedAdamW(params, lr=1e-2, weight_decay=0.1, max_grad_norm=0.5, bucket_bytes=200)
+    assert len(opt.buckets) >= 2 and opt.world == 2
+    norms = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        for i, p in enumerate(params):
+            p.grad = None if (i == 4 and rank == 1) else torch.randn(p.shape, generator=g)     # a head rank 1 never touched
+        norms.append(opt.step())
+    q.put((rank, norms, [p.detach().clone() for p in params], opt.state_bytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_cycle_gloo_world2():
+    """ZeRO-2 AdamW over 2 CPU ranks (kernels replaced by torch restatements in the workers): both ranks end every step with the same
+    parameters, equal to single-process torch.optim.AdamW on the rank-averaged, norm-clipped gradients; each rank holds half the state."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0 = torch.Generator().manual_seed(7)
+    shapes = ((7, 5), (33,), (4, 4, 3), (1,), (6, 2))
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g0)) for s in shapes]
+    topt = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.1)
+    ref_norms = []
+    for step in range(3):
+        gens = [torch.Generator().manual_seed(1000 * step + r) for r in range(2)]
+        for i, p in enumerate(ref):
+            g_r0 = torch.randn(p.shape, generator=gens[0])
+            g_r1 = torch.randn(p.shape, generator=gens[1])
+            p.grad = (g_r0 + (torch.zeros_like(g_r1) if i == 4 else g_r1)) / 2
+        ref_norms.append(float(torch.nn.utils.clip_grad_norm_(ref, 0.5)))
+        topt.step()
+    (r0, n0, p0, sb0), (r1, n1, p1, sb1) = out
+    total = sum(int(torch.tensor(s).prod()) for s in shapes)
+    assert sb0 == sb1 and 12 * total / 2 <= sb0 <= 12 * (total / 2 + 8 * 3)          # 3 fp32 words per owned element, shards padded to 8
+    for a, b, c in zip(n0, n1, ref_norms):
+        assert abs(a - b) < 1e-6 and abs(a - c) < 1e-5 * max(1.0, c)
+    for a, b, c in zip(p0, p1, ref):
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a, c.detach(), rtol=2e-6, atol=2e-7)

@@ -33,8 +33,7 @@ class ShardedAdamW:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("ShardedAdamW: no trainable parameter")
-        if any(not p.is_cuda for p in self.params):
-            raise RuntimeError("u-llava_amd: ShardedAdamW updates on the GPU (no CPU path exists)")
+        self._check_device()
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.max_grad_norm = max_grad_norm
         self.group = group
@@ -58,6 +57,10 @@ class ShardedAdamW:
             self.buckets.append(dict(params=plist, numel=numel, shard=shard, flat=flat, recv=None,
                                      master=mine.float().clone(), m=torch.zeros(shard, device=dev, dtype=torch.float32),
                                      v=torch.zeros(shard, device=dev, dtype=torch.float32)))
+
+    def _check_device(self):
+        if any(not p.is_cuda for p in self.params):
+            raise RuntimeError("u-llava_amd: ShardedAdamW updates on the GPU (no CPU path exists)")
 
     # -- torch.optim.Optimizer's surface as the training scripts use it -------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
