@@ -576,6 +576,43 @@ def test_gemm_without_workspace_never_splits():
     assert torch.equal(y0[: 256 * 8], y1[: 256 * 8])         # whole-tile rounds do not depend on the policy
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(323, 4096, 4096, "resid"), (291, 4096, 11008, "resid"), (643, 1024, 4096, "bias_gelu"),
+                                          (130, 1024, 4096, "f32"), (323, 4096, 1024, "swiglu"), (200, 2176, 2048, "plain")])
+def test_small_m_gemm_split_k_matches_reference_and_unsplit(M, N, K, kind):
+    """single-image prefill shapes (M < 1024, few 128x128 tiles, long K): the 128x128 kernel cuts K into slices over the idle CUs, fp32
+    slabs in the caller's workspace, summed in slice order by the finalize launch with the full epilogue (bias / activation / residual /
+    SwiGLU / fp32 output).  Against the fp32 reference, against the unsplit launch (fp32 summation order only), and run to run."""
+    ops = pkg("ops")
+    x = _rand(M, K, seed=300 + M).to(DEV)
+    w = _rand(N, K, seed=301 + N, scale=K ** -0.5)
+    b = _rand(N, seed=302) if kind == "bias_gelu" else None
+    r = _rand(M, N, seed=303) if kind == "resid" else None
+    kw = dict(act="gelu" if kind == "bias_gelu" else None, residual=None if r is None else r.to(DEV), out_f32=kind == "f32")
+    if kind == "swiglu":
+        wd = pkg("modeling_core").interleave_gate_up(w[: N // 2].contiguous(), w[N // 2:].contiguous()).to(DEV)
+        ref = (F.silu((x.cpu().float() @ w[: N // 2].float().t()).to(BF)).to(BF) * (x.cpu().float() @ w[N // 2:].float().t()).to(BF)).to(BF)
+        run = lambda: ops.linear(x, wd, swiglu=True)
+    else:
+        wd = w.to(DEV)
+        t = F.linear(x.cpu().float(), w.float(), None if b is None else b.float())
+        if kind != "f32":
+            t = t.to(BF)
+        if kind == "bias_gelu":
+            t = F.gelu(t)
+        if r is not None:
+            t = r + t.to(BF)
+        ref = t
+        run = lambda: ops.linear(x, wd, None if b is None else b.to(DEV), **kw)
+    with ops.small_m_split_k(True):                     # opt-in latency mode (default off: batch invariance, see ops.py)
+        y1, y2 = run(), run()
+    y0 = run()
+    assert torch.equal(y1, y2), "split-K must be deterministic"
+    assert not torch.equal(y1, y0), "the split must actually have run (another summation order)"
+    assert_close_bf16(y1, ref.float() if kind == "f32" else ref.to(BF), ulps=2.0, what=f"split-K {kind} vs reference", outlier_frac=1e-4,
+                      outlier_floor=float(ref.float().abs().max()))
+    assert_close_bf16(y1, y0.cpu(), ulps=2.0, what=f"split-K {kind} vs unsplit", outlier_frac=1e-4, outlier_floor=float(ref.float().abs().max()))
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,D", [(300, 256), (643 * 3, 512), (256 * 9 + 17, 1024 + 128)])
 def test_qkv_gemm_with_fused_rope_is_bit_identical_to_gemm_then_rope(M, D, dt):

@@ -440,9 +440,13 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
 
-    // ---- block -> tile: XCD-contiguous chunks, grouped raster inside ------------------------
+    // ---- block -> (tile, K slice): XCD-contiguous chunks, grouped raster inside --------------
+    // split-K (p.sk > 1: few tiles and a long K -- the o_proj / down_proj of a single-image prefill are 96 tiles of 64 / 172 K-steps on a
+    // chip that holds 512 blocks): slice s = blockIdx / tiles works on K-steps [s nk / sk, (s + 1) nk / sk) and leaves its raw fp32
+    // accumulators in p.ws [tile][slice][128][128]; gemm128_splitk_finalize sums the slices in order and applies the epilogue.
     const int nwg = p.nbm * p.nbn;
-    int bid = blockIdx.x;
+    const int slice = blockIdx.x / nwg;
+    int bid = blockIdx.x - slice * nwg;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective for any nwg
@@ -497,9 +501,11 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_all = p.K / BK;
+    const int k_first = p.sk > 1 ? (int)((long)nk_all * slice / p.sk) : 0;
+    const int nk = p.sk > 1 ? (int)((long)nk_all * (slice + 1) / p.sk) : nk_all;
+    stage(k_first & 1, k_first);
+    for (int kt = k_first; kt < nk; ++kt) {
         const int cur = kt & 1;
         // Tile kt was issued one iteration ago and is the only DMA in flight for this wave.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -523,6 +529,15 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*(l>>4) + r][m = m0 + wm*64 + j*16 + (l&15)] --------------
+    if (p.sk > 1) {                                        // a K slice: raw accumulators to the workspace, row-major [m][n] per (tile, slice)
+        float* slab = p.ws + ((long)(bm * p.nbn + bn) * p.sk + slice) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(f32x4_t*)(slab + (wm * 64 + j * 16 + (lane & 15)) * BN + wn * 64 + i * 16 + 4 * (lane >> 4)) = acc[i][j];
+        return;
+    }
     __builtin_amdgcn_s_barrier();                          // every wave has consumed the last K-tile: LDS is free
     staged_epilogue<SWIGLU, 4, ROPE>(p, acc, smem + wave * (64 * 144), lane, m0 + wm * 64, n0 + wn * 64, smem + (wave ^ 1) * (64 * 144));
 }
@@ -1676,19 +1691,27 @@ __global__ __launch_bounds__(512) void gemm256d_kernel(GemmArgs p) {
 
 // Sum the K-slices of the stream-K tail tiles and apply the same epilogue as the main kernel.  One thread per 4 output
 // columns (8 accumulator columns for SwiGLU).
-__global__ __launch_bounds__(256) void splitk_finalize_kernel(GemmArgs p) {
+template <int BM, int BN, bool LINEAR>
+__global__ __launch_bounds__(256) void splitk_finalize_any_kernel(GemmArgs p) {
     const int flags = p.flags;
     const bool swiglu = flags & EPI_SWIGLU;
     const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
     const bool out_f32 = flags & EPI_OUT_F32;
     const int n_out_total = swiglu ? p.N / 2 : p.N;
     const int tile_r = blockIdx.y;
-    const int pid = p.t_full + tile_r;
-    const int per_group = p.group_m * p.nbn;
-    const int gid = pid / per_group;
-    const int first_m = gid * p.group_m;
-    const int gsz = min(p.nbm - first_m, p.group_m);
-    const int m0 = (first_m + (pid % per_group) % gsz) * BM, n0 = ((pid % per_group) / gsz) * BN;
+    int m0, n0;
+    if constexpr (LINEAR) {                                      // the 128x128 kernel's split-K: slabs indexed by (M-tile, N-tile)
+        m0 = (tile_r / p.nbn) * BM;
+        n0 = (tile_r % p.nbn) * BN;
+    } else {                                                     // stream-K tail of the 256x256 kernels: the tiles behind the full rounds
+        const int pid = p.t_full + tile_r;
+        const int per_group = p.group_m * p.nbn;
+        const int gid = pid / per_group;
+        const int first_m = gid * p.group_m;
+        const int gsz = min(p.nbm - first_m, p.group_m);
+        m0 = (first_m + (pid % per_group) % gsz) * BM;
+        n0 = ((pid % per_group) / gsz) * BN;
+    }
     const float* slab0 = p.ws + (long)tile_r * p.sk * (BM * BN);
     const int quads_per_row = swiglu ? BN / 8 : BN / 4;
     for (int q = blockIdx.x * 256 + threadIdx.x; q < BM * quads_per_row; q += gridDim.x * 256) {
@@ -1883,18 +1906,32 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
             hipLaunchKernelGGL((big::gemm256_kernel<false, true>), dim3(grid), dim3(512), big::LDS_BYTES_W4, (hipStream_t)stream, a);
         else
             hipLaunchKernelGGL(big::gemm256_kernel<false>, dim3(grid), dim3(512), big::LDS_BYTES_W4, (hipStream_t)stream, a);
-        if (a.sk > 1) hipLaunchKernelGGL(big::splitk_finalize_kernel, dim3(32, rem), dim3(256), 0, (hipStream_t)stream, a);
+        if (a.sk > 1) hipLaunchKernelGGL((big::splitk_finalize_any_kernel<big::BM, big::BN, false>), dim3(32, rem), dim3(256), 0, (hipStream_t)stream, a);
         return ull_check_launch();
     }
     if (flags & (EPI_W_TILED | EPI_X_TILED)) return ULL_ERR_SHAPE;      // tile-major operands: 256x256 kernel only
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
+    // split-K: the chip holds 2 blocks per CU; a launch of at most half that many tiles with a long K (o_proj / down_proj of a single-image
+    // prefill: 96 tiles x 64 / 172 K-steps, each step one memory round trip in this kernel) is cut into sk slices of >= 8 K-steps that fill
+    // the slots, fp32 slabs in the caller's workspace (none: no split), summed in slice order by the finalize launch.
+    const int T = a.nbm * a.nbn, nk = (int)(K / BK), slots = 2 * n_cu;
+    if (ws && !force_small && T <= slots / 2 && nk >= 16) {
+        constexpr long SLAB = (long)BM * BN * sizeof(float);
+        int sk = slots / T;
+        if (sk > nk / 8) sk = nk / 8;
+        if (sk > 8) sk = 8;
+        if ((long)T * sk * SLAB > ws_bytes) sk = (int)(ws_bytes / (T * SLAB));
+        if (sk > 1) { a.sk = sk; a.ws = (float*)ws; }
+    }
+    const int grid = T * a.sk;
     if (flags & EPI_SWIGLU)
-        hipLaunchKernelGGL(gemm128_kernel<true>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gemm128_kernel<true>, dim3(grid), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
     else if (rope)
-        hipLaunchKernelGGL((gemm128_kernel<false, true>), dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((gemm128_kernel<false, true>), dim3(grid), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(gemm128_kernel<false>, dim3(a.nbm * a.nbn), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gemm128_kernel<false>, dim3(grid), dim3(256), GEMM_LDS, (hipStream_t)stream, a);
+    if (a.sk > 1) hipLaunchKernelGGL((big::splitk_finalize_any_kernel<BM, BN, true>), dim3(16, T), dim3(256), 0, (hipStream_t)stream, a);
     return ull_check_launch();
 }
 

@@ -7,6 +7,8 @@ operand; the other operands must match), row-major, last dim contiguous.
 import weakref
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -123,6 +125,27 @@ def _streamk_ws(device: torch.device, stream_id: int):
     return ws
 
 
+# Latency mode for single-image prefills (M < 1024): split-K in the 128x128 kernel.  OFF by default: it makes a sample's result depend on
+# the batch it is computed in (the fp32 summation order of K changes with the split), and the path's invariant -- sample b of a batch of
+# 32 equals the single-sample run bit for bit through every layer (tests/test_full_depth_gpu.py) -- is worth more than 5 ms of prefill.
+# ULL_SMALL_M_SPLIT_K=1 or `with ops.small_m_split_k(True):` turns it on (C2 shape at batch 1: 16.9 -> 11.9 ms, 59 -> 84 images/s).
+_SMALL_M_SPLIT_K = [os.environ.get("ULL_SMALL_M_SPLIT_K", "0") == "1"]
+
+
+class small_m_split_k:
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _SMALL_M_SPLIT_K[0]
+        _SMALL_M_SPLIT_K[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _SMALL_M_SPLIT_K[0] = self.prev
+        return False
+
+
 class streamk_policy:
     """with streamk_policy(min_k): ... -- K threshold of the stream-K tail inside the block (None = never split)."""
 
@@ -218,6 +241,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     ws_ptr, ws_bytes = None, 0
     min_k = _SK_MIN_K[0]
     if big and min_k is not None and K >= min_k:
+        ws = _streamk_ws(x.device, st)
+        ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
+    elif _SMALL_M_SPLIT_K[0] and not big and min_k is not None and K >= 1024 and M >= 128 and N * K >= (1 << 22) and -(-M // 128) * -(-N // 128) <= 256:
+        # opt-in latency mode (small_m_split_k): few 128x128 tiles, a long K and a weight of at least 8 MB (single-image prefill: o_proj /
+        # down_proj, CLIP's fc2): the kernel splits K over the idle CUs (376 -> 256 us per LLaMA layer at M = 323)
         ws = _streamk_ws(x.device, st)
         ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
     if wt is not None:
