@@ -33,6 +33,8 @@ MM = dict(IMG_START=32001, IMG_END=32002, IMG_PATCH=32003, VID_START=32004, VID_
 WORKLOADS = {
     # name: (image_size, prompt_tokens, per_gpu_batch, description)
     "c4": (336, 64, 32, "C4: ViT-L/14-336 + LLaMA-7B instruct forward, 336x336 image + 64-token prompt (S=643), batch 32/GPU"),
+    # the reference's own CPU-runnable case (BASELINE.json configs[0]; the shape `cpu_baseline` times the oracle on): one image, latency-bound
+    "c1": (224, 32, 1, "C1: ViT-L/14-224 + LLaMA-7B forward, one 224x224 image + 32-token prompt (S=291), batch 1"),
     "c2": (224, 64, 16, "C2: ViT-L/14-224 + LLaMA-7B VQA forward, 224x224 image + 32..64-token prompts right-padded to S=323, batch 16"),
     # full RES path: + SAM ViT-H encoder on 1024x1024, 3 [SEG]+[LOC] rounds per sample, prompt-encoder + mask decoder + postprocess
     "res": (224, 120, 8, "C3: full RES forward (ViT-L/14-224 + LLaMA-7B + SAM ViT-H 1024x1024 + MaskDecoder, 3 [SEG]/[LOC] per image), batch 8"),
