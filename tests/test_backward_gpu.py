@@ -537,3 +537,58 @@ def test_sharded_adamw_matches_torch_adamw_on_fp32_masters():
                 assert torch.equal(p.detach().cpu(), mst.to(torch.bfloat16))                # the 16-bit parameter IS the rounded master
                 oo += p.numel()
     assert torch.equal(packed[64:128], holder.k_proj.weight.detach())                          # the shared buffer moved with the parameters
+
+
+def test_optimizer_steps_never_leave_stale_weight_copies_at_big_m():
+    """ShardedAdamW updates parameters in place; the tile-major copies of o_proj / down_proj / lm_head (used from M >= 1024
+    tokens on) and the q|k|v / gate|up packs of the inference path are COPIES and must follow.  Two optimizer steps at M = 1280 tokens, then
+    the training forward, the no_grad forward and a forward of a FRESH model holding the updated state dict must all agree bit for bit
+    (stale copies would make the first two compute with step-0 weights)."""
+    M_, C_, O_, ops = pkg("modeling_core"), pkg("configuration"), pkg("optim"), pkg("ops")
+    cfg = C_.UllavaCoreConfig(vision_config=dict(image_size=28, patch_size=14, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                                 num_attention_heads=2), vision_hidden_layer=-2, projector_type="mlp",
+                              mm_token_ids=dict(IMG_START=601, IMG_END=602, IMG_PATCH=603, VID_START=604, VID_END=605, VID_PATCH=606),
+                              vocab_size=640, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4)
+    g = torch.Generator().manual_seed(11)
+
+    def build(sd=None):
+        m = M_.UllavaCoreForCausalLM(cfg, device=DEV)
+        if sd is None:
+            for n, p in m.named_parameters():
+                p.data.copy_((torch.ones(p.shape) if ("norm" in n and n.endswith("weight")) else torch.randn(p.shape, generator=g) * 0.05).to(BF))
+        else:
+            m.load_state_dict(sd, strict=True)
+        m.strict_checks = False
+        return m
+    model = build()
+    B, S = 4, 320                                         # M = 1280 tokens: the 256x256 tile kernel with tile-major weights
+    ids = torch.randint(5, 600, (B, S), generator=g).to(DEV)
+    labels = ids.clone()
+    model.pack_weights()                                  # tile-major copies of o_proj / down_proj / lm_head exist from here on
+    assert ops._tiled_of(model.lm_head.weight) is not None and ops._tiled_of(model.model.layers[0].mlp.down_proj.weight) is not None
+    with torch.no_grad():
+        before = model.forward(input_ids=ids).logits.clone()
+    for p in model.parameters():
+        p.requires_grad = False
+    for p in list(model.model.parameters()) + list(model.lm_head.parameters()):
+        p.requires_grad = True
+    opt = O_.ShardedAdamW([p for p in model.parameters() if p.requires_grad], lr=5e-3, weight_decay=0.0, max_grad_norm=1.0)
+    for _ in range(2):
+        opt.zero_grad()
+        out = model.forward(input_ids=ids, labels=labels)
+        out.loss.backward()
+        opt.step()
+    train_logits = model.forward(input_ids=ids, labels=labels).logits.detach()
+    with torch.no_grad():
+        eval_logits = model.forward(input_ids=ids).logits
+    fresh = build({k: v.detach().clone() for k, v in model.state_dict().items()})
+    with torch.no_grad():
+        want = fresh.forward(input_ids=ids).logits
+    assert not torch.equal(want, before), "the two optimizer steps did not move the model"
+    assert torch.equal(eval_logits, want), "no_grad forward after optimizer steps reads stale packed / tile-major weights"
+    # the training graph un-fuses SwiGLU / RoPE (different rounding points than the inference kernels): compare it with the fresh model's
+    # own training forward
+    for p in list(fresh.model.parameters()) + list(fresh.lm_head.parameters()):
+        p.requires_grad = True
+    want_train = fresh.forward(input_ids=ids, labels=labels).logits.detach()
+    assert torch.equal(train_logits, want_train), "training forward after optimizer steps reads stale tile-major weights"

@@ -253,7 +253,7 @@ print("OK")
 def test_lora_adapter_is_merged_at_load(tmp_path):
     """inference_ullava.py:41-43 loads a LoRA checkpoint with PeftModel.from_pretrained(model.llm, path); here the adapter PEFT wrote
     (adapter_config.json + adapter_model.safetensors, `base_model.model.<module>.lora_A|B.weight`) is merged into the targets at
-    load: W + (alpha / r) * B @ A, everything else untouched."""
+    load: W += (alpha / r) * (B @ A) with PEFT's rounding points, everything else untouched."""
     import json
     from safetensors.torch import save_file
     CK, M = pkg("checkpoint"), pkg("modeling_core")
@@ -270,7 +270,9 @@ def test_lora_adapter_is_merged_at_load(tmp_path):
             A, B = torch.randn(r, w.shape[1], generator=g) * 0.1, torch.randn(w.shape[0], r, generator=g) * 0.1
             sd[f"base_model.model.{mod}.lora_A.weight"] = A.to(w.dtype)
             sd[f"base_model.model.{mod}.lora_B.weight"] = B.to(w.dtype)
-            want[mod] = (w.detach().float() + (B.to(w.dtype).float() @ A.to(w.dtype).float()) * (alpha / r)).to(w.dtype)
+            # PEFT 0.4.0 Linear.merge in the weights' dtype: 16-bit product, 16-bit scaling, 16-bit sum (checkpoint.lora_merged_weight)
+            delta = ((B.to(w.dtype).float() @ A.to(w.dtype).float()).to(w.dtype).float() * (alpha / r)).to(w.dtype)
+            want[mod] = (w.detach().float() + delta.float()).to(w.dtype)
     assert not CK.has_lora_adapter(d)
     save_file(sd, os.path.join(d, "adapter_model.safetensors"))
     json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "target_modules": ["q_proj", "v_proj"], "fan_in_fan_out": False},
@@ -368,3 +370,110 @@ def test_hf_trainer_constructs_optimises_and_saves_the_shim_model(tmp_path):
     before = m.llm.model.layers[0].self_attn._qkv_pack[:64].clone()
     opt.step()
     assert not torch.equal(m.llm.model.layers[0].self_attn._qkv_pack[:64], before) and torch.equal(m.llm.model.layers[0].self_attn._qkv_pack[:64], q.data)
+
+
+REFERENCE = "/root/reference"
+
+
+def _reference_source_nodes():
+    """(find_linear_layers FunctionDef, the `if lora_r > 0:` block of train_ullava.main) parsed from the reference checkout when it is there
+    (the build container); the test executes THOSE lines against the shim -- nothing of the reference is kept in this repository."""
+    import ast
+    src = open(os.path.join(REFERENCE, "train_ullava.py")).read()
+    tree = ast.parse(src)
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "find_linear_layers")
+    blk = next(n for n in ast.walk(tree) if isinstance(n, ast.If) and isinstance(n.test, ast.Compare) and isinstance(n.test.left, ast.Name)
+               and n.test.left.id == "lora_r")
+    return fn, blk
+
+
+def test_peft_shim_runs_the_references_lora_call_sites(tmp_path, capsys):
+    """`from peft import LoraConfig, get_peft_model, PeftModel` resolves to u-llava_amd/shim/peft; the reference's own LoRA lines
+    (train_ullava.py:88-113 find_linear_layers, :217-245 the lora_r > 0 block, :71-79 the is_peft state-dict filter, :291 save_pretrained,
+    inference_ullava.py:43 PeftModel.from_pretrained) run against it unchanged."""
+    import ast
+    import sys
+    import types
+    shim = os.path.join(ROOT, "u-llava_amd", "shim")
+    saved_path, saved_mod = list(sys.path), sys.modules.pop("peft", None)
+    sys.path.insert(0, shim)
+    try:
+        import peft
+        assert peft.__file__.startswith(shim) and peft.__version__.endswith("ullava_amd")
+        from peft import LoraConfig, PeftModel, get_peft_model
+        C, M, MC = pkg("configuration"), pkg("modeling_ullava"), pkg("modeling_core")
+        cfg = C.UllavaConfig(llm_config=dict(vision_config=dict(hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                                                                image_size=28, patch_size=14), vocab_size=120, hidden_size=64, intermediate_size=128,
+                                             num_hidden_layers=3, num_attention_heads=4), seg_token_idx=101, loc_token_idx=102, out_dim=256,
+                             sam_config=dict(embed_dim=32, depth=2, num_heads=2, global_attn_indexes=[1]))
+
+        def build():
+            m = M.UllavaForCausalLM(cfg)
+            g = torch.Generator().manual_seed(0)
+            for p in list(m.parameters()) + list(m.buffers()):
+                p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.dtype))
+            return m
+        model = build()
+        assert isinstance(model.llm.model.layers[0].self_attn.q_proj, torch.nn.Linear)
+        assert isinstance(model.llm.lm_head, torch.nn.Linear) and model.llm.lm_head.bias is None and "lm_head.bias" not in model.llm.state_dict()
+        ns = dict(torch=torch, LoraConfig=LoraConfig, get_peft_model=get_peft_model, print=print, model=model, lora_r=4,
+                  model_args=types.SimpleNamespace(lora_r=4, lora_alpha=8, lora_dropout=0.05, lora_target_modules="q_proj,v_proj"))
+        if os.path.isdir(REFERENCE):
+            fn, blk = _reference_source_nodes()
+            exec(compile(ast.Module(body=[fn], type_ignores=[]), "train_ullava.py", "exec"), ns)
+            names = ns["find_linear_layers"](model.llm, ["q_proj", "v_proj"])
+            assert names == sorted(f"model.layers.{i}.self_attn.{k}" for i in range(3) for k in ("q_proj", "v_proj"))
+            exec(compile(ast.Module(body=[blk], type_ignores=[]), "train_ullava.py", "exec"), ns)        # model.llm = get_peft_model(...); print_trainable...
+        else:
+            names = sorted(f"model.layers.{i}.self_attn.{k}" for i in range(3) for k in ("q_proj", "v_proj"))
+            model.llm = get_peft_model(model.llm, LoraConfig(r=4, lora_alpha=8, target_modules=names, lora_dropout=0.05, bias="none", task_type="CAUSAL_LM"))
+            model.llm.print_trainable_parameters()
+        out = capsys.readouterr().out
+        assert "trainable params:" in out and "all params:" in out
+        assert isinstance(model.llm, PeftModel) and isinstance(model.llm.get_base_model(), MC.UllavaCoreForCausalLM)
+        core = model.llm.get_base_model()
+        assert core._lora == {"r": 4, "lora_alpha": 8.0, "lora_dropout": 0.05, "target_modules": ("q_proj", "v_proj")}
+        train_names = [n for n, p in model.named_parameters() if p.requires_grad and n.startswith("llm.")]
+        assert train_names and all(".lora_A." in n or ".lora_B." in n for n in train_names)
+        assert not hasattr(core.model.layers[0].self_attn.k_proj, "lora_A")
+        # attribute reads and writes fall through the wrapper (the MI355X model invalidates packs by assignment)
+        # (`.model` of a PeftModel is the wrapped language model itself -- LoraModel.model -- exactly as in PEFT)
+        assert model.llm.config is core.config and model.llm.model is core and model.llm.model.model is core.model
+        assert model.llm.dtype == core.dtype and model.dtype == core.dtype
+        core._packed = {"stale": True}
+        model.llm._packed = None
+        assert core._packed is None and "_packed" not in model.llm.__dict__
+        # train_ullava.py:71-79 `safe_save_model_for_hf_trainer(is_peft=True)`: the key filter must give back the un-wrapped model's key names
+        plain = set(build().state_dict())
+        filtered = {k.replace(".base_model.model", ""): v for k, v in model.state_dict().items() if "lora_" not in k}
+        assert set(filtered) == plain
+        # :291 model.llm.save_pretrained(output_dir): adapter files only, PEFT's key layout
+        with torch.no_grad():
+            for l in core.model.layers:
+                l.self_attn.q_proj.lora_B.weight.normal_(0, 0.05)
+                l.self_attn.v_proj.lora_B.weight.normal_(0, 0.05)
+        model.llm.save_pretrained(str(tmp_path))
+        assert sorted(os.listdir(tmp_path)) == ["adapter_config.json", "adapter_model.safetensors"]
+        from safetensors.torch import load_file
+        ad = load_file(str(tmp_path / "adapter_model.safetensors"))
+        assert len(ad) == 3 * 2 * 2 and all(k.startswith("base_model.model.model.layers.") for k in ad)
+        # inference_ullava.py:43: PeftModel.from_pretrained(model.llm, llm_path, torch_dtype=dtype) on a fresh model: the adapter is folded in with
+        # PEFT's merge arithmetic (16-bit product, 16-bit scaling, 16-bit sum)
+        fresh = build()
+        w0 = fresh.llm.model.layers[1].self_attn.v_proj.weight.detach().clone()
+        k0 = fresh.llm.model.layers[1].self_attn.k_proj.weight.detach().clone()
+        fresh.llm = PeftModel.from_pretrained(fresh.llm, str(tmp_path), torch_dtype=torch.bfloat16)
+        lin = core.model.layers[1].self_attn.v_proj
+        d = (lin.lora_B.weight.float() @ lin.lora_A.weight.float()).to(torch.bfloat16)
+        want = (w0.float() + (d.float() * 2.0).to(torch.bfloat16).float()).to(torch.bfloat16)
+        merged = fresh.llm.get_base_model().model.layers[1].self_attn
+        got = merged.v_proj.weight.detach()
+        assert torch.equal(got, want) and not torch.equal(got, w0)
+        assert torch.equal(merged.k_proj.weight.detach(), k0) and not hasattr(merged.v_proj, "lora_A")
+        with pytest.raises(NotImplementedError):
+            get_peft_model(build().llm, LoraConfig(r=4, target_modules=["o_proj"]))
+    finally:
+        sys.path[:] = saved_path
+        sys.modules.pop("peft", None)
+        if saved_mod is not None:
+            sys.modules["peft"] = saved_mod

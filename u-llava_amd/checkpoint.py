@@ -111,15 +111,7 @@ def save_pretrained(model: torch.nn.Module, path: str, max_shard_bytes: int = 5 
     if lora:
         # train_ullava.py:287-289 with lora_r > 0: the base / head weights as above, the adapter beside them the way
         # PeftModel.save_pretrained writes it (keys relative to the wrapped language model)
-        core = getattr(model, "llm", model)
-        lc = getattr(core, "_lora", None) or {}
-        from safetensors.torch import save_file as _save_adapter
-        _save_adapter({"base_model.model." + (k[4:] if k.startswith("llm.") else k): v for k, v in lora.items()},
-                      os.path.join(path, "adapter_model.safetensors"), metadata={"format": "pt"})
-        with open(os.path.join(path, "adapter_config.json"), "w") as f:
-            json.dump({"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": lc.get("r"), "lora_alpha": lc.get("lora_alpha"),
-                       "lora_dropout": lc.get("lora_dropout", 0.0), "target_modules": list(lc.get("target_modules", ())), "bias": "none",
-                       "fan_in_fan_out": False, "inference_mode": True}, f, indent=2, sort_keys=True)
+        save_lora_adapter(getattr(model, "llm", model), path)
     shards, cur, size = [], {}, 0
     for k in sorted(sd):
         n = sd[k].numel() * sd[k].element_size()
@@ -150,6 +142,22 @@ def save_pretrained(model: torch.nn.Module, path: str, max_shard_bytes: int = 5 
     total = sum(v.numel() * v.element_size() for v in sd.values())
     with open(os.path.join(path, f"{stem}.{ext}.index.json"), "w") as f:
         json.dump({"metadata": {"total_size": total}, "weight_map": wm}, f, indent=2, sort_keys=True)
+
+
+def save_lora_adapter(core: torch.nn.Module, path: str) -> None:
+    """PeftModel.save_pretrained (train_ullava.py:291 `model.llm.save_pretrained(output_dir)`): adapter_config.json + adapter_model.safetensors,
+    keys `base_model.model.<module path relative to the language model>.lora_A|lora_B.weight`."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    lc = getattr(core, "_lora", None)
+    if lc is None:
+        raise RuntimeError("u-llava_amd: no LoRA adapter is attached to this model")
+    sd = {"base_model.model." + k: v.detach().to("cpu").contiguous() for k, v in core.state_dict().items() if ".lora_A." in k or ".lora_B." in k}
+    save_file(sd, os.path.join(path, "adapter_model.safetensors"), metadata={"format": "pt"})
+    with open(os.path.join(path, "adapter_config.json"), "w") as f:
+        json.dump({"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": lc.get("r"), "lora_alpha": lc.get("lora_alpha"),
+                   "lora_dropout": lc.get("lora_dropout", 0.0), "target_modules": list(lc.get("target_modules", ())), "bias": "none",
+                   "fan_in_fan_out": False, "inference_mode": True}, f, indent=2, sort_keys=True)
 
 
 def _dtype_arg(torch_dtype):
@@ -210,7 +218,18 @@ def ullava_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict
 # adapter is MERGED into the base weights at load time instead: W += (lora_alpha / r) * B @ A for every target module -- what
 # `PeftModel.merge_and_unload()` leaves behind.  Reads the files PEFT writes (adapter_config.json + adapter_model.safetensors / .bin,
 # keys `base_model.model.<module path>.lora_A[.<adapter>].weight` [r, in] and `.lora_B[...].weight` [out, r]).  Host-side weight
-# preparation like the rest of this file; the product of the two small matrices is taken in fp32.
+# preparation like the rest of this file, with PEFT's own rounding points (lora_merged_weight).
+def lora_merged_weight(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float) -> torch.Tensor:
+    """PEFT 0.4.0 (the reference's pin, shells/requirements.txt:25) tuners/lora.py `Linear.merge`:
+    `self.weight.data += (lora_B.weight @ lora_A.weight) * scaling`, every operand in the weights' 16-bit dtype -- so the product B A is
+    rounded to 16 bits (fp32 accumulation over r), the scaling rounds again, the sum a third time.  Restated with those three roundings
+    (weight preparation, not the forward path: torch fp32 arithmetic, rounded where PEFT's tensors are 16-bit)."""
+    dt = w.dtype
+    d = (B.detach().float() @ A.detach().float()).to(dt)
+    d = (d.float() * float(scaling)).to(dt)
+    return (w.detach().float() + d.float().to(w.device)).to(dt)
+
+
 def has_lora_adapter(path: str) -> bool:
     return os.path.isfile(os.path.join(path, "adapter_config.json")) and any(
         os.path.isfile(os.path.join(path, f)) for f in ("adapter_model.safetensors", "adapter_model.bin"))
@@ -248,16 +267,15 @@ def merge_lora_adapter(llm: torch.nn.Module, path: str, adapter_name: str = "def
             target = modules.get(mod)
             if target is None or not hasattr(target, "weight"):
                 raise RuntimeError(f"u-llava_amd: adapter target {mod} is not a module of the model")
-            A, B = ab["lora_A"].float(), ab["lora_B"].float()
+            A, B = ab["lora_A"], ab["lora_B"]
             if A.shape[0] != r or B.shape[1] != r:
                 raise RuntimeError(f"u-llava_amd: adapter rank mismatch on {mod}: A {tuple(A.shape)}, B {tuple(B.shape)}, r = {r}")
-            delta = (B @ A) * (alpha / r)
-            if fan_in_fan_out:
-                delta = delta.t()
             w = target.weight
-            if tuple(delta.shape) != tuple(w.shape):
-                raise RuntimeError(f"u-llava_amd: adapter delta {tuple(delta.shape)} does not fit {mod}.weight {tuple(w.shape)}")
-            w.copy_((w.detach().float().cpu() + delta).to(w.dtype).to(w.device))
+            if fan_in_fan_out:
+                raise NotImplementedError("fan_in_fan_out adapters (Conv1D targets) do not occur on this path: every target is an nn.Linear")
+            if (B.shape[0], A.shape[1]) != tuple(w.shape):
+                raise RuntimeError(f"u-llava_amd: adapter delta {(B.shape[0], A.shape[1])} does not fit {mod}.weight {tuple(w.shape)}")
+            w.copy_(lora_merged_weight(w.detach().cpu(), A.to(w.dtype), B.to(w.dtype), alpha / r).to(w.device))
             merged.append(mod)
     if hasattr(llm, "_packed"):
         llm._packed = None                                   # fused q|k|v / tile-major copies describe the old weights

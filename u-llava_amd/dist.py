@@ -59,6 +59,16 @@ def _flat_buckets(grads, bucket_bytes: int):
 
 
 _DIRECT_DTYPES = (torch.bfloat16, torch.float16)          # element types `ull_sum_slabs` has a build for
+_KERNELS = None                                           # module that provides sum_slabs(); None = u-llava_amd.ops (the HIP kernels)
+
+
+def _kernels():
+    """The kernel module of the direct exchange.  `ops` (HIP only) unless a test has put a restatement in `_KERNELS` to drive the
+    collective sequence itself over gloo on CPU ranks; the product never sets it."""
+    if _KERNELS is not None:
+        return _KERNELS
+    from . import ops
+    return ops
 
 
 def allreduce_gradients(params, bucket_bytes: int = 512 << 20, group=None, force_direct: bool = False) -> int:
@@ -107,8 +117,8 @@ def allreduce_gradients(params, bucket_bytes: int = 512 << 20, group=None, force
             fb[o:o + g.numel()].copy_(g.reshape(-1))
             o += g.numel()
         fb[o:].zero_()
-        if direct_backend and dt in _DIRECT_DTYPES and dev.type == "cuda":
-            from . import ops
+        if direct_backend and dt in _DIRECT_DTYPES and (dev.type == "cuda" or force_direct):
+            ops = _kernels()
             if recv is None:
                 recv = torch.empty_like(flat)
             rb = recv[:shard * world]

@@ -45,17 +45,36 @@ def _dealias_state_dict(module, state_dict, prefix, local_metadata):
     tensors that own their storage (safetensors refuses shared memory; HF Trainer._save writes state_dict() as it is)."""
     for k in list(state_dict.keys()):
         v = state_dict[k]
+        if isinstance(v, nn.Parameter):
+            continue                 # state_dict(keep_vars=True): the caller asked for the parameters themselves, aliased or not
         if k.startswith(prefix) and isinstance(v, torch.Tensor) and v.untyped_storage().nbytes() > v.numel() * v.element_size() + 64:
             state_dict[k] = v.clone()
     return state_dict
 
 
-class Linear(nn.Module):
+class Linear(nn.Linear):
+    """An `nn.Linear` by type and by state-dict layout -- `isinstance(m, torch.nn.Linear)` is how the reference picks its LoRA targets
+    (train_ullava.py:88-113 `find_linear_layers`) and how HF utilities classify parameters -- whose storage is left UNINITIALISED at
+    construction (nn.Linear.__init__ would run a kaiming init over 7 B parameters on the host; weights arrive from a checkpoint or a
+    seeded generator) and whose `forward` is the HIP GEMM.  The model code never calls it (the projections are operands of fused launches);
+    it exists for callers that treat the module as a layer."""
+
     def __init__(self, in_features, out_features, bias=True, device=None, dtype=BF16):
-        super().__init__()
+        nn.Module.__init__(self)
         self.in_features, self.out_features = in_features, out_features
         self.weight = _param(out_features, in_features, device=device, dtype=dtype)
-        self.bias = _param(out_features, device=device, dtype=dtype) if bias else None
+        if bias:
+            self.bias = _param(out_features, device=device, dtype=dtype)
+        else:
+            self.register_parameter("bias", None)
+
+    def reset_parameters(self) -> None:
+        raise RuntimeError("u-llava_amd: parameters are loaded, never re-initialised in place")
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return A.linear(x, self.weight, self.bias)
+        return ops.linear(x, self.weight, self.bias)
 
 
 class Embedding(nn.Module):
@@ -247,6 +266,7 @@ class UllavaCoreForCausalLM(nn.Module):
         self._packed = None
         _clear_transposes()          # cached W^T copies of the training path describe the old weights
         self._inv_freq = None
+        self._reset_alias_slots()    # every parameter is a fresh tensor: the training path may alias them anew
         return out
 
     def get_input_embeddings(self):
@@ -315,8 +335,8 @@ class UllavaCoreForCausalLM(nn.Module):
             the adapters train: train_ullava.py's evaluation loop; the pack is rebuilt when the adapters change, see _pk)."""
             if lora is None or not hasattr(lin, "lora_A"):
                 return lin.weight
-            s_ = lora["lora_alpha"] / lora["r"]
-            return (lin.weight.float() + (lin.lora_B.weight.float() @ lin.lora_A.weight.float()) * s_).to(lin.weight.dtype)
+            from .checkpoint import lora_merged_weight
+            return lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, lora["lora_alpha"] / lora["r"])
         for l in self.model.layers:
             a, m = l.self_attn, l.mlp
             pk["llama"].append(dict(
@@ -348,6 +368,8 @@ class UllavaCoreForCausalLM(nn.Module):
                 ops.register_tiled(t)
         ops.register_tiled(self.lm_head.weight)
         pk["lora_versions"] = self._lora_versions()
+        pk["llama_versions"], pk["clip_versions"] = self._llama_versions(), self._clip_versions()
+        pk["freed"] = bool(free_originals)
         self._packed = pk
         if free_originals:
             for l in self.model.layers:
@@ -361,12 +383,31 @@ class UllavaCoreForCausalLM(nn.Module):
         return tuple(p_._version for l in self.model.layers for t in ("q_proj", "k_proj", "v_proj") if hasattr(getattr(l.self_attn, t), "lora_A")
                      for p_ in (getattr(l.self_attn, t).lora_A.weight, getattr(l.self_attn, t).lora_B.weight))
 
+    def _llama_versions(self):
+        """version counters of the LLaMA weights the packs hold COPIES of (q|k|v concatenated, gate|up interleaved)."""
+        return tuple(getattr(h, n).weight._version for l in self.model.layers
+                     for h, ns in ((l.self_attn, ("q_proj", "k_proj", "v_proj")), (l.mlp, ("gate_proj", "up_proj"))) for n in ns)
+
+    def _clip_versions(self):
+        ve = self.vision_encoder
+        return (ve.embeddings.patch_embedding.weight._version,) + tuple(
+            p_._version for l in ve.encoder.layers for n in ("q_proj", "k_proj", "v_proj") for p_ in (getattr(l.self_attn, n).weight,
+                                                                                                      getattr(l.self_attn, n).bias))
+
     def _pk(self, for_llama: bool = False):
-        """The packed weights.  for_llama (the inference LLaMA path): with un-merged LoRA adapters attached the q|k|v packs hold W + s B A,
-        so they are rebuilt when the adapters have changed since (an optimizer step bumps ._version).  The CLIP tower asks without the
-        check: a LoRA TRAINING forward needs only the CLIP packs, and re-packing 13.5 GB of LLaMA weights on every step because the
-        adapters moved cost 94 ms of device copies per step (profile of bench.py --workload train --train-config lora)."""
-        if self._packed is None or (for_llama and self._packed.get("lora_versions") != self._lora_versions()):
+        """The packed weights, re-made when a parameter they were copied from has been written since (`._version`: an optimizer step's
+        in-place update, load_state_dict, merge_lora ...).  for_llama (the inference LLaMA path) also checks the LLaMA packs: the q|k|v
+        concatenations / gate|up interleaves of the base weights, and with un-merged LoRA adapters attached the adapters too (the packs
+        then hold W + s B A).  The CLIP tower asks without that check: a TRAINING forward needs only the CLIP packs (its LLaMA half reads
+        the parameters through _alias_pack), and re-packing 13.5 GB of LLaMA weights on every step because the parameters moved cost
+        94 ms of device copies per step (profile of bench.py --workload train --train-config lora)."""
+        pk = self._packed
+        if pk is None:
+            return self.pack_weights()._packed
+        if pk.get("freed"):
+            return pk                        # pack_weights(free_originals=True): the packs are the only copy, nothing to compare with
+        if pk["clip_versions"] != self._clip_versions() or (for_llama and (
+                pk["llama_versions"] != self._llama_versions() or pk.get("lora_versions") != self._lora_versions())):
             self.pack_weights()
         return self._packed
 
@@ -493,12 +534,12 @@ class UllavaCoreForCausalLM(nn.Module):
         if cfg is None:
             return self
         s_ = cfg["lora_alpha"] / cfg["r"]
+        from .checkpoint import lora_merged_weight
         with torch.no_grad():
             for l in self.model.layers:
                 for t in cfg["target_modules"]:
                     lin = getattr(l.self_attn, t)
-                    delta = (lin.lora_B.weight.float() @ lin.lora_A.weight.float()) * s_
-                    lin.weight.copy_((lin.weight.float() + delta).to(lin.weight.dtype))
+                    lin.weight.copy_(lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, s_))
                     del lin.lora_A, lin.lora_B
         self._lora = None
         self._packed = None
@@ -529,28 +570,60 @@ class UllavaCoreForCausalLM(nn.Module):
     def gradient_checkpointing_disable(self):
         self.config.gradient_checkpointing = False
 
+    alias_packed_weights = True          # training path: q|k|v and gate|up parameters as row slices of one buffer each (see _alias_pack)
+
     @staticmethod
-    def _alias_pack(holder, names, slot):
+    def _alias_pack(holder, names, slot, enabled: bool = True):
         """Make the parameters `names` of `holder` row slices of ONE [sum(N_i), K] buffer (storage shared; values, shapes, names and
-        state-dict entries unchanged) and return that buffer.  Re-done whenever the aliasing was lost (.to(), a fresh Parameter)."""
+        state-dict entries unchanged) and return (that buffer, the parameters).
+
+        The aliasing is established ONCE per holder (and again after .to() / .half(), which re-create every parameter: _apply clears the
+        slots).  If it is found broken later -- a parameter's `.data` no longer points into the buffer -- somebody else has taken
+        ownership of the parameter storage (DeepSpeed ZeRO-1/2 rebinds p.data to its flat bit16 partition, FSDP to its flat parameter):
+        rebinding `.data` again would detach the parameters from that owner and its updates would never be seen.  The holder is then
+        marked and this function returns (None, params): the caller concatenates the live parameters under autograd instead (one
+        device copy per step, always correct).  `model.alias_packed_weights = False` turns the aliasing off altogether."""
         ws = [getattr(holder, n).weight for n in names]
+        if not enabled or getattr(holder, slot + "_external", False):
+            return None, ws
         packed = getattr(holder, slot, None)
-        ok = packed is not None and packed.device == ws[0].device and packed.dtype == ws[0].dtype
-        if ok:
+        if packed is not None:
+            ok = packed.device == ws[0].device and packed.dtype == ws[0].dtype
             o = 0
             for w in ws:
                 ok = ok and w.data_ptr() == packed.data_ptr() + o * packed.shape[1] * packed.element_size() and w.is_contiguous()
                 o += w.shape[0]
-            ok = ok and o == packed.shape[0]
-        if not ok:
-            with torch.no_grad():
-                packed = torch.cat([w.data for w in ws], dim=0).contiguous()
-                o = 0
-                for w in ws:
-                    w.data = packed[o:o + w.shape[0]]
-                    o += w.shape[0]
-            object.__setattr__(holder, slot, packed)             # a plain attribute: not a Parameter, not a buffer, not in the state dict
+            if ok and o == packed.shape[0]:
+                return packed, ws
+            object.__setattr__(holder, slot, None)
+            object.__setattr__(holder, slot + "_external", True)          # storage re-bound by an external owner: leave it alone
+            return None, ws
+        with torch.no_grad():
+            packed = torch.cat([w.data for w in ws], dim=0).contiguous()
+            o = 0
+            for w in ws:
+                w.data = packed[o:o + w.shape[0]]
+                o += w.shape[0]
+        object.__setattr__(holder, slot, packed)             # a plain attribute: not a Parameter, not a buffer, not in the state dict
         return packed, ws
+
+    def _reset_alias_slots(self):
+        """after _apply (.to / .cuda / .half): where the move re-created the parameters the shared buffers describe dead tensors -- drop them
+        (and any `external owner` mark) so that the next training forward aliases the new parameters; a no-op move keeps the aliasing."""
+        for l in self.model.layers:
+            for h, slot, names in ((l.self_attn, "_qkv_pack", ("q_proj", "k_proj", "v_proj")), (l.mlp, "_gu_pack", ("gate_proj", "up_proj"))):
+                packed = h.__dict__.get(slot)
+                if packed is not None:
+                    ws, o, ok = [getattr(h, n).weight for n in names], 0, True
+                    for w in ws:
+                        ok = ok and w.device == packed.device and w.dtype == packed.dtype and \
+                            w.data_ptr() == packed.data_ptr() + o * packed.shape[1] * packed.element_size()
+                        o += w.shape[0]
+                    if ok:
+                        continue
+                for a in (slot, slot + "_external"):
+                    if a in h.__dict__:
+                        object.__delattr__(h, a)
 
     def _llama_train(self, inputs_embeds, attention_mask, position_ids, output_hidden_states):
         """LlamaModel.forward with an autograd graph: the same HIP forward kernels (SwiGLU un-fused, RoPE stand-alone, weights
@@ -574,10 +647,11 @@ class UllavaCoreForCausalLM(nn.Module):
             a, m = l.self_attn, l.mlp
             # q|k|v and gate|up are each ONE buffer whose row slices are the parameters (no per-step torch.cat / interleave of trainable
             # weights, one dW GEMM per pack whose row slices are the parameters' gradients)
-            w_qkv, qkv_w = self._alias_pack(a, ("q_proj", "k_proj", "v_proj"), "_qkv_pack")
+            w_qkv, qkv_w = self._alias_pack(a, ("q_proj", "k_proj", "v_proj"), "_qkv_pack", self.alias_packed_weights)
             x, x_res = A.fork(x)                                 # two consumers: the norm and the residual add of o_proj
             h = A.rmsnorm(x, l.input_layernorm.weight, cfg.rms_norm_eps)
-            qkv_lin = A.linear_packed(h, w_qkv, *qkv_w)
+            # (no shared buffer -- an external owner holds the parameter storage, see _alias_pack: concatenate under autograd)
+            qkv_lin = A.linear_packed(h, w_qkv, *qkv_w) if w_qkv is not None else A.linear(h, torch.cat(qkv_w, dim=0))
             if getattr(self, "_lora", None) is not None:
                 # PEFT's Linear.forward: result += lora_B(lora_A(dropout(x))) * scaling -- here as two skinny GEMMs for the whole q|k|v row,
                 # the base projection riding along as the second one's residual operand
@@ -589,8 +663,8 @@ class UllavaCoreForCausalLM(nn.Module):
             x = A.linear(att, a.o_proj.weight, residual=x_res)
             x, x_res = A.fork(x)
             h = A.rmsnorm(x, l.post_attention_layernorm.weight, cfg.rms_norm_eps)
-            w_gu, gu_w = self._alias_pack(m, ("gate_proj", "up_proj"), "_gu_pack")
-            gu = A.linear_packed(h, w_gu, *gu_w)                 # columns [gate | up]
+            w_gu, gu_w = self._alias_pack(m, ("gate_proj", "up_proj"), "_gu_pack", self.alias_packed_weights)
+            gu = A.linear_packed(h, w_gu, *gu_w) if w_gu is not None else A.linear(h, torch.cat(gu_w, dim=0))      # columns [gate | up]
             x = A.linear(A.swiglu(gu, halves=True), m.down_proj.weight, residual=x_res)
         x = A.rmsnorm(x, self.model.norm.weight, cfg.rms_norm_eps)
         last = x.view(B, S, D)
@@ -672,7 +746,9 @@ class UllavaCoreForCausalLM(nn.Module):
         fuse_rope = hd == 128 and T > 4 and D % 64 == 0 and not (cache is not None and past > 0)
         # generation steps of at most 4 tokens (the GEMV shapes): RoPE and the cache append run in the q|k|v GEMV's epilogue, from the
         # same per-forward table
-        fuse_append = cache is not None and past > 0 and T <= 4 and hd % 2 == 0 and D % 8 == 0
+        # (that kernel stages the T x D activations in 32 KB of LDS: LLaMA-7B at T = 4 is exactly the limit; wider models / more rows take the
+        # stand-alone RMSNorm + RoPE-append kernels below)
+        fuse_append = cache is not None and past > 0 and T <= 4 and hd % 2 == 0 and D % 8 == 0 and T * D * 2 <= 32768
         rope_cs = ops.rope_table(pos, inv_freq, x.dtype) if (fuse_rope or fuse_append) else None
         all_h = []
         for li, w in enumerate(pk["llama"]):

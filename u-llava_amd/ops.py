@@ -75,7 +75,7 @@ def _rows(t: torch.Tensor):
 
 
 EPI_W_TILED = 64
-_TILED = {}          # data_ptr of a row-major weight -> (weakref to it, its tile-major copy)
+_TILED = {}          # data_ptr of a row-major weight -> (weakref to it, its tile-major copy, the weight's ._version the copy was made from)
 
 
 def tile_major(w: torch.Tensor) -> torch.Tensor:
@@ -89,20 +89,25 @@ def tile_major(w: torch.Tensor) -> torch.Tensor:
 
 def register_tiled(w: torch.Tensor) -> None:
     """Keep a tile-major copy of a weight for the prefill-shape GEMM (the row-major original still feeds the decode GEMV)."""
-    import weakref
     if w.dim() == 2 and w.shape[1] % 64 == 0 and w.shape[0] >= 512 and w.shape[1] >= 128 and w.is_contiguous():
         ptr = w.data_ptr()
-        _TILED[ptr] = (weakref.ref(w, lambda _r, _p=ptr: _TILED.pop(_p, None) if (_TILED.get(_p) or (None,))[0] is _r else None),
-                       tile_major(w))                     # the copy is dropped when the weight tensor dies
+        _TILED[ptr] = [weakref.ref(w, lambda _r, _p=ptr: _TILED.pop(_p, None) if (_TILED.get(_p) or (None,))[0] is _r else None),
+                       tile_major(w.detach()), w._version]    # the copy is dropped when the weight tensor dies
 
 
 def _tiled_of(w: torch.Tensor):
+    """The tile-major copy of `w`, or None.  The copy describes the weight AS IT WAS when the copy was made: an in-place update since
+    (an optimizer step's `p.copy_`, `load_state_dict`, `merge_lora`) bumps `w._version`, and the copy is then re-made from the live
+    values before it is handed out -- a training run must never multiply by step-0 weights."""
     e = _TILED.get(w.data_ptr())
     if e is None:
         return None
     if e[0]() is not w:
         _TILED.pop(w.data_ptr(), None)       # the address was recycled by another tensor
         return None
+    if e[2] != w._version:
+        e[1].copy_(tile_major(w.detach()))
+        e[2] = w._version
     return e[1]
 
 
