@@ -180,6 +180,65 @@ def gemm_roofline(cfg, tokens, device, iters=40, warm=10):
                 traffic=traffic, traffic_detail=detail, per_launch=per)
 
 
+def _time_launches(fn, iters=40, warm=10):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def sam_gemm_roofline(device, batch=8):
+    """The RES half of the metric: the four Linear launches of one SAM ViT-H block (image_encoder.py:196-260, common.py:13-26) at the RES
+    workload's token count (batch x 4096 tokens, d = 1280, MLP 5120) with their real epilogues -- qkv + bias, proj + bias + residual,
+    lin1 + bias + erf-GELU, lin2 + bias + residual -- timed like gemm_roofline (HIP events on the launch stream), 2 * M * N * K flop per
+    launch.  These K = 1280 launches are 44 % of a RES step and the kernels furthest below the LLaMA layer's rate."""
+    ops = importlib.import_module("u-llava_amd.ops")
+    M, D, I = batch * 4096, 1280, 5120
+    g = torch.Generator(device="cuda").manual_seed(8)
+    shapes = [("qkv+bias", 3 * D, D, None, False), ("proj+bias+residual", D, D, None, True), ("lin1+bias+gelu", I, D, "gelu", False),
+              ("lin2+bias+residual", D, I, None, True)]
+    per, tot_t, tot_f = [], 0.0, 0.0
+    for name, N, K, act, res in shapes:
+        x = torch.randn(M, K, device=device, generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=device, generator=g) * K ** -0.5).to(torch.bfloat16)
+        b = torch.randn(N, device=device, generator=g).to(torch.bfloat16)
+        r = torch.randn(M, N, device=device, generator=g).to(torch.bfloat16) if res else None
+        ops.register_tiled(w)
+        out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+        ms = _time_launches(lambda: ops.linear(x, w, b, act=act, residual=r, out=out))
+        fl = 2.0 * M * N * K
+        per.append(dict(gemm=name, M=M, N=N, K=K, ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
+        tot_t += ms
+        tot_f += fl
+    ach = tot_f / tot_t / 1e9
+    return dict(bound="mfma", kernel="big::gemm256w4_kernel / gemm256d_kernel (SAM ViT-H block: qkv, proj, lin1 + GELU, lin2; 2*M*N*K flop per launch)",
+                achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
+                us_per_block=round(tot_t * 1e3, 1), per_launch=per)
+
+
+def patchify_record(device, batch=32, image=336):
+    """north_star's HBM target line: ViT patchify at batch 32 -- Conv2d(3, 1024, 14, stride 14) straight from the pixels (`ull_patchify_*`) --
+    algorithmic bytes (pixels in + patches out + packed weights, BASELINE.md section 2: 60.6 MB at 336^2) over the average launch time."""
+    ops = importlib.import_module("u-llava_amd.ops")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    img = torch.randn(batch, 3, image, image, device=device, generator=g).to(torch.bfloat16)
+    w = (torch.randn(1024, 3, 14, 14, device=device, generator=g) * 0.02).to(torch.bfloat16)
+    wp = ops.pack_patch_weight(w)
+    ms = _time_launches(lambda: ops.patchify(img, wp, 14), iters=100, warm=20)
+    P = (image // 14) ** 2
+    nbytes = img.numel() * 2 + batch * P * 1024 * 2 + wp.numel() * 2
+    gbps = nbytes / ms / 1e6
+    return dict(kernel="big::patchify_strip_kernel (A tiles DMA'd from the pixels)", batch=batch, image=image, us=round(ms * 1e3, 2),
+                algorithmic_bytes=nbytes, GBps=round(gbps, 1), peak_GBps=8000.0, frac_hbm=round(gbps / 8000.0, 4),
+                mfma_tflops=round(2.0 * batch * P * 1024 * wp.shape[1] / ms / 1e9, 1),
+                note="north_star target 0.60; a GEMM-shaped patchify is MFMA-time bound below ~40 % of HBM peak (DESIGN.md, patchify)")
+
+
 def _cpu_model_name():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -217,6 +276,7 @@ def _c1_state_dict(device, n_llama=32, n_clip=24, P=256, V=32011):
     ve = "vision_encoder."
     mat(ve + "embeddings.class_embedding", Dv); mat(ve + "embeddings.patch_embedding.weight", Dv, 3, 14, 14)
     mat(ve + "embeddings.position_embedding.weight", P + 1, Dv); one(ve + "pre_layrnorm.weight", Dv); zero(ve + "pre_layrnorm.bias", Dv)
+    one(ve + "post_layernorm.weight", Dv); zero(ve + "post_layernorm.bias", Dv)       # (dead on this path: vision_hidden_layer = -2)
     for l in range(n_clip):
         p = f"{ve}encoder.layers.{l}."
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
@@ -227,11 +287,77 @@ def _c1_state_dict(device, n_llama=32, n_clip=24, P=256, V=32011):
     return sd
 
 
+C1_VCFG = dict(hidden_size=1024, num_attention_heads=16, num_hidden_layers=24, intermediate_size=4096, image_size=224, patch_size=14,
+               num_channels=3, layer_norm_eps=1e-5)
+
+
+def c1_case(seed=5, prompt_tokens=32, V=32011):
+    """The C1 inputs (BASELINE.json configs[0]: one 224x224 image + 32-token prompt, S = 291) and the oracle's config dict for
+    ViT-L/14-224 + LLaMA-7B.  Host tensors from a CPU generator: the same on every box."""
+    cfg = dict(hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, intermediate_size=11008, vocab_size=V, rms_norm_eps=1e-6,
+               rope_theta=10000.0, vision_hidden_layer=-2, projector_type="mlp", mm_token_ids=dict(MM), vision_config=dict(C1_VCFG))
+    g = torch.Generator().manual_seed(seed)
+    P = 256
+    ids = torch.tensor([[1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * P + [MM["IMG_END"]] + torch.randint(5, 32000, (prompt_tokens,), generator=g).tolist()])
+    mask = torch.ones_like(ids)
+    img = torch.randn(1, 3, 224, 224, generator=g).to(torch.bfloat16)
+    return cfg, ids, mask, img
+
+
+def c1_hip_model(sd, device, n_llama=32):
+    """The MI355X model holding the very weights of `sd` (the oracle's state dict, host bf16): same values on both sides of a parity check."""
+    C = importlib.import_module("u-llava_amd.configuration")
+    M = importlib.import_module("u-llava_amd.modeling_core")
+    cfg = C.UllavaCoreConfig(vision_config=dict(image_size=224, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
+                             projector_from_scratch=False, mm_token_ids=dict(MM), vocab_size=sd["lm_head.weight"].shape[0], num_hidden_layers=n_llama)
+    model = M.UllavaCoreForCausalLM(cfg, device=device)
+    model.load_state_dict(sd, strict=True)
+    model.strict_checks = False
+    return model
+
+
+class F32View(dict):
+    """The oracle's fp32 "truth" run on 16-bit-rounded weights without a second 28 GB copy: every read hands out an fp32 copy of ONE tensor."""
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self, k).float()
+
+    def get(self, k, default=None):
+        return dict.__getitem__(self, k).float() if k in self else default
+
+
+def parity_stats(hip_logits, oracle_logits, truth_logits, k=4.0):
+    """HIP logits vs the oracle's bf16 logits vs the oracle's fp32 logits on the same inputs and weights ([S, V] each).  `gated_exact`: at every
+    position whose fp32 top-1 / top-2 gap exceeds k x the measured bf16 noise of a logit DIFFERENCE at that position -- sqrt(2) x the rms of
+    (oracle_bf16 - fp32) over the vocabulary, i.e. the decision is k standard deviations away from flipping -- the three argmax token ids
+    are EQUAL: north_star's "token ids bit-exact" wherever 16-bit rounding cannot legitimately flip the decision.  (The max over the 32011
+    entries of a position is ~4.5 sigma of that noise and exceeds the MEDIAN top-2 gap of a random-init model: reported, not the gate.)"""
+    h, o, t = (x.detach().float().cpu().reshape(-1, x.shape[-1]) for x in (hip_logits, oracle_logits, truth_logits))
+    tmax = float(t.abs().max())
+    sigma = (o - t).pow(2).mean(-1).sqrt() * 2.0 ** 0.5
+    top2 = t.topk(2, dim=-1).values
+    gap = top2[:, 0] - top2[:, 1]
+    gated = gap > k * sigma
+    ah, ao, at = h.argmax(-1), o.argmax(-1), t.argmax(-1)
+    exact = (ah == ao) & (ao == at)
+    return dict(positions=int(h.shape[0]), max_rel=round(float((h - o).abs().max()) / tmax, 6),
+                hip_err_vs_fp32=round(float((h - t).abs().max()) / tmax, 6), oracle_err_vs_fp32=round(float((o - t).abs().max()) / tmax, 6),
+                hip_rms_vs_fp32=round(float((h - t).pow(2).mean().sqrt()), 5), oracle_rms_vs_fp32=round(float((o - t).pow(2).mean().sqrt()), 5),
+                argmax_agree=round(float((ah == ao).float().mean()), 4), argmax_agree_hip_fp32=round(float((ah == at).float().mean()), 4),
+                argmax_agree_oracle_fp32=round(float((ao == at).float().mean()), 4),
+                gate=f"fp32 top-1/top-2 gap > {k:g} x sqrt(2) x rms_v(oracle_bf16 - fp32) at that position", positions_gated=int(gated.sum()),
+                gated_exact=bool(exact[gated].all()), gated_mismatches=int((~exact[gated]).sum()),
+                median_gap=round(float(gap.median()), 4), median_diff_sigma=round(float(sigma.median()), 5),
+                max_abs_noise=round(float((o - t).abs().max()), 5))
+
+
 def cpu_baseline(device, c4_image=336, c4_prompt=64):
     """the oracle (torch-CPU bf16 restatement of the reference path) on ONE whole C1 forward -- 224x224 image +
     32-token prompt, S = 291, random-init ViT-L/14 (23 of 24 layers feed the projector) + all 32 LLaMA-7B layers + lm_head -- 1 warm-up +
-    3 timed forwards, median; thread count and CPU model stated.  Secondary record: the same oracle at the C4 shape (the GPU headline's
-    shape) from ONE and TWO CLIP / LLaMA layers, extrapolated linearly in layer count, with the 1- vs 2-layer check of that linearity."""
+    3 timed forwards, median; thread count and CPU model stated.  The logits of that forward are then compared with the HIP path's on the
+    same weights and inputs (`parity_vs_gpu`; the oracle as the CHECKER of the product, never the other way round), with the oracle's own
+    fp32 run as the truth that sets the noise gate.  Secondary record: the same oracle at the C4 shape (the GPU headline's shape) from ONE and
+    TWO CLIP / LLaMA layers, extrapolated linearly in layer count, with the 1- vs 2-layer check of that linearity."""
     from oracle import ullava_oracle as O
     t_build = time.perf_counter()
     sd = _c1_state_dict(device)
@@ -253,15 +379,9 @@ def cpu_baseline(device, c4_image=336, c4_prompt=64):
                 best_n, best_t = n, dt
     torch.set_num_threads(best_n)
     V, D = sd["lm_head.weight"].shape
-    vcfg = dict(hidden_size=1024, num_attention_heads=16, num_hidden_layers=24, intermediate_size=4096, image_size=224, patch_size=14,
-                num_channels=3, layer_norm_eps=1e-5)
-    cfg = dict(hidden_size=D, num_hidden_layers=32, num_attention_heads=32, intermediate_size=11008, vocab_size=V, rms_norm_eps=1e-6,
-               rope_theta=10000.0, vision_hidden_layer=-2, projector_type="mlp", mm_token_ids=dict(MM), vision_config=vcfg)
-    g = torch.Generator().manual_seed(5)
-    P = 256
-    ids = torch.tensor([[1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * P + [MM["IMG_END"]] + torch.randint(5, 32000, (32,), generator=g).tolist()])
-    mask = torch.ones_like(ids)
-    img = torch.randn(1, 3, 224, 224, generator=g).to(torch.bfloat16)
+    cfg, ids, mask, img = c1_case(V=V)
+    vcfg = cfg["vision_config"]
+    g = torch.Generator().manual_seed(6)
 
     def t(fn, n=3):
         fn()                                           # 1 warm-up
@@ -274,8 +394,25 @@ def cpu_baseline(device, c4_image=336, c4_prompt=64):
     with torch.no_grad():
         out = O.core_forward(sd, cfg, ids, mask, img)
         finite = bool(torch.isfinite(out["logits"].float()).all())
+        o_logits = out["logits"][0]
         del out
         t_c1 = t(lambda: O.core_forward(sd, cfg, ids, mask, img))
+        # parity of the product against this very forward: HIP model on the same weights + inputs, fp32 oracle run as the truth
+        parity = None
+        if device.type == "cuda":
+          try:
+            t0 = time.perf_counter()
+            truth = O.core_forward(F32View(sd), cfg, ids, mask, img.float())["logits"][0]
+            t_truth = time.perf_counter() - t0
+            hip_model = c1_hip_model(sd, device)
+            hip = hip_model.forward(input_ids=ids.to(device), attention_mask=mask.to(device), images=img.to(device)).logits[0]
+            parity = parity_stats(hip, o_logits, truth)
+            parity["fp32_truth_seconds"] = round(t_truth, 2)
+            parity["what"] = "HIP forward (cuda) vs this oracle forward vs the oracle in fp32: same 7.05 B random-init weights, same C1 inputs, logits [291, 32011]"
+            del hip_model, hip, truth
+            torch.cuda.empty_cache()
+          except Exception as e:                     # the comparison must never cost the bench line; a failure is REPORTED in its place
+            parity = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         # secondary: C4 shape from 1 and 2 layers (the 336-px position table is a fresh random one: timing only)
         P4 = (c4_image // 14) ** 2
         S4 = 2 + P4 + 1 + c4_prompt
@@ -293,7 +430,7 @@ def cpu_baseline(device, c4_image=336, c4_prompt=64):
     lin = dict(clip_layer_s_1=round(tc[1] - tc[0], 4), clip_layer_s_2nd=round(tc[2] - tc[1], 4),
                llama_layer_s_1=round(tl[1] - tl[0], 4), llama_layer_s_2nd=round(tl[2] - tl[1], 4))
     return dict(value=round(1.0 / t_c1, 4), unit="images/sec", cores=best_n, kind="port", cpu_model=_cpu_model_name(),
-                host_threads=os.cpu_count(), seconds_per_image=round(t_c1, 3), logits_finite=finite,
+                host_threads=os.cpu_count(), seconds_per_image=round(t_c1, 3), logits_finite=finite, parity_vs_gpu=parity,
                 sample=f"oracle (torch-CPU bf16 restatement of the reference path), WHOLE C1 forward: 1 image 224x224 + 32-token prompt, S=291, "
                        f"ViT-L/14 (23 layers used) + projector + 32 LLaMA-7B layers + lm_head (V={V}), random-init weights, 1 warm-up + 3 timed "
                        f"forwards, median {t_c1:.2f} s; {best_n} of {os.cpu_count()} host threads (fastest on two LLaMA layers of the oracle: {probe} ms); "
@@ -583,8 +720,13 @@ def main():
         image_size, prompt = WORKLOADS[a.workload][:2]
         res_rec = None
         roof = None
+        patch_rec = res_roof = None
         if rank == 0 and not a.no_roofline and a.workload != "train":
             roof = gemm_roofline(cfg, batch * S, dev)
+            if a.workload == "c4":
+                patch_rec = patchify_record(dev)
+                if not a.no_res:
+                    res_roof = sam_gemm_roofline(dev)
         if a.workload == "c4" and not a.no_res:
             # second half of BASELINE.json's metric: the full RES forward (C3), same timing protocol, same process
             del step, model
@@ -613,7 +755,11 @@ def main():
                 "model_tflops_per_sec_per_gpu": round(flops_img * value / world / 1e12, 1),
                 "frac_of_bf16_peak_end_to_end": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
         if res_rec is not None:
+            if res_roof is not None:
+                res_rec["roofline"] = res_roof
             line["res"] = res_rec
+        if patch_rec is not None:
+            line["patchify"] = patch_rec
         if roof is not None:
             line["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:

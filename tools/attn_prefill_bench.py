@@ -24,11 +24,20 @@ def run(name, B, H, S, hd, causal):
         f()
     e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) / 40 * 1e3
+    if os.environ.get("DUMP"):
+        torch.save(att.cpu(), os.environ["DUMP"] + "_" + name.split()[0] + f"_S{S}.pt")
+    if os.environ.get("CMP"):
+        ref = torch.load(os.environ["CMP"] + "_" + name.split()[0] + f"_S{S}.pt")
+        d = (att.cpu().float() - ref.float()).abs()
+        print(f"    vs {os.environ['CMP']}: {float((att.cpu() != ref).float().mean()) * 100:.5f} % of elements differ, max |d| {float(d.max()):.3g} "
+              f"(max |ref| {float(ref.float().abs().max()):.3g}), nan {int(torch.isnan(att.float()).sum())}")
     print(f"{name:28s}: {us:8.1f} us  {gf / us * 1e3:7.1f} TF/s (useful)  checksum {float(att.float().abs().mean()):.6f}  "
           f"sha {__import__('hashlib').sha256(att.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:12]}")
 
 
 run("llama B=32 S=643 (C4)", 32, 32, 643, 128, True)
+if os.environ.get("ONLY_C4"):
+    sys.exit(0)
 run("llama B=8 S=379 (RES)", 8, 32, 379, 128, True)
 run("llama B=16 S=323 (train)", 16, 32, 323, 128, True)
 run("clip B=32 S=577 (C4)", 32, 16, 577, 64, False)
