@@ -309,11 +309,7 @@ constexpr int attn_reg_nbuf() {
 
 //   VROW (LLaMA / CLIP prefill): the V tiles are DMA'd ROW-major from V itself ([64 keys][head dim], like the K tiles) and the V^T
 //   operand of P*V comes out of them through ds_read_b64_tr_b16: no V^T pass in front of the attention.
-//   ILV (LLaMA / CLIP prefill): a key tile that is clean for the whole wave (real keys, no key mask, below the causal diagonal) runs its four
-//   16-key score blocks as four INTERLEAVED accumulator chains -- k-step outer, block inner -- so that consecutive MFMAs never depend on
-//   each other (the per-block form issues 4 dependent MFMAs back to back: each waits out the previous one's 8 passes), with one branch
-//   per tile instead of one per block.  Same products in the same order per accumulator: bit-identical.
-template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false, bool VROW = false, bool ILV = false>
+template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false, bool VROW = false>
 __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)) ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(256))) char smem[];     // (256: the V fragment addresses below XOR bits 5..7)
     static_assert(!WIN16 || (EXACT && FL == FL_SAM_ENC && NT == 4), "WIN16 is the 14 x 14 window form of the exact kernel");
@@ -551,27 +547,7 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
             if constexpr (!EXACT) stream_step(kt);
-            bool tile_done = false;
-            if constexpr (ILV && (FL == FL_LLAMA || FL == FL_CLIP) && !WIN16) {
-                if (kt < nkt_w && p.key_mask == nullptr && kt * KT + KT <= p.Sk && (FL != FL_LLAMA || kt * KT + KT - 1 <= q0 + wave * 16 + koff)) {
-                    const char* tb = smem + (EXACT ? kt : (kt % NBUF)) * TILE;
-                    f32x4_t a4[4];
-#pragma unroll
-                    for (int ns = 0; ns < 4; ++ns) a4[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-                        for (int ns = 0; ns < 4; ++ns) {
-                            const uint4 kf = *(const uint4*)(tb + ns * 16 * KROW + kfo[ks]);
-                            a4[ns] = mfma16(kf, qf[ks], a4[ns]);
-                        }
-                    }
-#pragma unroll
-                    for (int ns = 0; ns < 4; ++ns) score_quad_clean<FL>(p, a4[ns], sp[kt][ns * 2], sp[kt][ns * 2 + 1], &mrow);
-                    tile_done = true;
-                }
-            }
-            if (kt < nkt_w && !tile_done) {
+            if (kt < nkt_w) {
                 const char* tb = smem + (EXACT ? kt : (kt % NBUF)) * TILE;
 #pragma unroll
                 for (int ns = 0; ns < 4; ++ns) {
@@ -770,239 +746,6 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
                 pk.y = pack2e(oacc[ds][2], oacc[ds][3]);
                 *(uint2*)(op + ds * 16 + fg * 4) = pk;
             }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Two-pass prefill attention with recomputed scores (LLaMA / CLIP flavors, V as rows of the q|k|v buffer), round 4.
-//
-// attn_reg_kernel keeps a wave's whole score row in registers (88 VGPRs of packed scores at S = 643): 160 registers = 3 waves per SIMD,
-// which caps a block at 64 queries (4 waves, 3 blocks per CU) -- and every 64-query block streams ALL its K and V tiles through the CU's
-// L1 again: 2.2 GB of L2 -> LDS traffic per LLaMA layer at the C4 shape, ~100 us at the ~85 GB/s a CU sustains, on top of the
-// arithmetic it does not overlap with (profiles/r03_attention_pmc.txt: 39 % of wave cycles parked, MFMA pipe 20 % busy).
-// Here nothing per-key stays in registers, so a block is NWV = 8 waves = 128 queries at <= 128 registers (2 blocks = 16 waves per CU):
-//   pass 1  per key tile: S = K Q^T on the MFMA, the reference's rounding chain (score_quad*), and an ONLINE (max, sum) per lane --
-//           m' = max(m, tile max); l = l * 2^((m - m') c) + sum 2^((s - m') c) -- combined over the 4 lanes of a query at the end;
-//   pass 2  per key tile: S again (same bits), P = bf16(2^((s - m) c) / l) -- the same expression attn_reg_kernel evaluates -- then
-//           O^T += V^T P^T with the V^T operand from the row-major V tile through ds_read_b64_tr_b16.
-// 1.5x the MFMA work (the pipe was 80 % idle) for 0.75x the L2 -> LDS bytes at twice the block size, 4 waves per SIMD instead of 3, a
-// 4-tile DMA ring that runs three tiles ahead in pass 1 and one K|V pair ahead in pass 2 (one barrier per pair), and no limit on Sk.
-// Numerics: every score, the row maximum and every numerator are the SAME bits as in attn_reg_kernel; the row SUM is accumulated in a
-// different fp32 order (per-tile rescaling) -- an fp32-ulp-level difference in 1 / l, the kind torch's own CPU and GPU softmax kernels
-// differ by -- so P = bf16(e / l) can differ from attn_reg_kernel's in a rounding-boundary case (measured: tools/attn_prefill_bench.py).
-template <int HDP, int FL, int NWV, int NBUF>
-__global__ __launch_bounds__(NWV * 64, 4) void attn_2p_kernel(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(256))) char smem[];
-    static_assert(FL == FL_LLAMA || FL == FL_CLIP, "flavors that pin hd = HDP and carry no bias tables");
-    static_assert((HDP / 8) % NWV == 0 && NBUF >= 4, "every wave issues the same number of DMA pieces per tile; the ring holds a K|V pair ahead");
-    constexpr int PM = HDP / 16 >= 8 ? 7 : HDP / 16 - 1;
-    constexpr int BQ = 16 * NWV, CPR = HDP / 8, KROW = HDP * 2, NKS = HDP / 32, NDS = HDP / 16, TILE = 64 * KROW, PPW = CPR / NWV;
-    constexpr float LOG2E = 1.4426950408889634f;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fg = lane >> 4;
-
-    const int nq = (p.Sq + BQ - 1) / BQ;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int head = (slot / nq) * 8 + xcd;          // all query tiles of a head on ONE XCD (K / V stay in that L2)
-    if (head >= p.B * p.H) return;
-    const int qt = nq - 1 - slot % nq;               // longest first
-    const int b = head / p.H, h = head % p.H;
-    const int q0 = qt * BQ;
-    const int koff = p.Sk - p.Sq;
-    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    char* maskb = smem + NBUF * TILE;                // one byte per key: 1 attend, 0 masked (finfo.min), 2 out of range (-inf)
-
-    int kend = p.Sk;
-    if (FL == FL_LLAMA && p.causal) kend = min(p.Sk, q0 + BQ + koff);
-    if (kend < 1) kend = 1;
-    const int nkt = (kend + KT - 1) / KT;            // key tiles this block streams (per pass)
-    int kend_w = p.Sk;
-    if (FL == FL_LLAMA && p.causal) kend_w = min(p.Sk, q0 + wave * 16 + 16 + koff);
-    const int nkt_w = (q0 + wave * 16 < p.Sq) ? max(1, (kend_w + KT - 1) / KT) : 0;     // tiles this wave computes on
-    const int total = 3 * nkt;                       // stream: K tiles 0..nkt-1 (pass 1), then K0 V0 K1 V1 ... (pass 2)
-
-    const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
-    const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
-    uint32_t kvo[2 * PPW];                           // per-lane byte offsets of this wave's pieces inside a K / V tile (same for every tile)
-#pragma unroll
-    for (int i0 = 0; i0 < PPW; ++i0) {
-        const int i = i0 * NWV + wave;
-        const int row = i * (64 / CPR) + lane / CPR;
-        const int ck = (lane % CPR) ^ swz<CPR>(row);
-        const int cpos = lane % CPR;
-        const int cv = ((((cpos >> 1) ^ (row & PM)) << 1) | (cpos & 1));
-        kvo[i0] = (uint32_t)(((long)row * p.k_ss + ck * 8) * 2);
-        kvo[PPW + i0] = (uint32_t)(((long)row * p.vt_ds + cv * 8) * 2);
-    }
-    const bool fast_dma_ok = 64 * p.k_ss * 2 < (1L << 31) && 64 * p.vt_ds * 2 < (1L << 31);
-    auto issue = [&](int u) {
-        const uint32_t dst = lds_base + (u % NBUF) * TILE;
-        const bool is_k = u < nkt || ((u - nkt) & 1) == 0;
-        const int kt = u < nkt ? u : (u - nkt) >> 1;
-        if (fast_dma_ok && kt * KT + KT <= p.Sk) {                   // every row of the tile is a real key: no clamp
-            const elem_t* tb = is_k ? kbase + (long)kt * KT * p.k_ss : vbase + (long)kt * KT * p.vt_ds;
-#pragma unroll
-            for (int i0 = 0; i0 < PPW; ++i0) glds16s(tb, is_k ? kvo[i0] : kvo[PPW + i0], dst + (i0 * NWV + wave) * 1024);
-            return;
-        }
-#pragma unroll
-        for (int i0 = 0; i0 < PPW; ++i0) {
-            const int i = i0 * NWV + wave;
-            const int row = i * (64 / CPR) + lane / CPR;
-            const int key = min(kt * KT + row, p.Sk - 1);            // rows past the last key: masked (-inf) in S, P exactly 0 for V
-            const int cpos = lane % CPR;
-            if (is_k) glds16(kbase + (long)key * p.k_ss + ((cpos ^ swz<CPR>(row)) * 8), dst + i * 1024);
-            else glds16(vbase + (long)key * p.vt_ds + (((((cpos >> 1) ^ (row & PM)) << 1) | (cpos & 1)) * 8), dst + i * 1024);
-        }
-    };
-    int issued = 0;                                  // tiles requested so far (wave-uniform; every wave issues PPW pieces per tile)
-    for (; issued < NBUF && issued < total; ++issued) issue(issued);
-
-    // ---- Q fragments + key-mask bytes (ordinary loads, drained together with the first DMA'd tiles) -------
-    uint4 qf[NKS];
-    const int qi = q0 + wave * 16 + fr;
-    {
-        const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = qi < p.Sq ? *(const uint4*)(qp + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
-        for (int j = tid; j < nkt * KT; j += NWV * 64) {
-            unsigned char m = 2;
-            if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
-            maskb[j] = m;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // (see attn_reg_kernel: redefining the fragments behind the explicit wait ends the compiler's own bookkeeping of those loads, which
-    // would otherwise put an s_waitcnt vmcnt(0) -- draining the DMA ring -- in front of their first use in every tile)
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
-    uint32_t kfo[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        kfo[ks] = fr * KROW + (((ks * 4 + fg) ^ swz<CPR>(fr)) << 4);
-        asm volatile("" : "+v"(kfo[ks]));
-    }
-    uint32_t vfo = (4 * fg + (fr >> 2)) * KROW + ((fr & 2) << 3) + ((fr & 1) << 3) + (((4 * (fg & 1) + (fr >> 2)) & PM) << 5);
-    asm volatile("" : "+v"(vfo));
-
-    // before tiles [c, c + n) are consumed: they have landed (only later tiles stay in flight), every wave has left the previous step (its
-    // buffers are free), and the ring is topped up to NBUF tiles from c
-    auto stream_step = [&](int c, int n) {
-        const int later = issued - c - n;            // 0 .. NBUF - 1 tiles may stay in flight
-        if (later <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
-        else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * PPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-        for (; issued < c + NBUF && issued < total; ++issued) issue(issued);
-    };
-    // S for key tile kt (K tile in buffer `buf`) -> 8 packed pairs (keys kt*64 + ns*16 + 4*fg + {0,1 | 2,3}) + the maximum of the 16 scores
-    auto scores = [&](int kt, int buf, uint32_t (&sp)[8], float& tmax) {
-        const char* tb = smem + buf * TILE;
-        const bool clean = p.key_mask == nullptr && kt * KT + KT <= p.Sk && (FL != FL_LLAMA || !p.causal || kt * KT + KT - 1 <= q0 + wave * 16 + koff);
-        f32x4_t a4[4];
-#pragma unroll
-        for (int ns = 0; ns < 4; ++ns) a4[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {           // four independent accumulator chains: consecutive MFMAs never wait for each other
-#pragma unroll
-            for (int ns = 0; ns < 4; ++ns) {
-                const uint4 kf = *(const uint4*)(tb + ns * 16 * KROW + kfo[ks]);
-                a4[ns] = mfma16(kf, qf[ks], a4[ns]);
-            }
-        }
-        if (clean) {
-#pragma unroll
-            for (int ns = 0; ns < 4; ++ns) score_quad_clean<FL>(p, a4[ns], sp[ns * 2], sp[ns * 2 + 1], &tmax);
-        } else {
-#pragma unroll
-            for (int ns = 0; ns < 4; ++ns) {
-                const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
-                score_quad<FL>(p, a4[ns], kt * KT + ns * 16 + fg * 4, mk, qi, koff, nullptr, 0, 0, sp[ns * 2], sp[ns * 2 + 1], &tmax);
-            }
-        }
-    };
-
-    // ---- pass 1: online (max, sum) of the rounded scores --------------------------------------------------------------------------
-    float m_run = -INFINITY, l_run = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
-        stream_step(kt, 1);
-        if (kt < nkt_w) {
-            uint32_t sp[8];
-            float tmax = -INFINITY;
-            scores(kt, kt % NBUF, sp, tmax);
-            const float m_new = fmaxf(m_run, rnd(tmax));            // (the clean path feeds unrounded products: rounding is monotone)
-            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-            float acc = l_run * __builtin_amdgcn_exp2f((m_run - m_safe) * LOG2E);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x2_t t = (f32x2_t{pk_lo(sp[i]), pk_hi(sp[i])} - m_safe) * LOG2E;
-                acc += __builtin_amdgcn_exp2f(t.x);
-                acc += __builtin_amdgcn_exp2f(t.y);
-            }
-            l_run = acc;
-            m_run = m_new;
-        }
-    }
-    float m = fmaxf(m_run, __shfl_xor(m_run, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    {
-        const float m_safe = m == -INFINITY ? 0.f : m;
-        l_run *= __builtin_amdgcn_exp2f((m_run - m_safe) * LOG2E);
-        m = m_safe;
-    }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_run;
-
-    // ---- pass 2: S again, P = bf16(exp(S - m) / l), O^T += V^T P^T ------------------------------------------------------------------
-    f32x4_t oacc[NDS];
-#pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int u = nkt + 2 * kt;
-        stream_step(u, 2);
-        if (kt < nkt_w) {
-            uint32_t sp[8];
-            float unused = -INFINITY;
-            scores(kt, u % NBUF, sp, unused);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x2_t t = (f32x2_t{pk_lo(sp[i]), pk_hi(sp[i])} - m) * LOG2E;
-                const f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * inv;
-                sp[i] = pack2e(e.x, e.y);
-            }
-            const uint32_t vb = lds_base + ((u + 1) % NBUF) * TILE + vfo;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const uint4 pf = make_uint4(sp[4 * kk], sp[4 * kk + 1], sp[4 * kk + 2], sp[4 * kk + 3]);
-#pragma unroll
-                for (int d0 = 0; d0 < NDS; d0 += 4) {
-                    u32x2_t va[4], vc[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t ad = vb ^ ((d0 + j) << 5);
-                        if (kk == 0) { va[j] = lds_tr_b64<0>(ad); vc[j] = lds_tr_b64<16 * KROW>(ad); }
-                        else { va[j] = lds_tr_b64<32 * KROW>(ad); vc[j] = lds_tr_b64<48 * KROW>(ad); }
-                    }
-                    lds_tr_wait<4>(va, vc);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        oacc[d0 + j] = mfma16(make_uint4(va[j].x, va[j].y, vc[j].x, vc[j].y), pf, oacc[d0 + j]);
-                }
-            }
-        }
-    }
-    if (qi < p.Sq) {
-        elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
-#pragma unroll
-        for (int ds = 0; ds < NDS; ++ds) {
-            uint2 pk;
-            pk.x = pack2e(oacc[ds][0], oacc[ds][1]);
-            pk.y = pack2e(oacc[ds][2], oacc[ds][3]);
-            *(uint2*)(op + ds * 16 + fg * 4) = pk;
         }
     }
 }
@@ -1809,7 +1552,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restri
     }
 }
 
-template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false, bool WIN16 = false, bool VROW = false, bool ILV = false>
+template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false, bool WIN16 = false, bool VROW = false>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
     const int lds = attn_reg_nbuf<HDP, NT, NWV, EXACT, VROW>() * TILE + NT * KT +
@@ -1817,25 +1560,11 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     if (lds > 160 * 1024) return ULL_ERR_LDS;
     static UllOncePerDevice once;
     if (lds > 64 * 1024 && once.first())
-        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16, VROW, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16, VROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16, VROW, ILV>), grid, dim3(NWV * 64), lds, st, a);
-    return ull_check_launch();
-}
-
-template <int HDP, int FL, int NWV = 8, int NBUF = 4>
-int launch_2p(const AttnArgs& a, hipStream_t st) {
-    constexpr int TILE = 64 * HDP * 2;
-    const int nt = (a.Sk + KT - 1) / KT;
-    const int lds = NBUF * TILE + nt * KT;
-    if (lds > 160 * 1024) return ULL_ERR_LDS;
-    static UllOncePerDevice once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)attn_2p_kernel<HDP, FL, NWV, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
-    const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_2p_kernel<HDP, FL, NWV, NBUF>), grid, dim3(NWV * 64), lds, st, a);
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16, VROW>), grid, dim3(NWV * 64), lds, st, a);
     return ull_check_launch();
 }
 
@@ -1903,16 +1632,7 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
     if (a.v_rows) {                      // V handed over row-major: the kernels that transpose on the fly (see the C entry)
         if constexpr (HDP == 128) {
-            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) {
-                static const int variant = getenv("ULL_ATTN_VARIANT") ? atoi(getenv("ULL_ATTN_VARIANT")) : 0;      // kernel A/B experiments only
-                if (variant == 1) return launch_attn<128, 11, FL_LLAMA, 8, false, false, true>(a, st);
-                if (variant == 2) return launch_attn<128, 11, FL_LLAMA, 4, false, false, true, true>(a, st);
-                if (variant == 3) return launch_attn<128, 11, FL_LLAMA, 8, false, false, true, true>(a, st);
-                if (variant == 4) return launch_2p<128, FL_LLAMA, 8, 4>(a, st);
-                if (variant == 5) return launch_2p<128, FL_LLAMA, 8, 6>(a, st);
-                if (variant == 6) return launch_2p<128, FL_LLAMA, 16, 6>(a, st);
-                return launch_attn<128, 11, FL_LLAMA, 4, false, false, true>(a, st);
-            }
+            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4, false, false, true>(a, st);
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, false, true>(a, st);
             if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16)
                 return launch_stream<128, FL_SAM_ENC, 2, true>(a, st);

@@ -266,6 +266,7 @@ class UllavaCoreForCausalLM(nn.Module):
         self._packed = None
         _clear_transposes()          # cached W^T copies of the training path describe the old weights
         self._inv_freq = None
+        self._pos_cache = None
         self._reset_alias_slots()    # every parameter is a fresh tensor: the training path may alias them anew
         return out
 
@@ -721,6 +722,12 @@ class UllavaCoreForCausalLM(nn.Module):
             self._inv_freq = inv.to(device)
         return self._inv_freq
 
+    def _pos_arange(self, device, n: int) -> torch.Tensor:
+        ar = getattr(self, "_pos_cache", None)
+        if ar is None or ar.device != device or ar.numel() < n:
+            ar = self._pos_cache = torch.arange(max(4096, 2 * n), device=device, dtype=torch.int64)
+        return ar
+
     def _llama(self, inputs_embeds, attention_mask, position_ids, output_hidden_states, cache: Optional[KVCache] = None):
         """LlamaModel.forward.  cache=None: plain prefill.  cache empty: prefill that also fills the cache.  cache filled:
         incremental step(s) -- the new tokens' q attend to cached K / V^T plus their own."""
@@ -732,7 +739,10 @@ class UllavaCoreForCausalLM(nn.Module):
         dev = inputs_embeds.device
         past = cache.length if cache is not None else 0
         if position_ids is None:
-            pos = (torch.arange(S, device=dev, dtype=torch.int64) + past).repeat(B)
+            # positions past .. past + S - 1 of every row: a slice of one arange kept per device (a decode step at batch 1 then costs no
+            # torch kernel for its positions -- it was an arange and an add per step; larger batches pay one repeat)
+            ar = self._pos_arange(dev, past + S)
+            pos = ar[past:past + S] if B == 1 else ar[past:past + S].repeat(B)
         else:
             pos = position_ids.to(torch.int64).expand(B, S).reshape(-1).contiguous()
         key_mask = None if attention_mask is None else attention_mask.to(torch.int32).contiguous()
