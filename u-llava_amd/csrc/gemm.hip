@@ -556,6 +556,7 @@ struct PatchArgs {
     const elem_t* img; const elem_t* zeros; const elem_t* img_end;
     int C, H, W, ps, gw, gh;          // image geometry; gw x gh patches per image
     int nseg;                         // C * ps real (c, ky) segments; segments >= nseg read zeros
+    int xcd_raster;                   // patchify_strip_kernel: all N-tiles of a strip on one XCD (needs nbm % 8 == 0)
 };
 
 template <int DUMMY>
@@ -1389,7 +1390,15 @@ __global__ __launch_bounds__(512) void patchify_strip_kernel(GemmArgs p, PatchAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wm = wave >> 2;
     const int fr = lane & 15, fg = lane >> 4;
-    const int bn = blockIdx.x % p.nbn, bm = blockIdx.x / p.nbn;     // the 4 N-tiles of a strip on neighbouring CUs: they share its pixels in L2
+    // The nbn N-tiles of a strip read the SAME pixels: they belong on one XCD (one L2), not on nbn neighbouring block ids -- which the
+    // hardware deals round-robin over the 8 XCDs, so that every strip was fetched from the fabric nbn times (PMC, round 4: 88 MB of
+    // fabric reads for 21.7 MB of pixels, L2 hit rate 51 %).  Block id -> (XCD, slot); an XCD owns nbm / 8 consecutive strips.
+    int bn = blockIdx.x % p.nbn, bm = blockIdx.x / p.nbn;
+    if (q.xcd_raster) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;     // slot 0 .. nbm * nbn / 8
+        bm = xcd * (p.nbm >> 3) + slot / p.nbn;
+        bn = slot % p.nbn;
+    }
     const int m0 = bm * TM, n0 = bn * TN;
     const int srow = lane >> 3;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
@@ -1968,6 +1977,7 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
     q.img = (const elem_t*)img; q.zeros = (const elem_t*)zeros;
     q.img_end = (const elem_t*)img + n_img * C * H * W;
     q.C = (int)C; q.H = (int)H; q.W = (int)W; q.ps = (int)ps; q.gw = (int)(W / ps); q.gh = (int)(H / ps); q.nseg = (int)(C * ps);
+    q.xcd_raster = 0;
     const int64_t M = n_img * q.gw * q.gh;
     if (M > (1 << 30)) return ULL_ERR_SHAPE;
     a.X = nullptr; a.W = (const elem_t*)Wp; a.C = out; a.bias = (const elem_t*)bias; a.R = nullptr;
@@ -1987,6 +1997,8 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
             const long tiles = (M / tm) * nbn;
             if (tiles > n_cu || tiles * 2 <= n_cu) continue;
             a.nbm = (int)(M / tm); a.nbn = nbn;
+            static const int raster_env = getenv("ULL_PATCHIFY_XCD") ? atoi(getenv("ULL_PATCHIFY_XCD")) : 1;       // tools: 0 = the old raster
+            q.xcd_raster = raster_env && (a.nbm % 8 == 0);
             const int lds = 2 * (tm + 256) * 128;
             if (wmb == 9) hipLaunchKernelGGL(big::patchify_strip_kernel<9>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a, q);
             else hipLaunchKernelGGL(big::patchify_strip_kernel<4>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a, q);
