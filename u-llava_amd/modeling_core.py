@@ -181,6 +181,35 @@ class KVCache:
     def __len__(self):
         return len(self.k)
 
+    @classmethod
+    def from_hf(cls, past, headroom: int = 512):
+        """A caller-supplied HF `past_key_values` -> KVCache (reference models/ullava_core.py:279-292 takes `past_key_values:
+        Optional[List[torch.FloatTensor]]`): the legacy tuple of per-layer (key, value) pairs, each [B, H, S, hd] with post-RoPE keys, or a
+        transformers Cache object exposing `key_cache` / `value_cache` lists (or `.layers[i].keys / .values`).  Keys are copied into the
+        K buffers, values go through `ull_transpose_v` into the permuted V^T layout; `last_hidden` starts empty (hidden states of the
+        cached positions are not part of an HF cache)."""
+        if hasattr(past, "key_cache") and hasattr(past, "value_cache"):
+            pairs = list(zip(past.key_cache, past.value_cache))
+        elif hasattr(past, "layers"):
+            pairs = [(l.keys, l.values) for l in past.layers]
+        else:
+            pairs = [(kv[0], kv[1]) for kv in past]
+        if not pairs:
+            raise ValueError("empty past_key_values")
+        k0 = pairs[0][0]
+        if k0.dim() != 4:
+            raise ValueError("past_key_values entries must be [batch, heads, seq, head_dim] tensors")
+        B, H, S, hd = k0.shape
+        c = cls(len(pairs), B, H, hd, S + headroom, k0.device, k0.dtype)
+        for li, (k, v) in enumerate(pairs):
+            if k.shape != (B, H, S, hd) or v.shape != (B, H, S, hd):
+                raise ValueError("past_key_values layers disagree in shape")
+            c.k[li][:, :, :S].copy_(k)
+            vr = v.permute(0, 2, 1, 3).contiguous()                              # [B, S, H, hd]: heads contiguous per token (data movement)
+            ops.transpose_v(vr, S * H * hd, H * hd, B, S, H, hd, pitch=c.smax, out=c.vt[li])
+        c.length = S
+        return c
+
     @staticmethod
     def vt_slot(pos: int) -> int:
         """column of key `pos` inside V^T (32-key blocks stored as slot 8g+4a+r <- key 16a+4g+r, see transpose_v)."""
@@ -212,6 +241,27 @@ def no_repeat_ngram_banned_tokens(rows, ngram_size: int):
                 banned.append(toks[i + ngram_size - 1])
         out.append(banned)
     return out
+
+
+def sampling_probs(logits: torch.Tensor, temperature: float, top_k: Optional[int] = 50, top_p: Optional[float] = None) -> torch.Tensor:
+    """The distribution HF `GenerationMixin._sample` draws from, in its own arithmetic and order (transformers generation/logits_process.py:
+    TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper on fp32 scores, then softmax): the reference's callers pass `temperature`
+    (and optionally `top_p`) and inherit `top_k = 50` from GenerationConfig's defaults (models/ullava.py:350-361, inference_ullava_core.py:73-80).
+    One `torch.multinomial(probs, 1)` per step on these probabilities consumes the RNG exactly as HF does, so a seeded run draws HF's tokens
+    from the same logits.  Integer / fp32 bookkeeping on [B, V] scores (the logits themselves come from the HIP lm_head)."""
+    scores = logits.float()
+    if temperature is not None and temperature != 1.0:
+        scores = scores / temperature
+    if top_k is not None and top_k > 0:
+        k = min(int(top_k), scores.size(-1))
+        scores = scores.masked_fill(scores < torch.topk(scores, k)[0][..., -1, None], float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(scores, descending=False)
+        cumulative = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cumulative <= (1 - top_p)
+        remove[..., -1:] = 0                                     # min_tokens_to_keep = 1
+        scores = scores.masked_fill(remove.scatter(1, sorted_indices, remove), float("-inf"))
+    return torch.softmax(scores, dim=-1)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -824,7 +874,8 @@ class UllavaCoreForCausalLM(nn.Module):
         cache = None
         if past_key_values is not None or use_cache:
             if past_key_values is not None and not isinstance(past_key_values, KVCache):
-                raise NotImplementedError("past_key_values must be the KVCache returned by a previous forward(use_cache=True)")
+                # an HF-style cache handed in by the caller (legacy tuple of (key, value) per layer, or a transformers Cache object)
+                past_key_values = KVCache.from_hf(past_key_values, headroom=getattr(self, "_cache_headroom", 512))
             cache = past_key_values
         output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
@@ -871,7 +922,7 @@ class UllavaCoreForCausalLM(nn.Module):
 
     @torch.no_grad()
     def generate(self, input_ids=None, images=None, videos=None, attention_mask=None, max_new_tokens=32, do_sample=False,
-                 temperature=1.0, top_p=None, num_beams=1, no_repeat_ngram_size=None, stopping_criteria=None, eos_token_id=None,
+                 temperature=1.0, top_p=None, top_k=50, num_beams=1, no_repeat_ngram_size=None, stopping_criteria=None, eos_token_id=None,
                  pad_token_id=None, output_hidden_states=False, return_dict_in_generate=False, use_cache=None,
                  keep_last_step_only=False, **kwargs):
         """Token-by-token decoding with HF GenerationMixin's greedy / sampling semantics (the reference inherits `generate`):
@@ -889,7 +940,7 @@ class UllavaCoreForCausalLM(nn.Module):
             # HF generate() validates its model kwargs and raises on unknown ones; options this loop does not implement must not be
             # swallowed (a silently ignored `repetition_penalty` changes the ids)
             raise TypeError(f"generate() got unsupported keyword arguments {sorted(kwargs)} (supported: greedy / sampling with temperature, "
-                            "top_p, no_repeat_ngram_size, stopping_criteria, eos_token_id, pad_token_id, max_new_tokens)")
+                            "top_k, top_p, no_repeat_ngram_size, stopping_criteria, eos_token_id, pad_token_id, max_new_tokens)")
         ngram = int(no_repeat_ngram_size) if no_repeat_ngram_size else 0
         if ngram < 0:
             raise ValueError(f"`no_repeat_ngram_size` has to be a positive integer, but is {no_repeat_ngram_size}")
@@ -970,14 +1021,7 @@ class UllavaCoreForCausalLM(nn.Module):
                     if banned:
                         logits[b_, torch.as_tensor(banned, device=logits.device)] = float("-inf")
             if sampling:
-                probs = torch.softmax(logits / temperature, dim=-1)
-                if top_p is not None and top_p < 1.0:
-                    sp, si = probs.sort(dim=-1, descending=True)
-                    keep = (sp.cumsum(-1) - sp) < top_p
-                    sp = sp * keep
-                    probs = torch.zeros_like(probs).scatter_(-1, si, sp)
-                    probs = probs / probs.sum(-1, keepdim=True)
-                nxt = torch.multinomial(probs, 1)
+                nxt = torch.multinomial(sampling_probs(logits, temperature, top_k, top_p), 1)
             else:
                 nxt = logits.argmax(-1, keepdim=True)
             if pad is not None:
