@@ -304,13 +304,13 @@ def c1_case(seed=5, prompt_tokens=32, V=32011):
     return cfg, ids, mask, img
 
 
-def c1_hip_model(sd, device, n_llama=32):
-    """The MI355X model holding the very weights of `sd` (the oracle's state dict, host bf16): same values on both sides of a parity check."""
+def c1_hip_model(sd, device, n_llama=32, dtype=torch.bfloat16):
+    """The MI355X model holding the very weights of `sd` (the oracle's state dict, host 16-bit): same values on both sides of a parity check."""
     C = importlib.import_module("u-llava_amd.configuration")
     M = importlib.import_module("u-llava_amd.modeling_core")
     cfg = C.UllavaCoreConfig(vision_config=dict(image_size=224, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
                              projector_from_scratch=False, mm_token_ids=dict(MM), vocab_size=sd["lm_head.weight"].shape[0], num_hidden_layers=n_llama)
-    model = M.UllavaCoreForCausalLM(cfg, device=device)
+    model = M.UllavaCoreForCausalLM(cfg, device=device, dtype=dtype)
     model.load_state_dict(sd, strict=True)
     model.strict_checks = False
     return model
@@ -345,7 +345,7 @@ def parity_stats(hip_logits, oracle_logits, truth_logits, k=4.0):
                 hip_rms_vs_fp32=round(float((h - t).pow(2).mean().sqrt()), 5), oracle_rms_vs_fp32=round(float((o - t).pow(2).mean().sqrt()), 5),
                 argmax_agree=round(float((ah == ao).float().mean()), 4), argmax_agree_hip_fp32=round(float((ah == at).float().mean()), 4),
                 argmax_agree_oracle_fp32=round(float((ao == at).float().mean()), 4),
-                gate=f"fp32 top-1/top-2 gap > {k:g} x sqrt(2) x rms_v(oracle_bf16 - fp32) at that position", positions_gated=int(gated.sum()),
+                gate=f"fp32 top-1/top-2 gap > {k:g} x sqrt(2) x rms_v(oracle_16bit - fp32) at that position", positions_gated=int(gated.sum()),
                 gated_exact=bool(exact[gated].all()), gated_mismatches=int((~exact[gated]).sum()),
                 median_gap=round(float(gap.median()), 4), median_diff_sigma=round(float(sigma.median()), 5),
                 max_abs_noise=round(float((o - t).abs().max()), 5))
