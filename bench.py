@@ -325,6 +325,12 @@ class F32View(dict):
     def get(self, k, default=None):
         return dict.__getitem__(self, k).float() if k in self else default
 
+    def items(self):                                    # (oracle helpers that re-key a sub-tree iterate: they get fp32 copies too)
+        return ((k, dict.__getitem__(self, k).float()) for k in self.keys())
+
+    def values(self):
+        return (dict.__getitem__(self, k).float() for k in self.keys())
+
 
 def parity_stats(hip_logits, oracle_logits, truth_logits, k=4.0):
     """HIP logits vs the oracle's bf16 logits vs the oracle's fp32 logits on the same inputs and weights ([S, V] each).  `gated_exact`: at every

@@ -221,6 +221,63 @@ def test_c1_greedy_ids_match_oracle_where_gated(dt):
     assert torch.equal(got_kv.cpu(), want), "generate() with the KV cache: token ids differ from the oracle's greedy loop"
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, pytest.param(torch.float16, marks=pytest.mark.skipif(
+    os.environ.get("ULL_SLOW_TESTS") != "1", reason="the CPU oracle's fp16 SAM ViT-H + LLaMA-7B forward takes ~5 min (measured record: "
+                                                    "profiles/r04_parity_res_full_depth.json); ULL_SLOW_TESTS=1 runs it"))])
+def test_res_full_depth_against_oracle(dt):
+    """BASELINE.json configs[2] at FULL depth and batch 1 (bf16, and fp16 = the reference's evaluation dtype): ViT-L/14-224 + 32 LLaMA-7B layers + SAM ViT-H (32 blocks, d = 1280, 1024 x 1024) +
+    prompt encoder + two-way MaskDecoder + postprocess, three [SEG] / [LOC] rounds, the very weights on both sides (random init made on the
+    GPU, copied to the host for the oracle): `UllavaForCausalLM.forward(inference=True)` vs `O.ullava_forward` in bf16 vs the oracle in fp32.
+    SAM image embedding, LLaMA logits, mask logits (fp32 [3, 480, 640]) and boxes must be as close to the fp32 truth as the oracle's own
+    bf16 run is (x3, with a floor of a few bf16 ulps) -- the C3 path against the oracle at the size bench.py times it, not only through
+    properties."""
+    import bench
+    from oracle import ullava_oracle as O
+    with torch.no_grad():
+        model, cfg = bench.build_model(224, DEV, seed=3, with_sam=True)
+        if dt != torch.bfloat16:
+            model = model.to(dt)                                  # .half(): the packed copies are re-made from the cast parameters
+            model.llm.strict_checks = False
+        vis, ids, mask = bench.make_inputs(cfg, 1, 120, DEV, 3)
+        vis = vis.to(dt)
+        S = ids.shape[1]
+        for r in range(3):
+            ids[:, S - 10 - 40 * r] = bench.SEG
+            ids[:, S - 5 - 40 * r] = bench.LOC
+        g = torch.Generator(device="cuda").manual_seed(2003)
+        images_sam = torch.randn(1, 3, 1024, 1024, device=DEV, generator=g).to(dt)
+        sizes, resizes = [(480, 640)], [(768, 1024)]
+        out = model.forward(images_sam=images_sam, images=vis, input_ids=ids, labels=None, attention_mask=mask, mask_list=[None], size_list=sizes,
+                            resize_list=resizes, bbox_list=[None], inference=True)
+        emb = model.get_visual_embs(images_sam)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    llm_cfg = bench.c1_case()[0]
+    ocfg = dict(llm=llm_cfg, seg_token_idx=bench.SEG, loc_token_idx=bench.LOC,
+                sam=dict(embed_dim=1280, depth=32, num_heads=16, global_attn_indexes=[7, 15, 23, 31], window_size=14, patch_size=16, img_size=1024,
+                         out_chans=256))
+    torch.set_num_threads(min(os.cpu_count(), 64))
+    a = (images_sam.cpu(), vis.cpu(), ids.cpu(), mask.cpu(), sizes, resizes)
+    with torch.no_grad():
+        ref = O.ullava_forward(sd, ocfg, *a)
+        truth = O.ullava_forward(bench.F32View(sd), ocfg, a[0].float(), a[1].float(), *a[2:])
+    rec = {}
+    for name, hip, r_, t_ in (("sam_image_embedding", emb, ref["image_embeddings"], truth["image_embeddings"]),
+                              ("logits", out["logits"], ref["logits"], truth["logits"]),
+                              ("pred_masks", out["pred_masks"][0], ref["pred_masks"][0], truth["pred_masks"][0]),
+                              ("pred_boxes", out["pred_boxes"][0], ref["pred_boxes"][0], truth["pred_boxes"][0])):
+        e_ref, e_hip = _rel(r_, t_), _rel(hip, t_)
+        rec[name] = dict(oracle_bf16_err=round(e_ref, 5), hip_err=round(e_hip, 5), hip_vs_oracle=round(_rel(hip, r_), 5), shape=list(t_.shape))
+    print(f"RES full depth vs oracle ({dt}):", json.dumps(rec))
+    assert tuple(out["pred_masks"][0].shape) == (3, 480, 640) and out["pred_masks"][0].dtype == torch.float32
+    for name, floor in (("sam_image_embedding", 2.0 ** -5), ("logits", 2.0 ** -6), ("pred_masks", 2.0 ** -5), ("pred_boxes", 2.0 ** -5)):
+        assert rec[name]["hip_err"] <= max(3.0 * rec[name]["oracle_bf16_err"], floor), (name, rec[name])
+    # mask SIGNS (the segmentation itself): where the fp32 logit is at least 4 x the oracle's bf16 error away from zero, all three agree
+    hm, rm, tm = out["pred_masks"][0].cpu(), ref["pred_masks"][0].float(), truth["pred_masks"][0]
+    clear = tm.abs() > 4.0 * float((rm - tm).abs().max())
+    assert bool(((hm > 0) == (tm > 0))[clear].all()) and bool(((rm > 0) == (tm > 0))[clear].all())
+    print(f"mask pixels decided with margin: {float(clear.float().mean()) * 100:.1f} %, sign agreement there: exact")
+
+
 RCCL_SCRIPT = r"""
 import importlib, os, sys, json
 sys.path.insert(0, os.environ["ULL_ROOT"])
