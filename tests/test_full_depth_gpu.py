@@ -78,6 +78,56 @@ def test_c4_bench_workload_full_depth():
     assert agree >= 0.99
 
 
+@pytest.mark.parametrize("case", ["c4_336", "c5_video"])
+def test_c4_c5_shapes_full_depth_against_oracle(case):
+    """The other two core-path configs of BASELINE.json at full depth and batch 1 against the oracle (bf16 + fp32 truth), same rule as
+    test_c1_full_depth_against_oracle: C4's shape (336 x 336 image -> 576 visual tokens, 64-token prompt, S = 643; a 577-row position table) and
+    C5's (an 8-frame 224 x 224 clip -> per-frame ViT-L, 8 + 256 pooled tokens, S = 299)."""
+    import bench
+    from oracle import ullava_oracle as O
+    sd, model = _c1_fixture()
+    llm_cfg = bench.c1_case()[0]
+    g = torch.Generator().manual_seed(17)
+    if case == "c4_336":
+        sd = dict(sd)
+        sd["vision_encoder.embeddings.position_embedding.weight"] = (torch.randn(577, 1024, generator=g) * 0.02).to(torch.bfloat16)
+        llm_cfg = dict(llm_cfg, vision_config=dict(llm_cfg["vision_config"], image_size=336))
+        C = pkg("configuration")
+        M = pkg("modeling_core")
+        with torch.no_grad():
+            model = M.UllavaCoreForCausalLM(C.UllavaCoreConfig(vision_config=dict(image_size=336, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
+                                                               mm_token_ids=dict(bench.MM), vocab_size=32011), device=DEV)
+            model.load_state_dict(sd, strict=True)
+        model.strict_checks = False
+        vis = torch.randn(1, 3, 336, 336, generator=g).to(torch.bfloat16)
+        head = [1, bench.MM["IMG_START"]] + [bench.MM["IMG_PATCH"]] * 576 + [bench.MM["IMG_END"]]
+        ids = torch.tensor([head + torch.randint(5, 32000, (64,), generator=g).tolist()])
+        kw_h, kw_o = dict(images=vis.to(DEV)), dict(images=vis)
+        kw_t = dict(images=vis.float())
+    else:
+        vis = torch.randn(1, 3, 8, 224, 224, generator=g).to(torch.bfloat16)
+        head = [1, bench.MM["VID_START"]] + [bench.MM["VID_PATCH"]] * (8 + 256) + [bench.MM["VID_END"]]
+        ids = torch.tensor([head + torch.randint(5, 32000, (32,), generator=g).tolist()])
+        kw_h, kw_o, kw_t = dict(videos=vis.to(DEV)), dict(videos=vis), dict(videos=vis.float())
+    mask = torch.ones_like(ids)
+    torch.set_num_threads(min(os.cpu_count(), 64))
+    with torch.no_grad():
+        out = model.forward(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), output_hidden_states=True, **kw_h)
+        ref = O.core_forward(sd, llm_cfg, ids, mask, **kw_o)
+        truth = O.core_forward(bench.F32View(sd), llm_cfg, ids, mask, **kw_t)
+    assert tuple(out.logits.shape) == (1, ids.shape[1], 32011)
+    e0_ref, e0_hip = _rel(ref["hidden_states"][0], truth["hidden_states"][0]), _rel(out.hidden_states[0], truth["hidden_states"][0])
+    st = bench.parity_stats(out.logits[0], ref["logits"][0], truth["logits"][0])
+    print(f"{case} full depth vs oracle:", json.dumps(dict(S=int(ids.shape[1]), spliced_embeds=dict(oracle_bf16_err=round(e0_ref, 5), hip_err=round(e0_hip, 5)), logits=st)))
+    assert e0_hip <= max(3.0 * e0_ref, 2.0 ** -7)                # the CLIP tower + projector + splice (hidden state 0)
+    assert st["hip_err_vs_fp32"] <= max(3.0 * st["oracle_err_vs_fp32"], 2.0 ** -6)
+    assert st["gated_exact"] and st["positions_gated"] >= st["positions"] // 10, st
+    assert st["hip_rms_vs_fp32"] <= 1.25 * st["oracle_rms_vs_fp32"], st
+    if case == "c4_336":
+        del model
+        torch.cuda.empty_cache()
+
+
 def test_res_bench_workload_full_depth():
     import bench
     with torch.no_grad():
