@@ -35,12 +35,13 @@ struct AttnArgs {
     const elem_t* rel_h; const elem_t* rel_w;   // [B*H, Sq, KH] / [B*H, Sq, KW] or null
     int KH, KW;
     int rel_mode;                       // 1: rel_h/rel_w are per-query tables [B*H,Sq,KH|KW]; 2: they are the raw rel_pos_h/w parameters
-    int win16;                          // ull_sam_window_attention: the WIN16 form of the exact kernel, see below
+    int win16;                          // ull_sam_window_attention: sam_window_kernel, see below
+    uint32_t mg_h, mg_nwx, mg_nwy, mg_nw;   // win16: ceil(2^32 / d) for d = H, nwx, nwy, nwx * nwy (udiv_magic: no run-time integer division in the kernel)
     int v_rows;                         // Vt is V itself, [B,H,S,hd] by (vt_bs, vt_hs, vt_ds = token stride): kernels with a VROW form
                                         //    [2KH-1,hd] / [2KW-1,hd] and the tables are built in the kernel prologue on the MFMA
     float inv_kw;                       // 1 / KW
     float q_scale;                      // != 1: Q is consumed as bf16(q * q_scale)  (SAM: (q * scale) @ k^T)
-    // WIN16 (ull_sam_window_attention): Q / K / V / O rows are tokens of [img, img_h, img_w] grids in image order, "batch" b is
+    // win16 (ull_sam_window_attention): Q / K / V / O rows are tokens of [img, img_h, img_w] grids in image order, "batch" b is
     // window (img, wy, wx) of the 14 x 14 partition, Vt points at the V part of the rows (same strides as K), and window positions
     // outside the grid are the reference's zero padding (image_encoder.py:262-289 pads AFTER norm1, so a padded token's q|k|v is
     // the qkv bias): K / V rows of such keys come from k_pad / v_pad.
@@ -48,11 +49,16 @@ struct AttnArgs {
     const elem_t* k_pad; const elem_t* v_pad;   // K / V part of the pad token's row (+ h * k_hs)
 };
 
-// token index (in image order) of position (ly, lx) of window b, or -1 for a padding position
-ULL_DEV long win_token(const AttnArgs& p, int b, int ly, int lx, int ws) {
-    const int wx = b % p.nwx, wy = (b / p.nwx) % p.nwy, img = b / (p.nwx * p.nwy);
-    const int iy = wy * ws + ly, ix = wx * ws + lx;
-    return (iy < p.img_h && ix < p.img_w) ? ((long)img * p.img_h + iy) * p.img_w + ix : -1;
+// ull_sam_window_attention: window b = (img * nwy + wy) * nwx + wx -> (image, first token row, first token column).  The divisors are
+// run-time values; a / d goes through the host-computed m = ceil(2^32 / d): exact while a * d < 2^32 (the dispatcher checks), m = 0
+// encodes d = 1.  (As three integer divisions, ~30 scalar instructions each and repeated per DMA piece, this was ~1200 scalar
+// instructions in every wave's prologue.)
+struct WinOrigin { int img, iy0, ix0; };
+ULL_DEV int udiv_magic(int a, uint32_t m) { return m ? (int)__umulhi((uint32_t)a, m) : a; }
+ULL_DEV WinOrigin win_origin(const AttnArgs& p, int b, int ws) {
+    const int t = udiv_magic(b, p.mg_nwx), wx = b - t * p.nwx;
+    const int img = udiv_magic(b, p.mg_nw), wy = t - img * p.nwy;
+    return WinOrigin{img, wy * ws, wx * ws};
 }
 
 // Compile-time "flavors" of the score epilogue.  The runtime-flag version (FL_RUNTIME) costs ~6 wave-uniform branches per
@@ -125,6 +131,51 @@ ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& l
     hi = pack2e(o[2], o[3]);
 }
 
+
+// SAM 14 x 14 windows (sam_window_kernel): one lane's scores of window row kh for its four window columns kw = 4 fg + r:
+// rnd(rnd(rnd(acc) + rel_h[kh]) + rel_w[kw]), the reference's three roundings, two values at a time: one packed convert rounds a pair, the
+// two adds are one packed add, the third rounding IS the packed pair that is kept, and the row maximum takes the unrounded sums (rounding
+// is monotone; the caller rounds the maximum once).  wv23 = -inf in the lanes whose columns are the padding slots kw = 14, 15.
+// 21 vector instructions per window row instead of 45, same bits (the kernel is bound by its vector-issue slots: docs/experiments.md).
+ULL_DEV void score_quad_win(const f32x4_t& acc, float hb, const f32x2_t& wv01, const f32x2_t& wv23, uint32_t& lo, uint32_t& hi, float& row_max) {
+    // (the packed pairs are made opaque: seeing through pack -> unpack, the compiler converts every value on its own again)
+    uint32_t a01 = pack2e(acc[0], acc[1]), a23 = pack2e(acc[2], acc[3]);
+    asm volatile("" : "+v"(a01), "+v"(a23));
+    const f32x2_t x01 = f32x2_t{pk_lo(a01), pk_hi(a01)} + hb, x23 = f32x2_t{pk_lo(a23), pk_hi(a23)} + hb;
+    uint32_t b01 = pack2e(x01.x, x01.y), b23 = pack2e(x23.x, x23.y);
+    asm volatile("" : "+v"(b01), "+v"(b23));
+    const f32x2_t y01 = f32x2_t{pk_lo(b01), pk_hi(b01)} + wv01, y23 = f32x2_t{pk_lo(b23), pk_hi(b23)} + wv23;
+    row_max = fmaxf(fmaxf(fmaxf(row_max, y01.x), y01.y), fmaxf(y23.x, y23.y));
+    lo = pack2e(y01.x, y01.y);
+    hi = pack2e(y23.x, y23.y);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+}
+
+// ... and the exact fp32 softmax over the lane's 56 scores (14 window rows x 4 columns; the row's other 168 sit in the lanes fr, fr + 16,
+// fr + 32, fr + 48): every exponential is evaluated once and kept, subtraction / log2(e) / normalisation are packed fp32 operations.
+// mrow = the lane's running maximum from score_quad_win.  P = 16-bit softmax, in place.
+ULL_DEV void softmax_win(uint32_t (&sp)[4][8], float mrow) {
+    float m = rnd(mrow);
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+    f32x2_t e[28];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) {
+        const f32x2_t t = (f32x2_t{pk_lo(sp[i / 8][i % 8]), pk_hi(sp[i / 8][i % 8])} - m) * 1.4426950408889634f;   // __expf(x) = exp2(x * log2 e)
+        e[i] = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        sum += e[i].x;
+        sum += e[i].y;
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 28; ++i) {
+        const f32x2_t q = e[i] * inv;
+        sp[i / 8][i % 8] = pack2e(q.x, q.y);
+    }
+}
 
 // Stage this wave's 16 relative-position bias rows in LDS (`dst`, row pitch `bp` elements, see bias_pitch()).
 //   rel_mode 1: copy the precomputed per-query tables (stored reversed so both modes index the same way);
@@ -260,14 +311,7 @@ ULL_DEV int head_dim_of(const AttnArgs& p) {
 //   DMA'd up front, the NT V^T tiles right after the K barrier (they land during the score / softmax phases), so a block
 //   passes 2 barriers instead of 2*NT and exposes two memory round trips instead of 2*NT -- the streaming form measured
 //   46 us per block for ~10 us of work.  One block of NWV = 13 waves covers all 196 queries of a (window, head).
-//   WIN16 (the SAM 14 x 14 windows on image-order tokens): the key axis is re-indexed slot = 16 * kh + kw, i.e. every window row padded
-//   from KW = 14 to 16 slots; K AND V rows are gathered that way by the DMA straight from the q|k|v rows (window addressing, the pad
-//   token's row for positions outside the grid), and the V^T operand of P*V comes out of the row-major V tile through
-//   ds_read_b64_tr_b16 -- there is no V^T pass and no window partition pass for these blocks.  A 16-key block is then
-//   one window row: kh is a compile-time constant per block and kw = 4 * (lane / 16) + r a per-lane constant for the whole
-//   kernel, so the decomposed rel-pos bias costs one LDS read per quad and two adds per score (the generic path divides j by KW
-//   and reads two table entries per score: 28 VALU instructions per score against 10), padding is a per-lane constant, the
-//   two all-padding blocks of the fourth tile are not computed, and the row maximum is taken while the scores are produced.
+//   (The 14 x 14 windows on image-order tokens -- ull_sam_window_attention -- have their own kernel: sam_window_kernel below.)
 // gfx950's transposing LDS read: within each group of 16 lanes, lane i passes the address of 4 consecutive 16-bit elements -- row i / 4,
 // columns 4 * (i % 4) .. +3 of a 4 x 16 block -- and receives column i of the block (rows 0..3).  (Probed: tools/debug/tr_read_probe.hip.)
 // The compiler does not know this is an LDS load: lds_tr_wait() below must sit between the reads and their first use.
@@ -309,14 +353,11 @@ constexpr int attn_reg_nbuf() {
 
 //   VROW (LLaMA / CLIP prefill): the V tiles are DMA'd ROW-major from V itself ([64 keys][head dim], like the K tiles) and the V^T
 //   operand of P*V comes out of them through ds_read_b64_tr_b16: no V^T pass in front of the attention.
-template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool WIN16 = false, bool VROW = false>
+template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool VROW = false>
 __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)) ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(256))) char smem[];     // (256: the V fragment addresses below XOR bits 5..7)
-    static_assert(!WIN16 || (EXACT && FL == FL_SAM_ENC && NT == 4), "WIN16 is the 14 x 14 window form of the exact kernel");
-    static_assert(!VROW || (!WIN16 && (FL == FL_LLAMA || FL == FL_CLIP) && HDP >= 64), "VROW: flavors that pin hd = HDP");
+    static_assert(!VROW || ((FL == FL_LLAMA || FL == FL_CLIP) && HDP >= 64), "VROW: flavors that pin hd = HDP");
     constexpr int PM = HDP / 16 >= 8 ? 7 : HDP / 16 - 1;      // VROW: XOR mask of the 32-byte pair index (pairs per row - 1, at most 7)
-    constexpr int WKH = 14, WKW = 14;     // WIN16 window shape (checked by the dispatcher)
-    constexpr int NBLK = WIN16 ? WKH : 4 * NT;       // 16-key blocks that hold any key
     constexpr int BQ = 16 * NWV;
     constexpr int CPR = HDP / 8;          // 16-byte chunks per K-tile row
     constexpr int KROW = HDP * 2;         // K-tile row bytes
@@ -389,41 +430,17 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
 #pragma unroll
             for (int i0 = 0; i0 < CPR; i0 += NWV) {
                 const int i = i0 + wave;                        // one 1-KiB piece = 64/CPR rows
-                if (i < CPR && (!WIN16 || kt * KT + i * (64 / CPR) < NBLK * 16)) {
+                if (i < CPR) {
                     const int row = i * (64 / CPR) + lane / CPR;
                     const int c = (lane % CPR) ^ swz<CPR>(row);
-                    int key = min(kt * KT + row, p.Sk - 1);
-                    const elem_t* krow = nullptr;
-                    if constexpr (WIN16) {           // slot 16 * kh + kw <- window position (kh, kw); padding slots read a real key and are masked
-                        const int slot = kt * KT + row;
-                        const long tok = win_token(p, b, min(slot >> 4, WKH - 1), min(slot & 15, WKW - 1), WKW);
-                        krow = tok >= 0 ? p.K + tok * p.k_ss + (long)h * p.k_hs : p.k_pad + (long)h * p.k_hs;
-                    } else {
-                        krow = kbase + (long)key * p.k_ss;
-                    }
+                    const int key = min(kt * KT + row, p.Sk - 1);
+                    const elem_t* krow = kbase + (long)key * p.k_ss;
                     const elem_t* src = (c * 8 < hd) ? krow + c * 8 : p.zeros;
                     glds16(src, dst + i * 1024);
                 }
             }
-        } else if constexpr (WIN16) {
-            // V tile kt, ROW-major like the K tile: [64 slots][256 B].  The 32-byte pair of chunks (16 head dims) is XOR-swizzled with
-            // the row so that the 16 rows one transposing read touches spread over all banks (2 passes for 512 B: the minimum).
-            const int kt = s - nkt;
-#pragma unroll
-            for (int i0 = 0; i0 < 16; i0 += NWV) {
-                const int i = i0 + wave;                        // one 1-KiB piece = 4 slots
-                if (i < 16 && kt * KT + i * 4 < NBLK * 16) {
-                    const int row = i * 4 + (lane >> 4);
-                    const int cpos = lane & 15;                 // chunk position in the LDS row
-                    const int c = ((((cpos >> 1) ^ (row & 7)) << 1) | (cpos & 1));   // head-dim chunk stored there
-                    const int slot = kt * KT + row;
-                    const long tok = win_token(p, b, min(slot >> 4, WKH - 1), min(slot & 15, WKW - 1), WKW);
-                    const elem_t* vrow = tok >= 0 ? p.Vt + tok * p.k_ss + (long)h * p.k_hs : p.v_pad + (long)h * p.k_hs;
-                    glds16((c * 8 < hd) ? vrow + c * 8 : p.zeros, dst + i * 1024);
-                }
-            }
         } else if constexpr (VROW) {
-            // V tile kt, row-major: [64 keys][KROW bytes]; 32-byte pairs of chunks XOR-swizzled with the row (see WIN16 above)
+            // V tile kt, row-major: [64 keys][KROW bytes]; 32-byte pairs of chunks XOR-swizzled with the row (the 16 rows one transposing read touches spread over all banks)
             const int kt = s - nkt;
 #pragma unroll
             for (int i0 = 0; i0 < CPR; i0 += NWV) {
@@ -465,20 +482,13 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
     // ---- Q fragments + key-mask bytes (ordinary loads, drained together with the first DMA'd tiles) -------
     uint4 qf[NKS];
     const int qi = q0 + wave * 16 + fr;
-    long q_tok = 0;                       // WIN16: this lane's query token, -1 = a padding position
-    if constexpr (WIN16) {
-        q_tok = qi < p.Sq ? win_token(p, b, qi / WKW, qi % WKW, WKW) : -1;
-        if (__builtin_amdgcn_ballot_w64(q_tok >= 0) == 0) nkt_w = 0;         // 16 padding positions: barriers and DMA only
-    }
     {
         const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qi * p.q_ss;
-        if constexpr (WIN16) qp = p.Q + max(q_tok, 0L) * p.q_ss + (long)h * p.q_hs;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int d = ks * 32 + fg * 8;
-            qf[ks] = (qi < p.Sq && q_tok >= 0 && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+            qf[ks] = (qi < p.Sq && d < hd) ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
         }
-        if constexpr (!WIN16)
         for (int j = tid; j < nkt * KT; j += NWV * 64) {
             unsigned char m = 2;
             if (j < p.Sk) m = (p.key_mask == nullptr || p.key_mask[(long)b * p.Sk + j] != 0) ? 1 : 0;
@@ -502,12 +512,7 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
     // just requested, i.e. no DMA ever overlapped with the MFMAs.  Redefining the fragments here ends its bookkeeping of those loads.
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
-    float wv[4] = {0.f, 0.f, 0.f, 0.f};   // WIN16: rel_w of this lane's four window columns kw = 4 * fg + r (same for every block)
     float mrow = -INFINITY;               // running maximum of this lane's scores
-    if constexpr (WIN16) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wv[r] = e2f(brow[bw_off - min(fg * 4 + r, WKW - 1)]);
-    }
 
     uint32_t sp[NT][8];                   // [tile][2*ns + half]: bf16 pairs for keys kt*64 + ns*16 + 4*fg + {0,1 | 2,3}
     // LDS fragment addressing, per lane and ONCE: the K fragment of k-step ks sits at kfo[ks] inside rows fr, fr + 16, ... of a tile (the
@@ -551,7 +556,6 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
                 const char* tb = smem + (EXACT ? kt : (kt % NBUF)) * TILE;
 #pragma unroll
                 for (int ns = 0; ns < 4; ++ns) {
-                    if (WIN16 && kt * 4 + ns >= NBLK) continue;   // blocks past the last window row hold no key
                     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
                     const int row = ns * 16 + fr;
 #pragma unroll
@@ -560,19 +564,6 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
                             const uint4 kf = *(const uint4*)(tb + ns * 16 * KROW + kfo[ks]);
                             acc = mfma16(kf, qf[ks], acc);
                         }
-                    }
-                    if constexpr (WIN16) {
-                        // block = window row kh = 4 * kt + ns; this lane's keys are columns kw = 4 * fg + r
-                        const float hb = e2f(brow[bh_off - (kt * 4 + ns)]);
-                        float o[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = rnd(rnd(rnd(acc[r]) + hb) + wv[r]);
-                        if (fg == 3) o[2] = o[3] = -INFINITY;             // kw = 14, 15: padding slots
-                        mrow = fmaxf(mrow, fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])));
-                        sp[kt][ns * 2] = pack2e(o[0], o[1]);
-                        sp[kt][ns * 2 + 1] = pack2e(o[2], o[3]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        continue;
                     }
                     if constexpr (FL == FL_LLAMA || FL == FL_CLIP) {
                         // a whole tile of real keys, no key mask, entirely below the diagonal for each of the wave's queries: nothing to look up
@@ -603,31 +594,11 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float sum = 0.f;
-        if constexpr (WIN16) {
-            if (nkt_w > 0) {
-            // 56 scores per lane: the exponentials fit in registers, so each is evaluated once (the generic form evaluates it for
-            // the sum and again for P because a long row does not fit)
-            float e[NBLK * 4];
-#pragma unroll
-            for (int i = 0; i < NBLK * 2; ++i) {
-                e[2 * i] = __expf(pk_lo(sp[i / 8][i % 8]) - m);
-                e[2 * i + 1] = __expf(pk_hi(sp[i / 8][i % 8]) - m);
-                sum += e[2 * i];
-                sum += e[2 * i + 1];
-            }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int i = 0; i < NBLK * 2; ++i) sp[i / 8][i % 8] = pack2e(e[2 * i] * inv, e[2 * i + 1] * inv);
-            }
-        } else {
 #pragma clang loop unroll(full)
         for (int kt = 0; kt < NT; ++kt)
             if (kt < nkt_w) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (kt * 4 + i / 2 >= NBLK) continue;
                     // __expf(x) = v_exp_f32(x * log2(e)), written out so that the subtraction and the multiply pair up (v_pk_*_f32)
                     const f32x2_t t = (f32x2_t{pk_lo(sp[kt][i]), pk_hi(sp[kt][i])} - m) * 1.4426950408889634f;
                     sum += __builtin_amdgcn_exp2f(t.x);
@@ -643,14 +614,12 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
             if (kt < nkt_w) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (kt * 4 + i / 2 >= NBLK) continue;
                     const f32x2_t t = (f32x2_t{pk_lo(sp[kt][i]), pk_hi(sp[kt][i])} - m) * 1.4426950408889634f;
                     const f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * inv;
                     sp[kt][i] = pack2e(e.x, e.y);
                 }
                 if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
             }
-        }
     }
 
     // ---- phase 3: O^T = V^T P^T; P feeds the MFMA B operand straight from registers ---------------------
@@ -667,32 +636,7 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
             if constexpr (!EXACT) stream_step(nkt + kt);
-            if constexpr (WIN16) {
-                if (kt < nkt_w) {
-                    // row-major V tile: lane (fr, fg) asks for slots 4 * fg + fr / 4 (and 16 below), head dims 16 * ds + 4 * (fr % 4) .. +3,
-                    // and receives head dim 16 * ds + fr of slots 4 * fg .. +3: the A operand that matches the P registers.
-                    static_assert(NDS >= 5, "hd = 80");
-                    const int swr = 4 * (fg & 1) + (fr >> 2);                  // (slot & 7) of both reads
-                    const uint32_t vb = lds_base + (NT + kt) * TILE + (4 * fg + (fr >> 2)) * 256 + ((fr & 2) << 3) + ((fr & 1) << 3);
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        if (2 * (kt * 2 + kk) >= NBLK) continue;
-                        const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
-                        u32x2_t va[5], vc[5];
-#pragma unroll
-                        for (int ds = 0; ds < 5; ++ds) {
-                            const uint32_t ad = vb + ((ds ^ swr) << 5);
-                            if (kk == 0) { va[ds] = lds_tr_b64<0>(ad); vc[ds] = lds_tr_b64<16 * 256>(ad); }
-                            else { va[ds] = lds_tr_b64<32 * 256>(ad); vc[ds] = lds_tr_b64<48 * 256>(ad); }
-                        }
-                        lds_tr_wait(va, vc);
-#pragma unroll
-                        for (int ds = 0; ds < 5; ++ds)
-                            oacc[ds] = mfma16(make_uint4(va[ds].x, va[ds].y, vc[ds].x, vc[ds].y), pf, oacc[ds]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            } else if constexpr (VROW) {
+            if constexpr (VROW) {
                 if (kt < nkt_w) {
                     const uint32_t vb = lds_base + (EXACT ? NT + kt : ((nkt + kt) % NBUF)) * TILE + vfo;
                     // four head-dim blocks at a time (8 reads in flight, 16 registers): more would cost the third wave per SIMD
@@ -720,7 +664,6 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
                 const char* tb = smem + (EXACT ? NT + kt : ((nkt + kt) % NBUF)) * TILE;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    if (2 * (kt * 2 + kk) >= NBLK) continue;
                     const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
 #pragma unroll
                     for (int ds = 0; ds < NDS; ++ds) {
@@ -735,9 +678,8 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
             }
         }
     }
-    if (qi < p.Sq && q_tok >= 0) {
+    if (qi < p.Sq) {
         elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
-        if constexpr (WIN16) op = p.O + q_tok * p.o_ss + (long)h * p.o_hs;
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
             if (ds * 16 < hd) {
@@ -747,6 +689,286 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
                 *(uint2*)(op + ds * 16 + fg * 4) = pk;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAM 14 x 14 window attention (ull_sam_window_attention), one workgroup per CU walking a run of consecutive (window, head) items.
+//
+// The arithmetic is attn_reg_kernel's exact form (all 196 keys of a window resident: 4 K tiles + 4 V tiles of 64 slots, slot 16 kh + kw =
+// window position (kh, kw), 13 waves of 16 queries, scores -> rel-pos bias -> exact fp32 softmax -> P*V from registers), statement for
+// statement; what differs is everything around it.  That kernel ran one item per block -- 154 KB of LDS, so one block per CU -- and
+// was bound by its instruction issue (~4100 instructions per wave and item, 13 waves on 4 SIMDs), 40 % of them a prologue that an item
+// repeats for nothing: six integer divisions, the window -> token addressing of every DMA piece, the rel-pos tables fetched from memory.
+// Here the per-lane pieces of all addressing are computed once per block, the two rel-pos tables sit in LDS for the block's life, and
+// the NEXT item's prologue is spread under the current item's phases, still with two barriers per item and the same tile buffers:
+//   * the K tiles of the next item are requested behind the barrier that ends everybody's scores (they land under softmax and P*V),
+//     the V tiles behind the barrier that ends everybody's P*V (they land under the next scores);
+//   * its Q rows are requested after the softmax into the registers of the current ones (dead since the scores) and land under P*V;
+//   * a wave's bias rows in LDS are private to it: it rebuilds them for the next item once its P*V is stored.
+// (Nothing may spill: a reload is a VMEM load, and the wait the compiler puts in front of its use also waits for every DMA in flight.)
+// Items of a block are consecutive: mostly the 16 heads of one window (same token rows, neighbouring 160-byte columns, one XCD's L2).
+// LDS bias row of a query: [rel_h products t = 0..26][pad][rel_w products t = 0..26][pad] = 56 elements: both halves start 8-byte aligned, so
+// the four products a lane holds (t = 16 st + 4 fg + r) go out as one 64-bit write
+constexpr int SW_NWV = 13, SW_NT = 4, SW_WS = 14, SW_HD = 80, SW_NTAB = 2 * SW_WS - 1, SW_BW = SW_NTAB + 1, SW_BP = 2 * SW_BW, SW_TILE = 64 * 256;
+constexpr int SW_LDS = 2 * SW_NT * SW_TILE + SW_NWV * 16 * SW_BP * 2 + 2 * SW_NTAB * SW_HD * 2;      // 163 008 bytes
+static_assert(SW_LDS <= 160 * 1024, "K + V tiles, 208 bias rows and the two rel-pos tables fit one CU's LDS");
+__global__ __launch_bounds__(SW_NWV * 64) void sam_window_kernel(AttnArgs p, int n_items) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    constexpr int NWV = SW_NWV, NT = SW_NT, WS = SW_WS, NBLK = SW_WS, KROW = 256, TILE = SW_TILE, NKS = 3, HD = SW_HD, NTAB = SW_NTAB, BW = SW_BW, BP = SW_BP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    elem_t* biasb = (elem_t*)(smem + 2 * NT * TILE);
+    elem_t* tabs = biasb + NWV * 16 * BP;             // [2][27][80]: rel_pos_h, rel_pos_w
+    elem_t* brow = biasb + (wave * 16 + fr) * BP;     // this lane's query's bias row (the wave's 16 rows are private to it)
+
+    int item = (int)((uint32_t)blockIdx.x * (uint32_t)n_items / gridDim.x);
+    const int last = (int)((uint32_t)(blockIdx.x + 1) * (uint32_t)n_items / gridDim.x);
+    if (item >= last) return;
+
+    // ---- per-lane state ---------------------------------------------------------------------------------------------------------------
+    // Registers are the scarce thing here (13 waves: 128 per lane, 56 of them the softmax's exponentials), so only what the inner loops
+    // read stays resident -- the K / V fragment offsets and the lane's bias row.  Everything the per-item address arithmetic needs is
+    // re-derived from the lane id where it is used (a few vector instructions per item), behind an opaque copy of the id so that the
+    // compiler cannot hoist it back out of the item loop: hoisted, it spills, and a spill reload in the middle of the DMA requests waits
+    // for all of them.
+    const int qi = wave * 16 + fr;                    // this lane's query: window position (qi / 14, qi % 14); >= 196: none
+    const int qy = min(qi, WS * WS - 1) / WS;
+    const elem_t* brow_h = biasb + (wave * 16 + fr) * BP + qy + WS - 1;       // rel_h(kh) = brow_h[-kh]
+    uint32_t kfo[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        kfo[ks] = fr * KROW + (((ks * 4 + fg) ^ (fr & 15)) << 4);
+        asm volatile("" : "+v"(kfo[ks]));
+    }
+    // V fragment of head-dim block ds: (tile base + vfx) ^ (ds << 5) -- the 32-byte pair of chunks is XOR-swizzled with (slot & 7)
+    uint32_t vfx = (lds_base + NT * TILE + (4 * fg + (fr >> 2)) * 256 + ((fr & 2) << 3) + ((fr & 1) << 3)) ^ ((4 * (fg & 1) + (fr >> 2)) << 5);
+    asm volatile("" : "+v"(vfx));
+    const uint32_t row_pitch = (uint32_t)p.img_w * (uint32_t)p.k_ss * 2u;      // bytes between window rows (dispatcher: 14 rows < 2^31)
+
+    // ---- per-item scalar state ----------------------------------------------------------------------------------------------------------
+    struct Item { int h, iy0, ix0; long tok0; };       // head, window origin, token index of the window's first position
+    auto locate = [&](int it) {
+        const int b = udiv_magic(it, p.mg_h);
+        const WinOrigin wo = win_origin(p, b, WS);
+        return Item{it - b * p.H, wo.iy0, wo.ix0, ((long)wo.img * p.img_h + wo.iy0) * p.img_w + wo.ix0};
+    };
+    // The wave's pieces of the four K (which = 0) or V (which = 1) tiles of an item.  One LDS-DMA piece = 1 KiB = 4 window columns x 16
+    // chunks of ONE window row: piece i of tile kt holds window row 4 kt + i / 4, columns 4 (i % 4) + lane / 16; a wave's pieces are
+    // i = wave and, in waves 0..2, i = wave + 13.  Everything a lane needs except the row is the same for the four tiles, so per tile
+    // the source is one 64-bit add of a wave-uniform row offset and one select (per piece -- token index, its 64-bit multiply by the
+    // row pitch, three nested selects -- it was ~40 instructions x 10 pieces in every wave).
+    //   in  = this lane's chunk of window row 0 (used when row and column are inside the image and the chunk holds real head dims)
+    //   out = its source otherwise: the padded position's row (= the qkv bias: what the reference's F.pad + Linear leaves there), or
+    //         zeros for the chunks past the head dim
+    auto issue_tiles = [&](const Item& t, int which) {
+        int ln = tid;
+        asm volatile("" : "+v"(ln));
+        const char* in_base = (const char*)((which ? p.Vt : p.K) + t.tok0 * p.k_ss + (long)t.h * p.k_hs);
+        const char* pad_base = (const char*)((which ? p.v_pad : p.k_pad) + (long)t.h * p.k_hs);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = wave + j * NWV;
+            if (i < 16) {
+                const int l4 = (ln >> 4) & 3, cpos = ln & 15, row = i * 4 + l4;
+                const uint32_t c = 16u * (uint32_t)(which ? ((((cpos >> 1) ^ (row & 7)) << 1) | (cpos & 1)) : (cpos ^ (row & 15)));
+                const int lx = min((i & 3) * 4 + l4, WS - 1);                     // slots kw = 14, 15 read a real key and are masked
+                const bool real = c < HD * 2;                                     // chunks past the head dim are zeros
+                const bool col_ok = real && t.ix0 + lx < p.img_w;
+                const char* in = in_base + ((uint32_t)lx * (uint32_t)p.k_ss * 2u + c);
+                const char* out = real ? pad_base + c : (const char*)p.zeros;   // outside the image: the padded position's row (the qkv bias)
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    if (kt * 64 + i * 4 >= NBLK * 16) continue;                   // slots past the last window row are never read
+                    const int ly = kt * 4 + (i >> 2);                             // the piece's window row (wave-uniform)
+                    const bool row_ok = t.iy0 + ly < p.img_h;
+                    glds16((row_ok && col_ok) ? in + (uint32_t)ly * row_pitch : out, lds_base + (which * NT + kt) * TILE + i * 1024);
+                }
+            }
+        }
+    };
+    // byte offset of this lane's query's row inside the window (pitch = the row pitch of Q or O in elements) and whether it is in the image
+    auto query_pos = [&](const Item& t, int pitch, uint32_t& off, bool& ok) {
+        int ln = tid;
+        asm volatile("" : "+v"(ln));
+        const int q = (ln >> 6) * 16 + (ln & 15), qc = min(q, WS * WS - 1), y = qc / WS, x = qc - y * WS;
+        ok = q < WS * WS && t.iy0 + y < p.img_h && t.ix0 + x < p.img_w;
+        off = (uint32_t)(y * p.img_w + x) * (uint32_t)pitch * 2u;
+    };
+    auto load_q = [&](const Item& t, uint4 (&q)[NKS], bool& ok) {
+        uint32_t off;
+        query_pos(t, (int)p.q_ss, off, ok);
+        int ln = tid;
+        asm volatile("" : "+v"(ln));
+        const int g = (ln >> 4) & 3;
+        const char* qb = (const char*)(p.Q + t.tok0 * p.q_ss + (long)t.h * p.q_hs) + (off + g * 16);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            q[ks] = (ok && ks * 32 + g * 8 < HD) ? *(const uint4*)(qb + ks * 64) : make_uint4(0, 0, 0, 0);
+    };
+    float wv[4];
+    // unscaled q -> the wave's bias rows in LDS (stage_rel_bias's rel_mode-2 product with the table fragments read from LDS, one
+    // (table, 16-row step) at a time: same fragments, MFMAs and rounding), then the scaled q and this lane's four rel_w values
+    auto finish_prologue = [&](uint4 (&q)[NKS]) {
+        int ln = tid;
+        asm volatile("" : "+v"(ln));
+        const int fr = ln & 15, fg = (ln >> 4) & 3;   // (shadow the block-level copies: see "per-lane state")
+        elem_t* dst = biasb + wave * 16 * BP;
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int tr = min(st * 16 + fr, NTAB - 1);
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const int d = ks * 32 + fg * 8;
+                    const uint4 tf = (d < HD) ? *(const uint4*)(tabs + (which * NTAB + tr) * HD + d) : make_uint4(0, 0, 0, 0);
+                    acc = mfma16(tf, q[ks], acc);
+                }
+                // acc[r] = G[t = 16 st + 4 fg + r][query fr]; t = 27 lands in the half's pad element, t >= 28 does not exist
+                if (st == 0 || fg < 3) {
+                    uint2 pk;
+                    pk.x = pack2e(acc[0], acc[1]);
+                    pk.y = pack2e(acc[2], acc[3]);
+                    *(uint2*)(dst + fr * BP + which * BW + st * 16 + fg * 4) = pk;
+                }
+            }
+        if (p.q_scale != 1.0f) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {        // scale_q8, two values per multiply
+                uint32_t* w = (uint32_t*)&q[ks];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2_t v = f32x2_t{pk_lo(w[j]), pk_hi(w[j])} * p.q_scale;
+                    w[j] = pack2e(v.x, v.y);
+                }
+            }
+        }
+        const elem_t* brow_w = brow_h - qy + BW + (min(qi, WS * WS - 1) - qy * WS);         // row + 28 + qx + 13: rel_w(kw) = brow_w[-kw]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[r] = e2f(*(brow_w - min(fg * 4 + r, WS - 1)));
+        if (fg == 3) wv[2] = wv[3] = -INFINITY;       // kw = 14, 15: padding slots
+    };
+
+    // ---- the block's first item: its whole prologue is exposed ------------------------------------------------------------------------
+    Item cur = locate(item);
+    uint4 qf[NKS];
+    bool q_ok;
+    issue_tiles(cur, 0);
+    load_q(cur, qf, q_ok);
+    for (int i = tid; i < 2 * NTAB * HD / 8; i += NWV * 64)
+        ((uint4*)tabs)[i] = ((const uint4*)(i < NTAB * HD / 8 ? p.rel_h : p.rel_w))[i < NTAB * HD / 8 ? i : i - NTAB * HD / 8];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the compiler does not see that wait: redefining the fragments ends its own bookkeeping of the loads, see attn_reg_kernel)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
+    __syncthreads();                                  // tables and every K piece are in LDS
+    issue_tiles(cur, 1);                              // V tiles land during the scores
+    finish_prologue(qf);
+
+    while (true) {
+        const bool has_next = item + 1 < last;
+        const bool live = __builtin_amdgcn_ballot_w64(q_ok) != 0;             // 16 padding positions: barriers and DMA only
+
+        // ---- phase 1: scores of window row kh = 4 kt + ns, this lane's columns kw = 4 fg + r --------------------------------------------
+        uint32_t sp[NT][8];
+        float mrow = -INFINITY;
+        if (live) {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const char* tb = smem + kt * TILE;
+#pragma unroll
+                for (int ns = 0; ns < 4; ++ns) {
+                    if (kt * 4 + ns >= NBLK) continue;
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        const uint4 kf = *(const uint4*)(tb + ns * 16 * KROW + kfo[ks]);
+                        acc = mfma16(kf, qf[ks], acc);
+                    }
+                    const float hb = e2f(*(brow_h - (kt * 4 + ns)));
+                    score_quad_win(acc, hb, f32x2_t{wv[0], wv[1]}, f32x2_t{wv[2], wv[3]}, sp[kt][ns * 2], sp[kt][ns * 2 + 1], mrow);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's V pieces, requested a phase ago
+        __builtin_amdgcn_s_barrier();                 // V tiles visible; every wave has left the scores: the K tiles are free
+        Item nxt = cur;
+        if (has_next) {
+            if (cur.h + 1 < p.H) nxt.h = cur.h + 1;   // same window, next head
+            else nxt = locate(item + 1);
+            issue_tiles(nxt, 0);                      // the next item's K tiles land under the softmax, P*V and its prologue
+        }
+        // ---- phase 2: exact fp32 softmax over the 196 scores of the row (registers only) ------------------------------------------------
+        if (live) softmax_win(sp, mrow);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool q_ok_cur = q_ok;
+        if (has_next) load_q(nxt, qf, q_ok);          // (the current Q fragments had their last use in phase 1) lands under P*V
+
+        // ---- phase 3: O^T = V^T P^T ------------------------------------------------------------------------------------------------------
+        f32x4_t oacc[5];
+#pragma unroll
+        for (int ds = 0; ds < 5; ++ds) oacc[ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            uint32_t vad[5];                          // re-derived per item: kept across the loop they would be spilled
+            {
+                uint32_t vf = vfx;
+                asm volatile("" : "+v"(vf));
+#pragma unroll
+                for (int ds = 0; ds < 5; ++ds) vad[ds] = vf ^ (ds << 5);
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    if (2 * (kt * 2 + kk) >= NBLK) continue;
+                    const uint4 pf = make_uint4(sp[kt][4 * kk], sp[kt][4 * kk + 1], sp[kt][4 * kk + 2], sp[kt][4 * kk + 3]);
+                    u32x2_t va[5], vc[5];
+#pragma unroll
+                    for (int ds = 0; ds < 5; ++ds) {                          // (tile and slot block are immediate offsets of the read)
+                        if (kt == 0) { if (kk == 0) { va[ds] = lds_tr_b64<0>(vad[ds]); vc[ds] = lds_tr_b64<16 * 256>(vad[ds]); }
+                                       else { va[ds] = lds_tr_b64<32 * 256>(vad[ds]); vc[ds] = lds_tr_b64<48 * 256>(vad[ds]); } }
+                        if (kt == 1) { if (kk == 0) { va[ds] = lds_tr_b64<TILE>(vad[ds]); vc[ds] = lds_tr_b64<TILE + 16 * 256>(vad[ds]); }
+                                       else { va[ds] = lds_tr_b64<TILE + 32 * 256>(vad[ds]); vc[ds] = lds_tr_b64<TILE + 48 * 256>(vad[ds]); } }
+                        if (kt == 2) { if (kk == 0) { va[ds] = lds_tr_b64<2 * TILE>(vad[ds]); vc[ds] = lds_tr_b64<2 * TILE + 16 * 256>(vad[ds]); }
+                                       else { va[ds] = lds_tr_b64<2 * TILE + 32 * 256>(vad[ds]); vc[ds] = lds_tr_b64<2 * TILE + 48 * 256>(vad[ds]); } }
+                        if (kt == 3) { va[ds] = lds_tr_b64<3 * TILE>(vad[ds]); vc[ds] = lds_tr_b64<3 * TILE + 16 * 256>(vad[ds]); }
+                    }
+                    lds_tr_wait(va, vc);              // (the K pieces in flight are VMEM: these reads are counted by lgkmcnt alone)
+#pragma unroll
+                    for (int ds = 0; ds < 5; ++ds)
+                        oacc[ds] = mfma16(make_uint4(va[ds].x, va[ds].y, vc[ds].x, vc[ds].y), pf, oacc[ds]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (q_ok_cur) {
+            uint32_t o_off;
+            bool unused;
+            query_pos(cur, (int)p.o_ss, o_off, unused);
+            int ln = tid;
+            asm volatile("" : "+v"(ln));
+            char* ob = (char*)(p.O + cur.tok0 * p.o_ss + (long)cur.h * p.o_hs) + (o_off + ((ln >> 4) & 3) * 8);
+#pragma unroll
+            for (int ds = 0; ds < 5; ++ds) {
+                uint2 pk;
+                pk.x = pack2e(oacc[ds][0], oacc[ds][1]);
+                pk.y = pack2e(oacc[ds][2], oacc[ds][3]);
+                *(uint2*)(ob + ds * 32) = pk;
+            }
+        }
+        if (!has_next) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next Q rows, this wave's pieces of the next K tiles, its stores
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
+        finish_prologue(qf);                          // this wave's bias rows and wv are its own: their last use was phase 1
+        __builtin_amdgcn_s_barrier();                 // next K tiles visible; every wave has left P*V: the V tiles are free
+        issue_tiles(nxt, 1);
+        cur = nxt; ++item;
     }
 }
 
@@ -1552,7 +1774,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const elem_t* __restri
     }
 }
 
-template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false, bool WIN16 = false, bool VROW = false>
+template <int HDP, int NT, int FL, int NWV = 8, bool EXACT = false, bool VROW = false>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int TILE = 64 * HDP * 2 > HDP * 128 ? 64 * HDP * 2 : HDP * 128;
     const int lds = attn_reg_nbuf<HDP, NT, NWV, EXACT, VROW>() * TILE + NT * KT +
@@ -1560,11 +1782,11 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     if (lds > 160 * 1024) return ULL_ERR_LDS;
     static UllOncePerDevice once;
     if (lds > 64 * 1024 && once.first())
-        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16, VROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_reg_kernel<HDP, NT, FL, NWV, EXACT, VROW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
-    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, WIN16, VROW>), grid, dim3(NWV * 64), lds, st, a);
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, VROW>), grid, dim3(NWV * 64), lds, st, a);
     return ull_check_launch();
 }
 
@@ -1632,14 +1854,14 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
     if (a.v_rows) {                      // V handed over row-major: the kernels that transpose on the fly (see the C entry)
         if constexpr (HDP == 128) {
-            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4, false, false, true>(a, st);
-            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, false, true>(a, st);
+            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4, false, true>(a, st);
+            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, true>(a, st);
             if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16)
                 return launch_stream<128, FL_SAM_ENC, 2, true>(a, st);
         }
         if constexpr (HDP == 64) {
-            if (fl == FL_CLIP && a.Sq > 16 && nt <= 5) return launch_attn<64, 5, FL_CLIP, 8, false, false, true>(a, st);
-            if (fl == FL_CLIP && a.Sq > 16 && nt <= 11) return launch_attn<64, 11, FL_CLIP, 4, false, false, true>(a, st);
+            if (fl == FL_CLIP && a.Sq > 16 && nt <= 5) return launch_attn<64, 5, FL_CLIP, 8, false, true>(a, st);
+            if (fl == FL_CLIP && a.Sq > 16 && nt <= 11) return launch_attn<64, 11, FL_CLIP, 4, false, true>(a, st);
         }
         return ULL_ERR_SHAPE;
     }
@@ -1659,7 +1881,11 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
         if (fl == FL_LLAMA && nt <= 16) return launch_attn<128, 16, FL_LLAMA>(a, st);
         if (a.win16) {                                                                   // 14 x 14 windows on image-order tokens
             if (fl != FL_SAM_ENC || a.KH != 14 || a.KW != 14 || a.Sk != 196 || a.Sq != 196 || a.key_mask) return ULL_ERR_SHAPE;
-            return launch_attn<128, 4, FL_SAM_ENC, 13, true, true>(a, st);
+            const int n_items = a.B * a.H, n_cu = ull_cu_count();
+            static UllOncePerDevice once;
+            if (once.first()) (void)hipFuncSetAttribute((const void*)sam_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(sam_window_kernel, dim3(n_items < n_cu ? n_items : n_cu), dim3(SW_NWV * 64), SW_LDS, st, a, n_items);
+            return ull_check_launch();
         }
         if (fl == FL_SAM_ENC && nt == 4 && a.Sq <= 208) return launch_attn<128, 4, FL_SAM_ENC, 13, true>(a, st);   // 14 x 14 windows
         if (fl == FL_SAM_ENC && nt <= 11) return launch_attn<128, 11, FL_SAM_ENC>(a, st);
@@ -1712,7 +1938,7 @@ extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs,
     a.rel_h = (const elem_t*)rel_h; a.rel_w = (const elem_t*)rel_w; a.KH = (int)rel_kh; a.KW = (int)rel_kw; a.q_scale = q_scale;
     a.inv_kw = rel_kw > 0 ? 1.0f / (float)rel_kw : 0.f;
     a.rel_mode = rel_h ? rel_mode : 0;
-    a.win16 = 0;
+    a.win16 = 0; a.mg_h = a.mg_nwx = a.mg_nwy = a.mg_nw = 0;
     a.v_rows = vt_len == 0;
     a.img_h = a.img_w = a.nwy = a.nwx = 0; a.k_pad = a.v_pad = nullptr;
     if (rel_h && rel_mode != 1 && rel_mode != 2) return ULL_ERR_ARG;
@@ -1805,6 +2031,11 @@ extern "C" int ULL_FN(ull_sam_window_attention_)(const void* qkv, int64_t ld, co
     a.inv_kw = 1.0f / (float)ws;
     a.rel_mode = 2; a.win16 = 1; a.v_rows = 0;
     a.img_h = (int)Hh; a.img_w = (int)Ww; a.nwy = nwy; a.nwx = nwx;
+    // the kernel's index arithmetic: (window, head) -> window -> image by multiply-high, row offsets inside a window in 32 bits
+    const int64_t items = (int64_t)a.B * nH, dmax = nH > (int64_t)nwy * nwx ? nH : (int64_t)nwy * nwx;
+    if (items * dmax >= (1LL << 32) || Ww * ld * 2 * ws >= (1LL << 31)) return ULL_ERR_SHAPE;
+    auto magic = [](int64_t d) { return d <= 1 ? 0u : (uint32_t)(((1ULL << 32) + (uint64_t)d - 1) / (uint64_t)d); };
+    a.mg_h = magic(nH); a.mg_nwx = magic(nwx); a.mg_nwy = magic(nwy); a.mg_nw = magic((int64_t)nwy * nwx);
     a.k_pad = (const elem_t*)pad_row + C; a.v_pad = (const elem_t*)pad_row + 2 * C;
     return dispatch_nt<128>(a, (hipStream_t)stream);
 }

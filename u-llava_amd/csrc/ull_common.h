@@ -239,6 +239,18 @@ struct UllOncePerDevice {
     }
 };
 
+// compute units of the current device (sizes the grids of the kernels that walk their work list: one workgroup per CU)
+static inline int ull_cu_count() {
+    static int n_cu[64];                 // 0 = not yet asked
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n_cu[dev]) {
+        hipDeviceProp_t prop;
+        n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n_cu[dev];
+}
+
 static inline int ull_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ULL_OK : ULL_ERR_LAUNCH;
