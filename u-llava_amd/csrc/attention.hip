@@ -1343,7 +1343,9 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
         __builtin_amdgcn_s_barrier();
         issue(kt + 1);
         const char* tb = smem + (kt & 1) * (2 * TILE);
-        float sv[16];
+        // scores as 16-bit pairs sq[2 ns + half] (keys 16 ns + 4 fg + {0,1 | 2,3}) and the tile maximum of this lane's 16
+        uint32_t sq[8];
+        float tm = -INFINITY;
 #pragma unroll
         for (int ns = 0; ns < 4; ++ns) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -1356,19 +1358,15 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
                 }
             }
             if constexpr (HOIST != 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sv[ns * 4 + r] = rnd(rnd(rnd(acc[r]) + rh) + rw[ns * 4 + r]);
+                // rnd(rnd(rnd(acc) + rel_h) + rel_w) two values at a time (score_quad_win: packed converts and adds, 21 vector
+                // instructions per quad instead of 45; the maximum is taken on the unrounded sums and rounded once below)
+                score_quad_win(acc, rh, f32x2_t{rw[ns * 4], rw[ns * 4 + 1]}, f32x2_t{rw[ns * 4 + 2], rw[ns * 4 + 3]}, sq[ns * 2], sq[ns * 2 + 1], tm);
             } else {
                 const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
-                uint32_t lo, hi;
-                score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, lo, hi);
-                sv[ns * 4 + 0] = pk_lo(lo); sv[ns * 4 + 1] = pk_hi(lo);
-                sv[ns * 4 + 2] = pk_lo(hi); sv[ns * 4 + 3] = pk_hi(hi);
+                score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, sq[ns * 2], sq[ns * 2 + 1], &tm);
             }
         }
-        float tm = sv[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) tm = fmaxf(tm, sv[i]);
+        tm = rnd(tm);
         tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
         tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
         const float mn = fmaxf(m, tm);                         // finite from tile 0 on (key 0 is always in range)
@@ -1385,8 +1383,9 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
         uint32_t pk[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float e0 = __expf(sv[2 * i] - m), e1 = __expf(sv[2 * i + 1] - m);
-            pk[i] = pack2e(e0, e1);
+            // __expf(x) = v_exp_f32(x * log2(e)), written out so that the subtraction and the multiply pair up (v_pk_*_f32)
+            const f32x2_t t = (f32x2_t{pk_lo(sq[i]), pk_hi(sq[i])} - m) * 1.4426950408889634f;
+            pk[i] = pack2e(__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y));
         }
         // The row sum runs over the ROUNDED probabilities, so that O / l is a true weighted mean of V rows: one more "V^T row" of ones
         // through the MFMA (2 per tile) instead of unpacking and adding every probability again on the VALU, which is the bound here.
