@@ -1883,6 +1883,7 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
             const int n_items = a.B * a.H, n_cu = ull_cu_count();
             static UllOncePerDevice once;
             if (once.first()) (void)hipFuncSetAttribute((const void*)sam_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            // one workgroup per CU (two / four shorter runs per CU: 165 / 188 us against 152 standalone, RES step 86.1 / 86.5 ms against 85.8)
             hipLaunchKernelGGL(sam_window_kernel, dim3(n_items < n_cu ? n_items : n_cu), dim3(SW_NWV * 64), SW_LDS, st, a, n_items);
             return ull_check_launch();
         }
