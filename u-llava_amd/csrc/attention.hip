@@ -1291,9 +1291,43 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 
     const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
     const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    // SAM global attention (HOIST 2 + VROW: 4096 keys = whole tiles, hd 80 in 256-byte rows): the per-lane part of every DMA source is
+    // the same for all 64 tiles -- one 32-bit byte offset per piece, computed once (per tile it was ~20 vector instructions x 4 pieces,
+    // a third of the tile's vector work) -- and the six chunks of a row that are head-dim padding are not transferred at all: the two
+    // the last QK k-step reads (dims 80..95) are zeroed once per tile slot below, the other four and V's six are never read.
+    constexpr bool FASTDMA = HOIST == 2 && VROW;
+    uint32_t dko[FASTDMA ? 2 : 1], dvo[FASTDMA ? 2 : 1];
+    bool dk_real[FASTDMA ? 2 : 1], dv_real[FASTDMA ? 2 : 1];
+    if constexpr (FASTDMA) {
+        static_assert(!FASTDMA || (CPR == 16 && NWV == 8), "two 1-KiB pieces per wave, K and V");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = wave + j * NWV, row = i * 4 + (lane >> 4), cpos = lane & 15;
+            const int ck = cpos ^ (row & 15), cv = ((((cpos >> 1) ^ (row & 7)) << 1) | (cpos & 1));
+            dko[j] = (uint32_t)(((long)row * p.k_ss + ck * 8) * 2);
+            dvo[j] = (uint32_t)(((long)row * p.vt_ds + cv * 8) * 2);
+            dk_real[j] = ck * 8 < hd;
+            dv_real[j] = cv * 8 < hd;
+        }
+        for (int t = tid; t < 2 * 64 * 2; t += 512) {          // chunks 10, 11 of every K row of both slots (after the barrier above)
+            const int slot = t >> 7, row = (t & 127) >> 1, c = 10 + (t & 1);
+            *(uint4*)(smem + slot * (2 * TILE) + row * KROW + ((c ^ (row & 15)) << 4)) = make_uint4(0, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the first tile's barrier orders these writes before every read)
+    }
     auto issue = [&](int kt) {                                // K tile kt and V^T tile kt -> slot kt & 1 = [K | V^T]
         if (kt >= nkt) return;
         const uint32_t dst = lds_base + (kt & 1) * (2 * TILE);
+        if constexpr (FASTDMA) {
+            const elem_t* tk = kbase + (long)kt * KT * p.k_ss;
+            const elem_t* tv = vbase + (long)kt * KT * p.vt_ds;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (dk_real[j]) glds16s(tk, dko[j], dst + (wave + j * NWV) * 1024);
+                if (dv_real[j]) glds16s(tv, dvo[j], dst + TILE + (wave + j * NWV) * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int i0 = 0; i0 < CPR; i0 += NWV) {
             const int i = i0 + wave;
@@ -1855,7 +1889,8 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
         if constexpr (HDP == 128) {
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4, false, true>(a, st);
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, true>(a, st);
-            if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16)
+            if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16 &&
+                64 * a.k_ss * 2 < (1L << 31) && 64 * a.vt_ds * 2 < (1L << 31))         // (32-bit per-lane DMA offsets inside a tile)
                 return launch_stream<128, FL_SAM_ENC, 2, true>(a, st);
         }
         if constexpr (HDP == 64) {
