@@ -1378,8 +1378,15 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
 // Measured (tools/patchify_bench.py, same box): 38.5 us against 42.4 at 336^2 = 19.7 % of the 8 TB/s the north-star target counts
 // against.  Per CU the tile needs 765 KB through the L1 (~9 us at the ~85 GB/s a CU sustains) and 12.7 us of MFMA time, so ~15-19 us
 // would be the floor of ANY single-round GEMM form of this op (= 40-50 % of HBM peak: the 60 % target, 12.6 us, is below the MFMA time
-// alone); what is left between 19 and 38 us is the 11-step loop waiting for HBM-sourced pixel tiles at a prefetch distance of one
-// step (two 68-KiB stages are all the LDS holds).  0.02 % of a C4 step.
+// alone).  Round 4 took the kernel apart (profiles/r04_patchify_variants.txt): (1) the DMA pieces' address arithmetic, ~420
+// instructions per K-step and wave, moved into a table (segtab): 38.2 -> 33.4-33.7 us, shipped; (2) a ring of four 34-KiB stages of
+// 32-wide K-steps, three steps in flight instead of one: 36.8 us (tools/probes/patchify_bk32_ring_r04.hip.inc) -- the loop does not wait
+// for memory latency; (3) fragment reads software-pipelined in groups of three pixel-row blocks under the previous group's MFMAs:
+// 33.4 us, no change; (4) ablations of the shipped form: without the MFMAs 27.0 us, without any DMA after the first stage 27.8 us.
+// A misaligned 16-byte-lane gather (28-byte lane stride) is not the limit either: it streams 98 GB/s per CU from the L2
+// (tools/probes/dma_align_probe.hip; 140 aligned).  What the ablations leave is the single round itself: launch + per-lane patch
+// addressing + first stage (~5 us), then all 256 blocks finish together and write 37.7 MB at once (~6 us at the 6.9 TB/s fill rate)
+// with nothing left to overlap it, around a K-loop of ~21 us against 12.7 us of MFMA time.  0.02 % of a C4 step.
 template <int WMB>
 __global__ __launch_bounds__(512) void patchify_strip_kernel(GemmArgs p, PatchArgs q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1403,38 +1410,49 @@ __global__ __launch_bounds__(512) void patchify_strip_kernel(GemmArgs p, PatchAr
     const int srow = lane >> 3;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     constexpr int PPW = (NPIECE + 7) / 8;                  // pieces per wave
+    // Element offset of (c, ky) segment idx = c * ps + ky inside an image, -1 past the last real segment: a table of K / 16 <= 64 entries in
+    // LDS, filled once.  (Computed per DMA piece and K-step -- an integer division by ps, a 64-bit multiply, three selects -- the nine
+    // pieces of a wave cost ~420 instructions per K-step against its 72 MFMAs, and the barrier of every step lined the two waves of a
+    // SIMD up so that both did their address arithmetic first and their MFMAs second: 38.2 us, 33.7 with the table; round 4.)
+    int* segtab = (int*)(smem + 2 * STAGE);
+    if (tid < 64) {
+        const int c = tid / q.ps, ky = tid - c * q.ps;
+        segtab[tid] = tid < q.nseg ? (c * q.H + ky) * q.W : -1;
+    }
     // piece pc (0 .. NPIECE): pc < TM / 8 -> A rows 8 pc .. + 8, else W rows
     const elem_t* src[PPW];                                // A: pixel (b, c = 0, y = py * ps, x = px * ps) + half * 8;  W: row start + chunk
-    int aseg[PPW];                                         // A: (c, ky) segment of this lane's chunk within the K-tile (0..3), -1 for a W piece
+    const int schunk = (lane & 7) ^ srow;                  // X tile swizzle: row & 7 (the same for every A piece of the lane)
+    const int aseg = schunk >> 1;                          // (c, ky) segment of this lane's chunk within the K-tile (0..3)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int pc = wave + 8 * i;
-        src[i] = nullptr; aseg[i] = -1;
+        src[i] = nullptr;
         if (pc < TM / 8) {
             const int r = pc * 8 + srow;
-            const int schunk = (lane & 7) ^ srow;          // X tile swizzle: row & 7
             const int m = min(m0 + r, p.M - 1);
             const int px = m % q.gw, py = (m / q.gw) % q.gh, b = m / (q.gw * q.gh);
             src[i] = q.img + (((long)b * q.C * q.H + (long)py * q.ps) * q.W + px * q.ps) + (schunk & 1) * 8;
-            aseg[i] = schunk >> 1;
         } else if (pc < NPIECE) {
             const int r = (pc - TM / 8) * 8 + srow;
             const int wchunk = (lane & 7) ^ w4_row_swizzle<false>(r);
             src[i] = p.W + (long)min(n0 + r, p.N - 1) * p.ldw + wchunk * 8;
         }
     }
-    auto stage = [&](int buf, int kt) {
+    // the 16-byte chunk of the last patch column runs 2 pixels into the next image row (zero weight columns): for the very last row of
+    // the image buffer that is past its end, and only the strip that holds the last patches can get there (two code paths: the guard
+    // costs a 64-bit compare and an exec-masked branch per piece)
+    const bool tail_strip = __builtin_amdgcn_readfirstlane(m0 + TM >= p.M ? 1 : 0) != 0;
+    __syncthreads();                                       // segtab
+    auto stage_t = [&](int buf, int kt, auto guarded) {
         const uint32_t sb = lds_base + buf * STAGE;
+        const int off = segtab[kt * 4 + aseg];
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int pc = wave + 8 * i;
             if (pc >= NPIECE) continue;
             if (pc < TM / 8) {
-                const int idx = kt * 4 + aseg[i];          // global (c, ky) segment of this lane's chunk
-                const int c = idx / q.ps, ky = idx - c * q.ps;
-                const bool real = idx < q.nseg;
-                const elem_t* sp = real ? src[i] + ((long)c * q.H + ky) * q.W : q.zeros;
-                if (real && sp + 8 > q.img_end) {          // the one chunk that would read past the image buffer: through registers
+                const elem_t* sp = off >= 0 ? src[i] + off : q.zeros;
+                if (decltype(guarded)::value && off >= 0 && sp + 8 > q.img_end) {          // through registers
                     const uint32_t* s32 = (const uint32_t*)sp;
                     *(uint4*)(smem + buf * STAGE + pc * 1024 + lane * 16) = make_uint4(s32[0], s32[1], s32[2], 0u);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1445,6 +1463,10 @@ __global__ __launch_bounds__(512) void patchify_strip_kernel(GemmArgs p, PatchAr
                 glds16(src[i] + (long)kt * BK, sb + A_BYTES + (pc - TM / 8) * 1024);
             }
         }
+    };
+    auto stage = [&](int buf, int kt) {
+        if (tail_strip) stage_t(buf, kt, std::true_type{});
+        else stage_t(buf, kt, std::false_type{});
     };
     int swz[2], wswz[2];
     swz[0] = ((0 + fg) ^ (lane & 7)) << 4;
@@ -1816,8 +1838,8 @@ static int gemm_device_state(int* n_cu_out) {
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)patchify_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        (void)hipFuncSetAttribute((const void*)big::patchify_strip_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (288 + 256) * 128);
-        (void)hipFuncSetAttribute((const void*)big::patchify_strip_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128);
+        (void)hipFuncSetAttribute((const void*)big::patchify_strip_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (288 + 256) * 128 + 256);
+        (void)hipFuncSetAttribute((const void*)big::patchify_strip_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128 + 256);
         n_cu[dev] = n;                   // last: a racing first call on another thread repeats the (idempotent) attribute calls
     }
     *n_cu_out = n_cu[dev];
@@ -1989,7 +2011,7 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
     int n_cu = 0;
     if (const int rc = gemm_device_state(&n_cu)) return rc;
     // one round of problem-sized strips when the batch allows it (C4: 32 x 576 patches = 64 strips of 288 x 4 column tiles = 256 blocks)
-    if ((N & 255) == 0 && (ldc & 7) == 0 && !getenv("ULL_PATCHIFY_TILES")) {
+    if ((N & 255) == 0 && (ldc & 7) == 0 && Kp <= 1024 && C * H * W < (1LL << 31) && !getenv("ULL_PATCHIFY_TILES")) {
         const int nbn = (int)(N / 256);
         for (const int wmb : {9}) {          // (WMB = 4, 128 x 256 strips for 224^2 at B = 32, measured 20.9 us against 19.6 for the 128x128 form: not used)
             const int tm = 32 * wmb;
@@ -1999,7 +2021,7 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
             a.nbm = (int)(M / tm); a.nbn = nbn;
             static const int raster_env = getenv("ULL_PATCHIFY_XCD") ? atoi(getenv("ULL_PATCHIFY_XCD")) : 1;       // tools: 0 = the old raster
             q.xcd_raster = raster_env && (a.nbm % 8 == 0);
-            const int lds = 2 * (tm + 256) * 128;
+            const int lds = 2 * (tm + 256) * 128 + 256;          // two stages + the segment table
             if (wmb == 9) hipLaunchKernelGGL(big::patchify_strip_kernel<9>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a, q);
             else hipLaunchKernelGGL(big::patchify_strip_kernel<4>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a, q);
             return ull_check_launch();
