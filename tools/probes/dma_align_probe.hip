@@ -1,5 +1,6 @@
 // Does the alignment of the 16-byte lanes of an LDS-DMA request (global_load_lds_dwordx4) change what a CU can pull from the L2?
-// Every wave streams the same 4-MB window (L2-resident) into its own LDS KiB: lane l of request i reads 16 bytes at
+// Every wave streams the same 1-MB window into its own LDS KiB -- the 8 waves of a CU ask for the same lines at about the same time, so
+// this measures the CU's address-coalescing / L1 path (64 B per clock when aligned), not the L2: lane l of request i reads 16 bytes at
 //   base + (i * 64 + l) * STRIDE   with STRIDE = 16 (aligned, contiguous), 32 (aligned, every other chunk) or 28 (the patchify gather: a
 //   patch's 14 bf16 pixels; 4-byte alignment, neighbouring lanes overlap by 4 bytes).
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/dma_align_probe tools/probes/dma_align_probe.hip ; run on the GPU box

@@ -1383,8 +1383,8 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
 // 32-wide K-steps, three steps in flight instead of one: 36.8 us (tools/probes/patchify_bk32_ring_r04.hip.inc) -- the loop does not wait
 // for memory latency; (3) fragment reads software-pipelined in groups of three pixel-row blocks under the previous group's MFMAs:
 // 33.4 us, no change; (4) ablations of the shipped form: without the MFMAs 27.0 us, without any DMA after the first stage 27.8 us.
-// A misaligned 16-byte-lane gather (28-byte lane stride) is not the limit either: it streams 98 GB/s per CU from the L2
-// (tools/probes/dma_align_probe.hip; 140 aligned).  What the ablations leave is the single round itself: launch + per-lane patch
+// A misaligned 16-byte-lane gather (28-byte lane stride) is not the limit either: a CU's address / L1 path takes it at 98 GB/s
+// (tools/probes/dma_align_probe.hip; 140 aligned), three times what the loop asks for.  What the ablations leave is the single round itself: launch + per-lane patch
 // addressing + first stage (~5 us), then all 256 blocks finish together and write 37.7 MB at once (~6 us at the 6.9 TB/s fill rate)
 // with nothing left to overlap it, around a K-loop of ~21 us against 12.7 us of MFMA time.  0.02 % of a C4 step.
 template <int WMB>
