@@ -59,6 +59,9 @@ struct GemmArgs {
     // transformers' apply_rotary_pos_emb with the per-token tables rope_cos / rope_sin [M, 64] (element type, already rounded)
     const elem_t* rope_cos; const elem_t* rope_sin;
     int rope_cols;
+#ifdef ULL_GEMM_STAMPS
+    unsigned long long* stamps;
+#endif
 };
 
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0+1024) (lane-linear).
@@ -669,6 +672,25 @@ __global__ __launch_bounds__(256, 2) void patchify_gemm_kernel(GemmArgs p, Patch
 //     being read from one LDS slot and tile k+2 is being DMA'd into the other: two slots give a prefetch distance of 2.
 //   * two barriers per BK=64 step and a hand-dealt slot schedule (at the loop): one MFMA per slot, the fragment reads and the DMA
 //     pieces of tile k+2 spread between them so that the memory pipe sees an even stream and is never drained.
+#ifdef ULL_GEMM_STAMPS      // debug build only (tools/gemm_tile_phases.py): per-block timestamps of the 4-wave kernel's phases
+unsigned long long* ull_stamp_host_ptr = nullptr;            // set by ull_debug_gemm_stamps_*, copied into GemmArgs::stamps at launch
+ULL_DEV void ull_stamp(unsigned long long* buf, int slot) {
+    if (buf && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) {     // wave 0, every lane the same store (a wave-uniform branch)
+        unsigned long long t = __builtin_amdgcn_s_memrealtime();            // 100 MHz
+        if (slot == 7) {                                                    // where the block ran: XCC id << 32 | HW_ID
+            uint32_t hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(20, 0, 32)" : "=s"(xcc));
+            t = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+        }
+        buf[(size_t)blockIdx.x * 8 + slot] = t;
+    }
+}
+#define ULL_STAMP(slot) ull_stamp(p.stamps, slot)
+#else
+#define ULL_STAMP(slot) ((void)0)
+#endif
+
 namespace big {
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -1069,6 +1091,12 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[NH][4][8], int
                             for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
                             o[h][pp] = pack8(a);
                         }
+                        // (A lane's 16 bytes: four lanes make 64 contiguous bytes per token row, half a 128-byte line; the other half goes
+                        // with the next instruction.  Full-line stores -- 8 rows x 128 B per instruction after a lane-pair exchange -- drain
+                        // a tile in 2.1 instead of 4.4 us per CU (tools/probes/store_pattern_probe.hip), and a timing-only build with that
+                        // address pattern shortened the epilogue from 5.8 to 3.8 us per tile WITHOUT shortening a single launch: these
+                        // launches run against the power cap, and time taken out of a low-power phase comes back as a lower clock in the
+                        // K-loop (docs/experiments.md, round 4).  Not built.)
                         if (m < p.M && nb + h * 64 + pp * 32 + 8 <= p.N) *(uint4*)(cb + (long)m * p.ldc + h * 64 + pp * 32) = o[h][pp];
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1092,6 +1120,7 @@ ULL_DEV void w4_direct_epilogue(const GemmArgs& p, f32x4_t (&acc)[NH][4][8], int
 template <bool SWIGLU, bool ROPE = false>
 __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    ULL_STAMP(0); ULL_STAMP(7);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
@@ -1186,10 +1215,12 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
         xbase += (long)kt0 * xstep; wbase += (long)kt0 * wstep;
         nk = kt1 - kt0;
     }
+    ULL_STAMP(1);                                     // index arithmetic done
     stage_all(0);
     stage_all(1);
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // tile 0 landed, tile 1 in flight
     __builtin_amdgcn_s_barrier();
+    ULL_STAMP(2);                                     // first K-tile in LDS
     Frags4 fa, fb;                                    // fa: half 0 of the current tile, fb: half 1
 #pragma unroll
     for (int c = 0; c < 16; ++c) read_one(0, 0, fa, c);
@@ -1303,6 +1334,7 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
         }
         if (kt == nk - 1) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     }
+    ULL_STAMP(3);                                     // K-loop done
     asm volatile("s_mov_b32 m0, %0" :: "s"(m0_keep) : "memory");   // (the dump's pieces may still be landing: they touch nothing
                                                                     // the epilogue uses, and s_endpgm waits for them)
 
@@ -1329,6 +1361,9 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
                                      ((SWIGLU ? p.N / 2 : p.N) & 7) == 0 && (!(fl & EPI_RESID) || (p.ldr & 7) == 0) && !(fl & ULL_W4_FORCE_STAGED));
         if (direct) {
             w4_direct_epilogue<SWIGLU, ROPE>(p, acc, lane, mrow0, nw0);
+            ULL_STAMP(4);                             // stores issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ULL_STAMP(5);                             // stores retired (this wave's)
             return;
         }
     }
@@ -1874,6 +1909,9 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
     a.ldx = ldx; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags;
     a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.rope_cols = rope_cols;
+#ifdef ULL_GEMM_STAMPS
+    a.stamps = ull_stamp_host_ptr;
+#endif
     const bool rope = rope_cos != nullptr;
     // short K and fewer than two rounds of 256x256 tiles (ViT patchify: K = 640, 128 / 288 tiles): the 128x128 kernel's 4x finer
     // tiles fill the chip better (measured 61 vs 70 us at B=32, 336^2)
@@ -1966,6 +2004,9 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
     return ull_check_launch();
 }
 
+#ifdef ULL_GEMM_STAMPS
+extern "C" int ULL_FN(ull_debug_gemm_stamps_)(void* buf) { ull_stamp_host_ptr = (unsigned long long*)buf; return ULL_OK; }
+#endif
 extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
                              const void* bias, const void* R, int64_t ldr,
                              int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream) {
@@ -2008,6 +2049,9 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
     a.rope_cos = a.rope_sin = nullptr; a.rope_cols = 0;
+#ifdef ULL_GEMM_STAMPS
+    a.stamps = nullptr;
+#endif
     int n_cu = 0;
     if (const int rc = gemm_device_state(&n_cu)) return rc;
     // one round of problem-sized strips when the batch allows it (C4: 32 x 576 patches = 64 strips of 288 x 4 column tiles = 256 blocks)
