@@ -94,13 +94,15 @@ def test_sam_attention_with_tables_of_another_length():
     assert_close_bf16(att2, ref[:S], ulps=2.0, what="window attention entry, resized tables", outlier_frac=2e-3, outlier_floor=vmax)
 
 
-@pytest.mark.parametrize("H,W", [(20, 20), (28, 14), (31, 17)])
-def test_window_attention_on_image_order_tokens(H, W):
+@pytest.mark.parametrize("H,W,B,nH", [(20, 20, 2, 2), (28, 14, 2, 2), (31, 17, 2, 2), (50, 37, 5, 16), (64, 64, 2, 16)])
+def test_window_attention_on_image_order_tokens(H, W, B, nH):
     """ull_sam_window_attention (tokens stay in image order; the kernel does the window addressing, reads the zero-padded positions'
     q|k|v from the qkv bias and V through the transposing LDS load) against window_partition -> qkv Linear -> V^T pass -> attention ->
     window_unpartition with the generic kernels, and against the oracle's Block-level arithmetic."""
+    # (the last two cases give every workgroup of sam_window_kernel a run of several (window, head) items: 960 and 800 items on 256 CUs,
+    # runs that cross from head 15 of one window to head 0 of the next, windows that hang over the right and bottom edges)
     ops = pkg("ops")
-    B, nH, hd, ws = 2, 2, 80, 14
+    hd, ws = 80, 14
     C = nH * hd
     y = _rand(B, H, W, C, seed=31).to(DEV)                      # norm1 output
     w, b = _rand(3 * C, C, seed=32, scale=C ** -0.5).to(DEV), _rand(3 * C, seed=33, scale=0.3).to(DEV)
