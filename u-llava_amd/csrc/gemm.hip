@@ -2055,7 +2055,7 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
     int n_cu = 0;
     if (const int rc = gemm_device_state(&n_cu)) return rc;
     // one round of problem-sized strips when the batch allows it (C4: 32 x 576 patches = 64 strips of 288 x 4 column tiles = 256 blocks)
-    if ((N & 255) == 0 && (ldc & 7) == 0 && Kp <= 1024 && C * H * W < (1LL << 31) && !getenv("ULL_PATCHIFY_TILES")) {
+    if ((N & 255) == 0 && (ldc & 7) == 0 && Kp <= 1024 && C * H * W < (1LL << 31)) {
         const int nbn = (int)(N / 256);
         for (const int wmb : {9}) {          // (WMB = 4, 128 x 256 strips for 224^2 at B = 32, measured 20.9 us against 19.6 for the 128x128 form: not used)
             const int tm = 32 * wmb;
@@ -2063,8 +2063,7 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
             const long tiles = (M / tm) * nbn;
             if (tiles > n_cu || tiles * 2 <= n_cu) continue;
             a.nbm = (int)(M / tm); a.nbn = nbn;
-            static const int raster_env = getenv("ULL_PATCHIFY_XCD") ? atoi(getenv("ULL_PATCHIFY_XCD")) : 1;       // tools: 0 = the old raster
-            q.xcd_raster = raster_env && (a.nbm % 8 == 0);
+            q.xcd_raster = a.nbm % 8 == 0;
             const int lds = 2 * (tm + 256) * 128 + 256;          // two stages + the segment table
             if (wmb == 9) hipLaunchKernelGGL(big::patchify_strip_kernel<9>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a, q);
             else hipLaunchKernelGGL(big::patchify_strip_kernel<4>, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, a, q);
