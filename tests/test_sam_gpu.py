@@ -134,6 +134,24 @@ def test_window_attention_on_image_order_tokens(H, W, B, nH):
     assert_close_bf16(got, o, ulps=2.0, what="window attention on image-order tokens", outlier_frac=2e-3, outlier_floor=vmax)
 
 
+@pytest.mark.parametrize("dt", [BF, torch.float16])
+def test_window_attention_is_batch_independent_bit_for_bit(dt):
+    """sam_window_kernel walks runs of (window, head) items, one workgroup per CU: which workgroup computes an item, and next to which
+    other items, depends on the batch.  The result must not: image b of a batch of 6 equals the single-image call bit for bit
+    (6 x 16 windows x 16 heads = 1536 items: six per workgroup; 1 x 256 items: one per workgroup)."""
+    ops = pkg("ops")
+    B, H, W, nH, hd, ws = 6, 50, 45, 16, 80, 14
+    C = nH * hd
+    qkv = _rand(B * H * W, 3 * C, seed=61).to(dt).to(DEV)
+    b = _rand(3 * C, seed=62, scale=0.3).to(dt).to(DEV)
+    rph, rpw = _rand(27, hd, seed=63, scale=0.3).to(dt).to(DEV), _rand(27, hd, seed=64, scale=0.3).to(dt).to(DEV)
+    full = ops.sam_window_attention(qkv, b, rph, rpw, B, H, W, nH, hd, ws)
+    assert bool(torch.isfinite(full.float()).all())
+    for i in (0, 3, 5):
+        one = ops.sam_window_attention(qkv[i * H * W:(i + 1) * H * W].contiguous(), b, rph, rpw, 1, H, W, nH, hd, ws)
+        assert torch.equal(one.view(torch.int16), full[i * H * W:(i + 1) * H * W].view(torch.int16)), f"image {i}"
+
+
 @pytest.mark.parametrize("side,hd,nH,NB", [(14, 80, 2, 3), (64, 80, 2, 1), (64, 32, 2, 1)])
 def test_sam_encoder_attention(side, hd, nH, NB):
     """windowed (196 keys, register kernel + bias) and global (4096 keys, single-pass streaming kernel + bias) SAM attention.
