@@ -223,6 +223,15 @@ int ull_interp_rows_linear_bf16(const void* x, void* y, int64_t L, int64_t M, in
  * nn.GELU that follows it in mask_decoder.py:53-64 output_upscaling. */
 int ull_layernorm2d_cl_bf16(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu, void* stream);
 
+/* image_encoder.py:117-124 ("prevent overflow"): an fp16 model runs the neck under torch.autocast(float32), so the neck's two LayerNorm2d
+ * (common.py:31-43) see fp32 convolution outputs and compute in fp32 with their fp16 weight / bias promoted.  fp16 build only (a bf16 model
+ * goes straight through ull_layernorm2d_cl_bf16).  x[row] = xa[row] + xb[row] * xb_scale (xb may be null): fp32 channels-last rows [rows, C];
+ * y = w * ((x - mean) / sqrt(var + eps)) + b in fp32.  y_lo == null: y_hi = fp16(y), the `.to(float16)` that ends the neck.  y_lo != null:
+ * y_hi = fp16(y), y_lo = fp16((y - y_hi) * 2^11): the two-term split that lets the following 3x3 convolution run as fp16 GEMMs with fp32
+ * accumulation on an fp32-accurate input, conv(y) = conv(y_hi) + 2^-11 conv(y_lo). */
+int ull_neck_layernorm2d_f32in_f16(const void* xa, const void* xb, float xb_scale, const void* w, const void* b, void* y_hi, void* y_lo,
+                                   int64_t rows, int64_t C, float eps, void* stream);
+
 /* image_encoder.py:100-106 neck Conv2d(k=3, padding=1): x [B,H,W,C] -> cols [B*H*W, 9*C] in (ky,kx,ci) order. */
 int ull_im2col3x3_bf16(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 

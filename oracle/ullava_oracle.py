@@ -376,7 +376,8 @@ def sam_attention(sd, p: str, x: Tensor, n_heads: int) -> Tensor:
 
 
 def sam_image_encoder(sd, scfg: dict, x: Tensor, pfx: str = "visual_model.image_encoder.", trace: Optional[dict] = None) -> Tensor:
-    """ImageEncoderViT.forward (image_encoder.py:110-125); bf16/fp32 go straight through the neck.
+    """ImageEncoderViT.forward (image_encoder.py:110-125); the neck of an fp16 model runs in fp32 (:117-124), bf16/fp32 go
+    straight through it.
     trace: optional dict receiving the stage outputs ([B, H, W, C] after the patch embedding and after every block)."""
     ps = scfg["patch_size"]
     x = F.conv2d(x, sd[pfx + "patch_embed.proj.weight"], sd[pfx + "patch_embed.proj.bias"], stride=ps).permute(0, 2, 3, 1)
@@ -402,11 +403,18 @@ def sam_image_encoder(sd, scfg: dict, x: Tensor, pfx: str = "visual_model.image_
         if trace is not None:
             trace[f"block{i}"] = x
     x = x.permute(0, 3, 1, 2)
-    x = F.conv2d(x, sd[pfx + "neck.0.weight"])
-    x = layer_norm_2d(x, sd[pfx + "neck.1.weight"], sd[pfx + "neck.1.bias"])
-    x = F.conv2d(x, sd[pfx + "neck.2.weight"], padding=1)
-    x = layer_norm_2d(x, sd[pfx + "neck.3.weight"], sd[pfx + "neck.3.bias"])
-    return x
+    dtype = x.dtype
+    # image_encoder.py:117-124: an fp16 model runs the neck under torch.autocast("cuda", dtype=float32) ("prevent overflow"):
+    # both convolutions get fp32 casts of their input and of their fp16-valued weights, LayerNorm2d's arithmetic promotes
+    # (fp16 weight * fp32 tensor -> fp32), and only the neck's result is cast back to fp16.  bf16 / fp32 go straight through.
+    # (The pinned torch==1.13.1 honours fast_dtype=float32; torch >= 2.x warns "target dtype is not supported" and disables
+    # the context, and a CPU-only host disables it as well -- the oracle restates the branch the reference's authors ran.)
+    up = (lambda t: t.float()) if dtype == torch.float16 else (lambda t: t)
+    x = F.conv2d(up(x), up(sd[pfx + "neck.0.weight"]))
+    x = layer_norm_2d(x, up(sd[pfx + "neck.1.weight"]), up(sd[pfx + "neck.1.bias"]))
+    x = F.conv2d(x, up(sd[pfx + "neck.2.weight"]), padding=1)
+    x = layer_norm_2d(x, up(sd[pfx + "neck.3.weight"]), up(sd[pfx + "neck.3.bias"]))
+    return x.to(dtype)
 
 
 # --------------------------------------------------------------------------- #

@@ -124,7 +124,8 @@ def _compact(o):
 
 def save(name, obj):
     obj = _compact(obj)
-    obj["meta"] = dict(META)
+    obj["meta"] = dict(META, **META_EXTRA)
+    META_EXTRA.clear()
     path = os.path.join(OUT, name)
     torch.save(obj, path)
     print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
@@ -302,6 +303,33 @@ SAM_TINY = dict(embed_dim=64, depth=2, num_heads=2, global_attn_indexes=[1], win
                 out_chans=256)
 
 
+class _AutocastFp32Neck(torch.nn.Module):
+    """What `with torch.autocast(device_type="cuda", dtype=torch.float32): x = self.neck(x)` computes on the authors' GPUs
+    (image_encoder.py:117-124), built from the reference's OWN neck modules: autocast hands both convolutions fp32 casts of their
+    input and of their fp16 weights, and LayerNorm2d's `weight * x` promotes to fp32 -- i.e. a deep copy of the fp16 neck with its
+    (fp16-valued) parameters promoted, applied to x.float().  The reference's forward then does `x.to(dtype)` itself.
+    Needed because this container has no GPU: the context manager prints "CUDA is not available ... Disabling autocast" and the
+    branch would silently run in fp16 (torch >= 2.x disables fast_dtype=float32 on a GPU too; the pinned torch==1.13.1 does not)."""
+
+    def __init__(self, neck16):
+        super().__init__()
+        import copy
+        self.neck32 = copy.deepcopy(neck16).float()
+
+    def forward(self, x):
+        return self.neck32(x.float())
+
+
+def _emulate_fp16_neck_autocast(image_encoder):
+    assert next(image_encoder.neck.parameters()).dtype == torch.float16
+    image_encoder.neck = _AutocastFp32Neck(image_encoder.neck)
+    META_EXTRA["fp16_neck"] = ("autocast(cuda, float32) branch of image_encoder.py:117-124 EMULATED on CPU with the reference's own "
+                               "neck modules promoted to fp32 (copy.deepcopy(neck).float()(x.float()).half())")
+
+
+META_EXTRA = {}
+
+
 def _full_setup(dtype, seed):
     """tiny UllavaForCausalLM (shrunk SAM encoder) + a 2-sample batch: sample 0 has two [SEG] + one [LOC], sample 1 one [SEG] + two [LOC]."""
     from models.segment_anything.build_sam import _build_sam
@@ -321,6 +349,8 @@ def _full_setup(dtype, seed):
     m = UllavaForCausalLM(cfg).eval()
     assert m.llm.config._attn_implementation == "eager" and m.llm.vision_encoder.config._attn_implementation == "eager"
     shapes, sd = load_seeded(m, seed, dtype)
+    if dtype == torch.float16:
+        _emulate_fp16_neck_autocast(m.visual_model.image_encoder)
     # sample 0: two [SEG] + one [LOC]; sample 1: one [SEG], two [LOC], right padded
     a = [1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * 4 + [MM["IMG_END"], 11, 12, SEG, 13, LOC, 14, 15, SEG, 16]
     b = [1, MM["IMG_START"]] + [MM["IMG_PATCH"]] * 4 + [MM["IMG_END"], 21, LOC, SEG, 22, LOC]

@@ -242,3 +242,88 @@ def test_core_forward_fp16_vs_oracle_and_greedy_ids():
         seq = model.generate(input_ids=fx["greedy_prompt"].to(DEV), images=images[:1].to(DEV), max_new_tokens=8, do_sample=False,
                              use_cache=use_cache, eos_token_id=-1)
         assert torch.equal(seq.cpu(), seq_ref), (use_cache, seq.tolist(), seq_ref.tolist())
+
+
+def test_neck_layernorm2d_fp32_kernel():
+    """ull_neck_layernorm2d_f32in_f16 (image_encoder.py:117-124 + common.py:31-43 in fp32): the final form rounds the fp32 result once;
+    the split form carries the fp32 result in two fp16 terms to ~2^-22; rows whose values would overflow an fp16 LayerNorm2d's
+    (x - u)^2 (|x - u| > 256) are ordinary numbers here."""
+    ops = pkg("ops")
+    g = torch.Generator().manual_seed(5)
+    rows, C = 1000, 256
+    xa = torch.randn(rows, C, generator=g) * torch.logspace(-2, 5, rows)[:, None]           # row scales 1e-2 .. 1e5
+    xb = torch.randn(rows, C, generator=g) * torch.logspace(-2, 5, rows)[:, None]
+    w, b = (torch.randn(C, generator=g) * 0.2 + 1.0).to(H), (torch.randn(C, generator=g) * 0.2).to(H)
+
+    def ref(x):
+        return O.layer_norm_2d(x.t().reshape(1, C, rows, 1), w.float(), b.float()).reshape(C, rows).t()
+    y1 = ref(xa)
+    got = ops.neck_layernorm2d_f32(xa.to(DEV), None, 0.0, w.to(DEV), b.to(DEV), 1e-6, split=False).cpu()
+    assert got.dtype == H and bool(torch.isfinite(got.float()).all())
+    flips = got != y1.to(H)
+    assert float(flips.float().mean()) < 2e-3, float(flips.float().mean())                  # fp32 summation order: rare 1-ulp flips only
+    assert_close_f16(got, y1.to(H), ulps=1.0, what="neck LN2d fp32 -> fp16")
+    y2 = ref(xa + xb * 2.0 ** -11)
+    hl = ops.neck_layernorm2d_f32(xa.to(DEV), xb.to(DEV), 2.0 ** -11, w.to(DEV), b.to(DEV), 1e-6, split=True).cpu()
+    assert hl.shape == (2, rows, C)
+    rec = hl[0].double() + hl[1].double() * 2.0 ** -11
+    err = float((rec - y2.double()).abs().max() / y2.double().abs().max())
+    print("split LN2d: max error of hi + 2^-11 lo vs fp32", err)
+    assert err < 2e-6
+    assert torch.equal(hl[0], ops.neck_layernorm2d_f32((xa + xb * 2.0 ** -11).to(DEV), None, 0.0, w.to(DEV), b.to(DEV), 1e-6, split=False).cpu())
+
+
+def _g8_model_and_inputs(fx, sd):
+    C, M = pkg("configuration"), pkg("modeling_ullava")
+    cfg, cd = fx["cfg"], fx["cfg"]["llm"]
+    ucfg = C.UllavaConfig(llm_config=dict(vision_config=cd["vision_config"], vision_hidden_layer=cd["vision_hidden_layer"],
+                                          projector_type="mlp", projector_from_scratch=bool(cd.get("projector_from_scratch", False)),
+                                          mm_token_ids=cd["mm_token_ids"], vocab_size=cd["vocab_size"],
+                                          hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
+                                          num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"]),
+                            seg_token_idx=cfg["seg_token_idx"], loc_token_idx=cfg["loc_token_idx"], sam_config=dict(cfg["sam"]))
+    model = M.UllavaForCausalLM(ucfg, device=DEV, dtype=H)
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(H)
+    return model, images_sam
+
+
+def test_fp16_neck_runs_in_fp32_where_an_fp16_neck_overflows():
+    """image_encoder.py:117-124 "prevent overflow": with neck.0.weight scaled so that the 1x1 convolution's output reaches ~4e5, an
+    fp16 neck produces inf (conv) -> nan (LayerNorm2d) and the whole mask path is lost; the reference's autocast(float32) branch -- and
+    the HIP fp16 build -- keep it finite: masks equal the oracle's (fp32 neck) to the G8 tolerance."""
+    fx = load_fixture("g8_full_tiny_fp16.pt")
+    sd = fixture_sd(fx, H)
+    pfx = "visual_model.image_encoder."
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(H)
+    tr = {}
+    O.sam_image_encoder(sd, fx["cfg"]["sam"], images_sam, trace=tr)
+    h = tr[f"block{fx['cfg']['sam']['depth'] - 1}"].permute(0, 3, 1, 2)
+    c0 = F.conv2d(h.float(), sd[pfx + "neck.0.weight"].float())
+    scale = 2.0 ** math.ceil(math.log2(4e5 / float(c0.abs().max())))                      # power of two: the scaled fp16 weights stay exact
+    w_big = sd[pfx + "neck.0.weight"].float() * scale
+    assert float(w_big.abs().max()) < 6e4
+    sd[pfx + "neck.0.weight"] = w_big.to(H)
+    assert not bool(torch.isfinite(F.conv2d(h, sd[pfx + "neck.0.weight"]).float()).all()), "the case must overflow an fp16 neck"
+    emb = O.sam_image_encoder(sd, fx["cfg"]["sam"], images_sam)
+    assert emb.dtype == H and bool(torch.isfinite(emb.float()).all())
+    o = O.ullava_forward(sd, fx["cfg"], images_sam, fx["images"], fx["input_ids"], fx["attention_mask"], fx["size_list"], fx["resize_list"])
+    model, _ = _g8_model_and_inputs(fx, sd)
+    eng_emb = model._sam.encode(images_sam.to(DEV))
+    out = model(images_sam=images_sam.to(DEV), images=fx["images"].to(DEV), input_ids=fx["input_ids"].to(DEV), labels=None,
+                attention_mask=fx["attention_mask"].to(DEV), mask_list=[None, None], size_list=fx["size_list"],
+                resize_list=fx["resize_list"], bbox_list=[None, None], inference=True)
+    ee = rel_err(eng_emb.view(2, 64, 64, -1).permute(0, 3, 1, 2), emb)
+    print("fp16 model, fp32 neck: image embedding err vs oracle", ee)
+    assert ee < 4e-3
+    for i in range(2):
+        pm = out["pred_masks"][i].cpu()
+        assert bool(torch.isfinite(pm).all()), "masks must stay finite"
+        em = float((pm - o["pred_masks"][i]).abs().max()) / float(o["low_res_masks"][i].float().abs().max())
+        print(f"overflow case, sample {i}: mask err vs oracle {em:.2e}")
+        RESULTS.append(dict(test="fp16_neck_overflow_case", sample=i, mask_vs_oracle=em, neck0_scale=scale))
+        assert em <= 4e-3

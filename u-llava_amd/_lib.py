@@ -90,6 +90,9 @@ SIGNATURES = {
 # every dtype-dependent entry point exists twice: ull_*_bf16 (bfloat16 build) and ull_*_f16 (IEEE binary16 build), same signature
 SIGNATURES.update({name[:-4] + "f16": args for name, args in list(SIGNATURES.items()) if name.endswith("_bf16")})
 
+# fp16-only entry points (no bf16 twin): the fp32 neck of an fp16 SAM encoder (image_encoder.py:117-124)
+SIGNATURES["ull_neck_layernorm2d_f32in_f16"] = [_ptr, _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr]
+
 VALUE_RETURNING = {"ull_gemm_streamk_ws_bytes": _i64}      # plain queries: the return value is the answer, not a status
 
 ERRORS = {-1: "ULL_ERR_ARG (null pointer / bad size)", -2: "ULL_ERR_SHAPE (alignment or shape constraint)",

@@ -114,6 +114,64 @@ __global__ __launch_bounds__(256) void layernorm2d_cl_kernel(const elem_t* __res
     *(uint4*)(y + row * C + sub * 8) = pack8(o);
 }
 
+#ifdef ULL_ELEM_F16
+// image_encoder.py:117-124: an fp16 model runs its neck under autocast(float32) -- LayerNorm2d (common.py:31-43) then sees the fp32
+// output of a convolution and promotes: everything below is fp32 arithmetic in the reference's order (u = mean(x); d = x - u;
+// s = mean(d*d); y = w * (d / sqrt(s + eps)) + b with the fp16 w / b promoted), separate multiply and add (no contraction).
+//   x[row] = xa[row] (+ xb[row] * xb_scale when xb != null): fp32 channels-last rows (xb: the second term of the split GEMM below).
+//   y_lo == null: y_hi[row] = fp16(y)                       -- the `x.to(float16)` that ends the neck.
+//   y_lo != null: y_hi = fp16(y), y_lo = fp16((y - y_hi) * 2^11) -- a two-term fp16 split of the fp32 activations (22 significand
+//                 bits), so that the 3x3 convolution that follows can run as fp16 MFMA GEMMs on both terms with fp32 accumulation and
+//                 still see its fp32 input: conv(y) = conv(y_hi) + 2^-11 conv(y_lo); the weights are fp16 values, exact in either.
+// One row per `lpr` lanes, 8 channels per lane (C <= 512, C % 8 == 0).
+__global__ __launch_bounds__(256) void neck_ln2d_f32_kernel(const float* __restrict__ xa, const float* __restrict__ xb, float xb_scale,
+                                                            const elem_t* __restrict__ w, const elem_t* __restrict__ b,
+                                                            elem_t* __restrict__ y_hi, elem_t* __restrict__ y_lo, long rows, int C, float eps,
+                                                            int lpr) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (lpr - 1);
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / lpr) + lane / lpr;
+    const bool ok = row < rows && sub * 8 < C;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    if (ok) {
+        const float4 a0 = *(const float4*)(xa + row * C + sub * 8), a1 = *(const float4*)(xa + row * C + sub * 8 + 4);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        if (xb) {
+            const float4 b0 = *(const float4*)(xb + row * C + sub * 8), b1 = *(const float4*)(xb + row * C + sub * 8 + 4);
+            const float t[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __fadd_rn(v[j], __fmul_rn(t[j], xb_scale));   // 2^-11 scaling is exact
+        }
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1 += v[j];
+    const float u = group_sum(s1, lpr) / (float)C;
+    float d[8], s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        d[j] = ok ? v[j] - u : 0.f;
+        s2 = __fadd_rn(s2, __fmul_rn(d[j], d[j]));
+    }
+    const float var = group_sum(s2, lpr) / (float)C;
+    const float den = __fsqrt_rn(var + eps);
+    if (!ok) return;
+    float wv[8], bv[8], hi[8], lo[8];
+    unpack8(*(const uint4*)(w + sub * 8), wv);
+    unpack8(*(const uint4*)(b + sub * 8), bv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float y = __fadd_rn(__fmul_rn(wv[j], __fdiv_rn(d[j], den)), bv[j]);
+        hi[j] = rnd(y);
+        lo[j] = (y - hi[j]) * 2048.0f;
+    }
+    *(uint4*)(y_hi + row * C + sub * 8) = pack8(hi);
+    if (y_lo) *(uint4*)(y_lo + row * C + sub * 8) = pack8(lo);
+}
+#endif
+
 // x [B, H, W, C] channels-last -> cols [B*H*W, 9*C], column block (ky*3+kx) holds the C channels of the neighbour
 // (y+ky-1, x+kx-1), zeros outside the image (conv padding=1).  Weight is packed host-side in the same (ky,kx,ci) order.
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const elem_t* __restrict__ x, elem_t* __restrict__ out, int H, int W, int C,
@@ -257,6 +315,21 @@ extern "C" int ULL_FN(ull_layernorm2d_cl_)(const void* x, const void* w, const v
                        (const elem_t*)x, (const elem_t*)w, (const elem_t*)b, (elem_t*)y, rows, (int)C, eps, lpr, gelu);
     return ull_check_launch();
 }
+
+#ifdef ULL_ELEM_F16
+extern "C" int ull_neck_layernorm2d_f32in_f16(const void* xa, const void* xb, float xb_scale, const void* w, const void* b, void* y_hi, void* y_lo,
+                                              int64_t rows, int64_t C, float eps, void* stream) {
+    if (!xa || !w || !b || !y_hi || rows <= 0) return ULL_ERR_ARG;
+    if ((C & 7) || C > 512) return ULL_ERR_SHAPE;
+    int lpr = 1;
+    while (lpr < (C >> 3)) lpr <<= 1;
+    const long rows_per_block = 4 * (64 / lpr);
+    hipLaunchKernelGGL(neck_ln2d_f32_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)xa, (const float*)xb, xb_scale, (const elem_t*)w, (const elem_t*)b, (elem_t*)y_hi, (elem_t*)y_lo, rows, (int)C,
+                       eps, lpr);
+    return ull_check_launch();
+}
+#endif
 
 extern "C" int ULL_FN(ull_im2col3x3_)(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
     if (!x || !out || B <= 0) return ULL_ERR_ARG;

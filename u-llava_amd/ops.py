@@ -612,6 +612,21 @@ def layernorm2d_cl(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float
     return out
 
 
+def neck_layernorm2d_f32(xa: torch.Tensor, xb: Optional[torch.Tensor], xb_scale: float, w: torch.Tensor, b: torch.Tensor, eps: float,
+                         split: bool) -> torch.Tensor:
+    """LayerNorm2d of the fp16 model's fp32 neck (image_encoder.py:117-124): fp32 rows xa (+ xb * xb_scale) -> fp16.
+    split=False: [rows, C] = fp16(y).  split=True: [2, rows, C] = (fp16(y), fp16((y - fp16(y)) * 2^11)), the two-term image of y."""
+    _chk(xa, "xa", torch.float32); _chk(w, "w", torch.float16); _chk(b, "b", torch.float16)
+    C = xa.shape[-1]
+    rows = xa.numel() // C
+    if not xa.is_contiguous() or (xb is not None and (not xb.is_contiguous() or xb.shape != xa.shape or xb.dtype != torch.float32)):
+        raise RuntimeError("u-llava_amd.neck_layernorm2d_f32: xa / xb must be contiguous fp32 rows of the same shape")
+    out = torch.empty((2, rows, C) if split else (rows, C), device=xa.device, dtype=torch.float16)
+    _lib.call("ull_neck_layernorm2d_f32in_f16", _p(xa), _p(xb), float(xb_scale), _p(w), _p(b), _p(out), _p(out[1]) if split else None, rows, C,
+              float(eps), _stream())
+    return out
+
+
 def im2col3x3(x: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
     _chk(x, "x")
     C = x.shape[-1]

@@ -213,6 +213,17 @@ class SamEngine:
             x = ops.linear(f, blk.mlp.lin2.weight, blk.mlp.lin2.bias, residual=x)
             if trace is not None:
                 trace[f"block{i}"] = x.view(B, g, g, C)
+        if x.dtype == torch.float16:
+            # image_encoder.py:117-124: the fp16 model's neck runs in fp32 ("prevent overflow") and only its result is cast back.
+            # 1x1 conv: fp16 MFMA products are exact in fp32, fp32 accumulators written out unrounded; LayerNorm2d in fp32; the 3x3
+            # conv sees its fp32 input as a two-term fp16 split (hi + 2^-11 lo, 22 significand bits) stacked as 2B images: one GEMM,
+            # fp32 out, the halves recombined by the last LayerNorm2d, which also does the `.to(float16)`.
+            T = x.shape[0]
+            x32 = ops.linear(x, pk["neck0"], out_f32=True)
+            hl = ops.neck_layernorm2d_f32(x32, None, 0.0, enc.neck[1].weight, enc.neck[1].bias, 1e-6, split=True)
+            o = ops.linear(ops.im2col3x3(hl.view(2 * T, -1), 2 * B, g, g), pk["neck2"], out_f32=True)
+            x = ops.neck_layernorm2d_f32(o[:T], o[T:], 2.0 ** -11, enc.neck[3].weight, enc.neck[3].bias, 1e-6, split=False)
+            return x.view(B, g * g, cfg.out_chans)
         x = ops.linear(x, pk["neck0"])
         x = ops.layernorm2d_cl(x, enc.neck[1].weight, enc.neck[1].bias, 1e-6)
         x = ops.linear(ops.im2col3x3(x, B, g, g), pk["neck2"])
