@@ -268,11 +268,17 @@ def test_lora_adapter_is_merged_at_load(tmp_path):
             mod = f"model.layers.{li}.self_attn.{name}"
             w = dict(base.named_modules())[mod].weight
             A, B = torch.randn(r, w.shape[1], generator=g) * 0.1, torch.randn(w.shape[0], r, generator=g) * 0.1
-            sd[f"base_model.model.{mod}.lora_A.weight"] = A.to(w.dtype)
-            sd[f"base_model.model.{mod}.lora_B.weight"] = B.to(w.dtype)
-            # PEFT 0.4.0 Linear.merge in the weights' dtype: 16-bit product, 16-bit scaling, 16-bit sum (checkpoint.lora_merged_weight)
-            delta = ((B.to(w.dtype).float() @ A.to(w.dtype).float()).to(w.dtype).float() * (alpha / r)).to(w.dtype)
-            want[mod] = (w.detach().float() + delta.float()).to(w.dtype)
+            if name == "q_proj":
+                # adapter stored in fp32 (what PEFT 0.4.0 creates and the reference's training saves): fp32 delta, ONE rounding in `weight.data +=`
+                sd[f"base_model.model.{mod}.lora_A.weight"] = A
+                sd[f"base_model.model.{mod}.lora_B.weight"] = B
+                want[mod] = (w.detach().float() + (B @ A) * (alpha / r)).to(w.dtype)
+            else:
+                # adapter cast to the weights' 16-bit dtype: 16-bit product, 16-bit scaling, 16-bit sum (checkpoint.lora_merged_weight)
+                sd[f"base_model.model.{mod}.lora_A.weight"] = A.to(w.dtype)
+                sd[f"base_model.model.{mod}.lora_B.weight"] = B.to(w.dtype)
+                delta = ((B.to(w.dtype).float() @ A.to(w.dtype).float()).to(w.dtype).float() * (alpha / r)).to(w.dtype)
+                want[mod] = (w.detach().float() + delta.float()).to(w.dtype)
     assert not CK.has_lora_adapter(d)
     save_file(sd, os.path.join(d, "adapter_model.safetensors"))
     json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "target_modules": ["q_proj", "v_proj"], "fan_in_fan_out": False},
@@ -370,6 +376,36 @@ def test_hf_trainer_constructs_optimises_and_saves_the_shim_model(tmp_path):
     before = m.llm.model.layers[0].self_attn._qkv_pack[:64].clone()
     opt.step()
     assert not torch.equal(m.llm.model.layers[0].self_attn._qkv_pack[:64], before) and torch.equal(m.llm.model.layers[0].self_attn._qkv_pack[:64], q.data)
+
+
+def test_alias_pack_leaves_externally_owned_parameters_alone():
+    """DeepSpeed ZeRO-1/2 / FSDP bind p.data to their flat buffer BEFORE the first training forward (HF Trainer wraps first): the first
+    _alias_pack call must see that the parameters are views into somebody else's storage, mark the holder and never rebind -- the
+    owner's in-place updates of its flat buffer stay visible through the parameters."""
+    M_ = pkg("modeling_core")
+    holder = torch.nn.Module()
+    names = ("q_proj", "k_proj", "v_proj")
+    for n_ in names:
+        setattr(holder, n_, M_.Linear(8, 16, bias=False, device="cpu", dtype=torch.bfloat16))
+    flat = torch.arange(3 * 16 * 8 + 5, dtype=torch.float32).to(torch.bfloat16)          # the owner's flat partition (with its own padding)
+    o = 5
+    for n_ in names:
+        w = getattr(holder, n_).weight
+        w.data = flat[o:o + w.numel()].view_as(w)
+        o += w.numel()
+    packed, ws = M_.UllavaCoreForCausalLM._alias_pack(holder, names, "_qkv_pack")
+    assert packed is None and holder._qkv_pack_external is True
+    assert all(w.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for w in ws)
+    flat.add_(1.0)                                                                      # the owner's optimizer step
+    assert torch.equal(holder.k_proj.weight.data.reshape(-1), flat[5 + 128:5 + 256])
+    assert M_.UllavaCoreForCausalLM._alias_pack(holder, names, "_qkv_pack")[0] is None    # and it stays that way
+    # parameters that own their storage are aliased as before
+    h2 = torch.nn.Module()
+    for n_ in names:
+        setattr(h2, n_, M_.Linear(8, 16, bias=False, device="cpu", dtype=torch.bfloat16))
+        getattr(h2, n_).weight.data.normal_()
+    p2, w2 = M_.UllavaCoreForCausalLM._alias_pack(h2, names, "_qkv_pack")
+    assert p2 is not None and w2[2].data_ptr() == p2.data_ptr() + 32 * 8 * 2
 
 
 REFERENCE = "/root/reference"

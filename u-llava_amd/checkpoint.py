@@ -218,16 +218,22 @@ def ullava_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict
 # adapter is MERGED into the base weights at load time instead: W += (lora_alpha / r) * B @ A for every target module -- what
 # `PeftModel.merge_and_unload()` leaves behind.  Reads the files PEFT writes (adapter_config.json + adapter_model.safetensors / .bin,
 # keys `base_model.model.<module path>.lora_A[.<adapter>].weight` [r, in] and `.lora_B[...].weight` [out, r]).  Host-side weight
-# preparation like the rest of this file, with PEFT's own rounding points (lora_merged_weight).
+# preparation like the rest of this file, with PEFT's own rounding points for the adapter's stored dtype (lora_merged_weight).
 def lora_merged_weight(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float) -> torch.Tensor:
     """PEFT 0.4.0 (the reference's pin, shells/requirements.txt:25) tuners/lora.py `Linear.merge`:
-    `self.weight.data += (lora_B.weight @ lora_A.weight) * scaling`, every operand in the weights' 16-bit dtype -- so the product B A is
-    rounded to 16 bits (fp32 accumulation over r), the scaling rounds again, the sum a third time.  Restated with those three roundings
-    (weight preparation, not the forward path: torch fp32 arithmetic, rounded where PEFT's tensors are 16-bit)."""
+    `self.weight.data += (lora_B.weight @ lora_A.weight) * scaling`, evaluated in the dtypes PEFT's tensors have.  PEFT creates lora_A /
+    lora_B as default-dtype (fp32) nn.Linear and only moves them to the device, and adapter files written by the reference's training
+    hold fp32 tensors: the delta is then an fp32 matrix and the in-place add rounds ONCE, to the weight's 16-bit dtype.  An adapter that
+    was itself cast to 16 bits (model.half() after get_peft_model) gives three roundings: the product B A (fp32 accumulation over r),
+    the scaling, the sum.  The rounding points follow the adapter tensors' stored dtype (weight preparation, not the forward path)."""
     dt = w.dtype
-    d = (B.detach().float() @ A.detach().float()).to(dt)
-    d = (d.float() * float(scaling)).to(dt)
-    return (w.detach().float() + d.float().to(w.device)).to(dt)
+    adt = torch.promote_types(A.dtype, B.dtype)
+    d = B.detach().float() @ A.detach().float()
+    if adt in (torch.float16, torch.bfloat16):
+        d = (d.to(adt).float() * float(scaling)).to(adt).float()
+    else:
+        d = d * float(scaling)
+    return (w.detach().float() + d.to(w.device)).to(dt)
 
 
 def has_lora_adapter(path: str) -> bool:
@@ -275,7 +281,7 @@ def merge_lora_adapter(llm: torch.nn.Module, path: str, adapter_name: str = "def
                 raise NotImplementedError("fan_in_fan_out adapters (Conv1D targets) do not occur on this path: every target is an nn.Linear")
             if (B.shape[0], A.shape[1]) != tuple(w.shape):
                 raise RuntimeError(f"u-llava_amd: adapter delta {(B.shape[0], A.shape[1])} does not fit {mod}.weight {tuple(w.shape)}")
-            w.copy_(lora_merged_weight(w.detach().cpu(), A.to(w.dtype), B.to(w.dtype), alpha / r).to(w.device))
+            w.copy_(lora_merged_weight(w.detach().cpu(), A, B, alpha / r).to(w.device))      # rounding points by the adapter's stored dtype
             merged.append(mod)
     if hasattr(llm, "_packed"):
         llm._packed = None                                   # fused q|k|v / tile-major copies describe the old weights

@@ -724,8 +724,8 @@ __global__ __launch_bounds__(SW_NWV * 64) void sam_window_kernel(AttnArgs p, int
     elem_t* tabs = biasb + NWV * 16 * BP;             // [2][27][80]: rel_pos_h, rel_pos_w
     elem_t* brow = biasb + (wave * 16 + fr) * BP;     // this lane's query's bias row (the wave's 16 rows are private to it)
 
-    int item = (int)((uint32_t)blockIdx.x * (uint32_t)n_items / gridDim.x);
-    const int last = (int)((uint32_t)(blockIdx.x + 1) * (uint32_t)n_items / gridDim.x);
+    int item = (int)((uint64_t)blockIdx.x * (uint64_t)n_items / gridDim.x);            // 64-bit: blockIdx * n_items passes 2^32 from 2^24 items on
+    const int last = (int)((uint64_t)(blockIdx.x + 1) * (uint64_t)n_items / gridDim.x);
     if (item >= last) return;
 
     // ---- per-lane state ---------------------------------------------------------------------------------------------------------------

@@ -629,7 +629,8 @@ class UllavaCoreForCausalLM(nn.Module):
         state-dict entries unchanged) and return (that buffer, the parameters).
 
         The aliasing is established ONCE per holder (and again after .to() / .half(), which re-create every parameter: _apply clears the
-        slots).  If it is found broken later -- a parameter's `.data` no longer points into the buffer -- somebody else has taken
+        slots) -- and only if every parameter still owns its storage at that moment.  If a parameter is a view into somebody's flat
+        buffer already, or the aliasing is found broken later -- a parameter's `.data` no longer points into the buffer -- somebody else has taken
         ownership of the parameter storage (DeepSpeed ZeRO-1/2 rebinds p.data to its flat bit16 partition, FSDP to its flat parameter):
         rebinding `.data` again would detach the parameters from that owner and its updates would never be seen.  The holder is then
         marked and this function returns (None, params): the caller concatenates the live parameters under autograd instead (one
@@ -648,6 +649,12 @@ class UllavaCoreForCausalLM(nn.Module):
                 return packed, ws
             object.__setattr__(holder, slot, None)
             object.__setattr__(holder, slot + "_external", True)          # storage re-bound by an external owner: leave it alone
+            return None, ws
+        # First call on this holder.  A parameter that is already a VIEW into a larger storage has an owner: deepspeed.initialize
+        # (ZeRO-1/2: p.data = a slice of the flat bit16 group) or an FSDP wrap (flat parameter) ran before the first training forward --
+        # the order HF Trainer uses.  Taking the storage away here would leave the owner updating a buffer nobody reads.
+        if any(w.storage_offset() != 0 or w.untyped_storage().nbytes() > w.numel() * w.element_size() + 64 for w in ws):
+            object.__setattr__(holder, slot + "_external", True)
             return None, ws
         with torch.no_grad():
             packed = torch.cat([w.data for w in ws], dim=0).contiguous()

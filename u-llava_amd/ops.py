@@ -106,7 +106,9 @@ def _tiled_of(w: torch.Tensor):
         _TILED.pop(w.data_ptr(), None)       # the address was recycled by another tensor
         return None
     if e[2] != w._version:
-        e[1].copy_(tile_major(w.detach()))
+        # a NEW tensor, not copy_: a copy first made under torch.inference_mode() (the reference wraps generate / evaluate in it,
+        # inference_ullava_core.py:72, models/ullava.py:349) is an inference tensor and may not be updated in place outside that mode
+        e[1] = tile_major(w.detach())
         e[2] = w._version
     return e[1]
 
