@@ -10,8 +10,12 @@ is already running inside such a launch (WORLD_SIZE set by the driver's own `pyt
 A "step" = one forward of the per-GPU batch.  Headline workload = BASELINE.json config C4 (336x336 synthetic images, 64-token
 prompts, S = 643, per-GPU batch 32, weak scaling); the same JSON line carries a `res` sub-record = config C3 (full RES forward:
 + SAM ViT-H encoder at 1024x1024, 3 [SEG]/[LOC] per image, MaskDecoder, postprocess; batch 8) timed with the same protocol, so
-both halves of BASELINE.json's metric ("ViT-L-336 + LLaMA-7B + SAM RES forward") are measured in the driver's run.
-Inputs and random-init weights are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+both halves of BASELINE.json's metric ("ViT-L-336 + LLaMA-7B + SAM RES forward") are measured in the driver's run, and `extra.c2` /
+`extra.c5` = BASELINE.json configs[1] (VQA, batch 16, ragged prompts) and configs[4] (8-frame video clips, 8 per GPU) at their own sizes
+(`config.also_timed` repeats the three in brief).  Inputs and random-init weights are resident in HBM before the timed region.
+Every timed region is bracketed by barriers; the process group is destroyed after the last one and rank 0's single-rank probes
+(roofline, patchify, CPU baseline) run afterwards, on a node where no other rank is working.  Rank 0 prints ONE JSON line, which also
+carries what the collective layer itself saw (`process_group.rccl_world_size`) and the per-rank step time range.
 """
 import argparse
 import hashlib
@@ -566,25 +570,33 @@ def timed_steps(step, steps, warmup, dist, batch, device):
     for _ in range(steps):
         last = step()
     sync()
+    busy = time.perf_counter() - t0                                           # this rank's own K steps, before it waits for the others
     if dist:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
     check_finite(last)                                                        # outside the timed region: the last step's outputs
-    return D.global_rate(float(batch * steps), elapsed, device=device)        # (images/s whole job, images, max elapsed)
+    rate, total, t_max = D.global_rate(float(batch * steps), elapsed, device=device)     # (images/s whole job, images, max elapsed)
+    lo, hi = D.elapsed_spread(busy, device=device)                            # fastest / slowest rank's own time: where skew comes from
+    return rate, total, t_max, {"min": round(lo / steps * 1e3, 3), "max": round(hi / steps * 1e3, 3)}
 
 
 TRAIN_CONFIGS = {"full": 16, "lora": 32, "qv": 8}          # per-GPU batch (configs/train/ullava.yaml:148, ullava_lora.yaml:148)
 
 
-def workload_step(name, dev, rank, batch_override=None, train_config="full"):
-    """Build model + inputs of a workload; returns (step callable, per-GPU batch, S, cfg, description, flops per image)."""
+def workload_step(name, dev, rank, batch_override=None, train_config="full", model=None):
+    """Build model + inputs of a workload; returns (step callable, per-GPU batch, S, cfg, description, flops per image, model).
+    model: an already built UllavaCoreForCausalLM of the workload's image size to run it on (C2 / C5 after RES), else one is built."""
     image_size, prompt, batch, desc = WORKLOADS[name]
     if name == "train":
         batch = TRAIN_CONFIGS[train_config]
     batch = batch_override or batch
     res, video = name == "res", name == "c5"
-    model, cfg = build_model(image_size, dev, seed=rank, with_sam=res)
+    if model is None:
+        model, cfg = build_model(image_size, dev, seed=rank, with_sam=res)
+    else:
+        cfg = model.config
+        assert not res and cfg.vision_config.image_size == image_size
     vis, ids, mask = make_inputs(cfg, batch, prompt, dev, rank, ragged=(name == "c2"), video=video)
     S = ids.shape[1]
     P = (image_size // 14) ** 2
@@ -666,6 +678,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-res", action="store_true", help="skip the C3 RES sub-record of the default (c4) run")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C5 sub-records of the default (c4) run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks (only with --stub)")
     ap.add_argument("--stub", action="store_true", help="replace the model step by a fixed host-side delay (tests the N-rank protocol without a GPU)")
     ap.add_argument("--init-pg", action="store_true", help="initialise the process group (RCCL) even at --gpus 1, so that the barrier and the "
@@ -708,6 +721,18 @@ def main():
             dist_.init_process_group("gloo")
         dist = dist_
 
+    pg = None
+    if dist is not None:
+        # what the collective layer itself reports: a SCALE record must show that RCCL saw N ranks, not what the launcher was asked for
+        pg = {"backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(), "rank": dist.get_rank()}
+
+    def close_pg():
+        """barrier + destroy: every timed region is over.  Rank 0's single-rank probes run AFTER this, on an otherwise idle node (in an
+        N > 1 run ranks 1..N-1 have left; before round 5 they sat in a barrier while rank 0 probed between the C4 and RES timings)."""
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+
     if a.stub:
         image_size, prompt, batch, desc = WORKLOADS[a.workload]
         batch = a.batch or batch
@@ -715,51 +740,68 @@ def main():
         def step():
             time.sleep(0.01 * (1 + rank))                        # rank r is (r+1)x slower: the MAX over ranks must show
             return torch.zeros(1)
-        value, total_images, elapsed = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
+        value, total_images, elapsed, spread = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
+        close_pg()
         if rank == 0:
+            import torch.distributed as dist_chk
+            probes = {"order": "after destroy_process_group", "process_group_alive": bool(dist_chk.is_initialized())}
+            time.sleep(0.02)                                     # stands for the roofline / patchify / cpu_baseline probes
             print(json.dumps({"metric": METRIC, "value": round(value, 3), "unit": "images/sec (whole job)", "n_gpus": world, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "stub", "total_images": total_images,
-                              "cpu_affinity": affinity,
+                              "cpu_affinity": affinity, "process_group": pg, "per_rank_ms_per_step": spread, "probes": probes,
                               "config": {"workload": "stub step (host-side delay), " + desc, "per_gpu_batch": batch,
                                          "global_batch": batch * world, "parallelism": f"dp{world}"}}), flush=True)
-        if dist:
-            dist.barrier()
-            dist.destroy_process_group()
         return
+
+    def sub_record(svalue, ssteps, selapsed, sspread, sbatch, sS, sdesc, sflops, **cfg_extra):
+        return {"value": round(svalue, 3), "unit": "images/sec (whole job)", "steps": ssteps, "ms_per_step": round(selapsed / ssteps * 1e3, 3),
+                "per_rank_ms_per_step": sspread, "images_per_sec_per_gpu": round(svalue / world, 3),
+                "config": dict({"workload": sdesc, "per_gpu_batch": sbatch, "global_batch": sbatch * world, "seq_len": sS}, **cfg_extra),
+                "model_tflops_per_image": round(sflops / 1e12, 3),
+                "frac_of_bf16_peak_end_to_end": round(sflops * svalue / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
     with (torch.enable_grad() if a.workload == "train" else torch.no_grad()):
         step, batch, S, cfg, desc, flops_img, model = workload_step(a.workload, dev, rank, a.batch, a.train_config)
-        value, total_images, elapsed = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
+        value, total_images, elapsed, spread = timed_steps(step, a.steps, a.warmup, dist, batch, dev)
         image_size, prompt = WORKLOADS[a.workload][:2]
         res_rec = None
-        roof = None
-        patch_rec = res_roof = None
-        if rank == 0 and not a.no_roofline and a.workload != "train":
-            roof = gemm_roofline(cfg, batch * S, dev)
-            if a.workload == "c4":
-                patch_rec = patchify_record(dev)
-                if not a.no_res:
-                    res_roof = sam_gemm_roofline(dev)
+        extra = {}
         if a.workload == "c4" and not a.no_res:
             # second half of BASELINE.json's metric: the full RES forward (C3), same timing protocol, same process
             del step, model
             torch.cuda.empty_cache()
             rstep, rbatch, rS, rcfg, rdesc, rflops, rmodel = workload_step("res", dev, rank)
             rsteps = max(3, min(a.steps, 10))
-            rvalue, rimgs, relapsed = timed_steps(rstep, rsteps, max(1, min(a.warmup, 2)), dist, rbatch, dev)
-            res_rec = {"value": round(rvalue, 3), "unit": "images/sec (whole job)", "steps": rsteps, "ms_per_step": round(relapsed / rsteps * 1e3, 3),
-                       "images_per_sec_per_gpu": round(rvalue / world, 3),
-                       "config": {"workload": rdesc, "per_gpu_batch": rbatch, "global_batch": rbatch * world, "seq_len": rS,
-                                  "sam_input": "1024x1024 (valid 768x1024 -> 480x640 masks)", "prompts_per_image": 3},
-                       "model_tflops_per_image": round(rflops / 1e12, 3),
-                       "frac_of_bf16_peak_end_to_end": round(rflops * rvalue / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
-            del rstep, rmodel
+            rvalue, rimgs, relapsed, rspread = timed_steps(rstep, rsteps, max(1, min(a.warmup, 2)), dist, rbatch, dev)
+            res_rec = sub_record(rvalue, rsteps, relapsed, rspread, rbatch, rS, rdesc, rflops,
+                                 sam_input="1024x1024 (valid 768x1024 -> 480x640 masks)", prompts_per_image=3)
+            if not a.no_extra:
+                # the other two BASELINE.json configurations, timed at their own sizes on the RES model's language model (the very
+                # ViT-L/14-224 + LLaMA-7B of C2 / C5; SAM stays idle): C2 = configs[1] (VQA, batch 16, ragged prompts), C5 = configs[4] (video, 8 clips / GPU)
+                del rstep
+                for wname in ("c2", "c5"):
+                    wstep, wbatch, wS, _, wdesc, wflops, _ = workload_step(wname, dev, rank, model=rmodel.llm)
+                    wsteps = max(3, min(a.steps, 5))
+                    wvalue, _, welapsed, wspread = timed_steps(wstep, wsteps, 2, dist, wbatch, dev)
+                    extra[wname] = sub_record(wvalue, wsteps, welapsed, wspread, wbatch, wS, wdesc, wflops)
+                    del wstep
+            del rmodel
             torch.cuda.empty_cache()
+        close_pg()
+        # ---- single-rank probes: after the process group is gone (see close_pg) -------------------------------------------------------
+        roof = patch_rec = res_roof = None
+        if rank == 0 and not a.no_roofline and a.workload != "train":
+            roof = gemm_roofline(cfg, batch * S, dev)
+            if a.workload == "c4":
+                patch_rec = patchify_record(dev)
+                if not a.no_res:
+                    res_roof = sam_gemm_roofline(dev)
 
     if rank == 0:
         line = {"metric": METRIC, "value": round(value, 3), "unit": "images/sec (whole job, all GPUs)", "cpu_affinity": affinity,
-                "outputs_finite": True, "process_group": (a.backend if dist is not None else None),
+                "outputs_finite": True, "process_group": pg, "per_rank_ms_per_step": spread,
+                "probes": {"order": "after destroy_process_group", "ranks_running": 1},
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                 "config": {"workload": desc, "per_gpu_batch": batch, "global_batch": batch * world, "seq_len": S, "image": image_size,
@@ -768,10 +810,19 @@ def main():
                 "model_tflops_per_image": round(flops_img / 1e12, 3),
                 "model_tflops_per_sec_per_gpu": round(flops_img * value / world / 1e12, 1),
                 "frac_of_bf16_peak_end_to_end": round(flops_img * value / world / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        also = {}
         if res_rec is not None:
             if res_roof is not None:
                 res_rec["roofline"] = res_roof
             line["res"] = res_rec
+            also["res"] = {"images_per_sec": res_rec["value"], "ms_per_step": res_rec["ms_per_step"], "per_gpu_batch": res_rec["config"]["per_gpu_batch"]}
+        for k, v in extra.items():
+            also[k] = {"images_per_sec": v["value"], "ms_per_step": v["ms_per_step"], "per_gpu_batch": v["config"]["per_gpu_batch"]}
+        if extra:
+            line["extra"] = extra
+        if also:
+            # the other BASELINE.json configurations timed in this run, in brief (full records: `res`, `extra.c2`, `extra.c5`)
+            line["config"]["also_timed"] = also
         if patch_rec is not None:
             line["patchify"] = patch_rec
         if roof is not None:
@@ -779,9 +830,6 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dev)
         print(json.dumps(line), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

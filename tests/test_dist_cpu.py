@@ -151,6 +151,13 @@ def test_bench_launch_and_aggregation_gloo_world8_stub():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 8 and rec["total_images"] == 8 * 32 * 2 and rec["config"]["global_batch"] == 256
     assert rec["ms_per_step"] >= 80.0                    # rank 7 sleeps 80 ms per step: the MAX over ranks
+    # what the collective layer saw, and where the skew is: rank 0 sleeps 10 ms per step, rank 7 80 ms
+    assert rec["process_group"] == {"backend": "gloo", "rccl_world_size": 8, "rank": 0}
+    sp = rec["per_rank_ms_per_step"]
+    assert 10.0 <= sp["min"] < 40.0 and 80.0 <= sp["max"] <= rec["ms_per_step"] + 0.01      # (+ the closing barrier)
+    # rank 0's single-rank probes run after the process group is gone (ranks 1..7 have left: nobody waits in a barrier, nobody
+    # shares the node with the probes)
+    assert rec["probes"] == {"order": "after destroy_process_group", "process_group_alive": False}
     aff = rec["cpu_affinity"]                            # 8 CPUs here -> one per rank; hosts with < 8 usable CPUs do not pin
     assert aff is None or (aff["cpus_per_rank"] >= 1 and aff["cpus_per_rank"] * 8 <= os.cpu_count())
 

@@ -43,6 +43,18 @@ def global_rate(units_local: float, elapsed_local: float, device=None) -> Tuple[
     return float(u.item() / t.item()), float(u.item()), float(t.item())
 
 
+def elapsed_spread(elapsed_local: float, device=None) -> Tuple[float, float]:
+    """(min, max) over ranks of one rank-local elapsed time: the same scalar all-reduce as global_rate (MIN and MAX), so that a
+    scaling record shows WHERE a slow whole-job step comes from (the job is as slow as its slowest rank)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return elapsed_local, elapsed_local
+    lo = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo.item()), float(hi.item())
+
+
 def _flat_buckets(grads, bucket_bytes: int):
     """Group gradient tensors (same dtype per bucket, declaration order) into buckets of at most `bucket_bytes`."""
     buckets, cur, size = [], [], 0
