@@ -78,6 +78,62 @@ def test_c4_bench_workload_full_depth():
     assert agree >= 0.99
 
 
+@pytest.mark.parametrize("name", ["c2", "c5"])
+def test_c2_c5_bench_workloads_full_depth(name):
+    """BASELINE.json configs[1] (C2: VQA, batch 16, prompts of 32..64 tokens right-padded to S = 323) and configs[4] (C5: 8 clips of 8 frames per
+    GPU, S = 299) exactly as `bench.py` times them (`extra.c2` / `extra.c5` of the bench line): 23 CLIP + 32 LLaMA-7B layers at the bench batch.
+    The oracle cannot run these sizes in test time, so -- as for C4 above -- size-independent properties: finite and deterministic; the hidden
+    states after LLaMA layers 0 / 1 equal those of a 3-layer model with the same weights (which test_model_gpu.py compares with the oracle at
+    these very batch shapes); a sample inside the batch equals the same sample alone; and for the ragged C2 batch a row truncated to its own
+    length gives the valid positions' logits (right padding is invisible under the causal mask; reference collator base_collator.py:27-42)."""
+    import bench
+    M, C = pkg("modeling_core"), pkg("configuration")
+    video = name == "c5"
+    kw = "videos" if video else "images"
+    with torch.no_grad():
+        step, batch, S, cfg, desc, flops, model = bench.workload_step(name, DEV, 0)
+        assert (batch, S, cfg.num_hidden_layers, cfg.vision_config.image_size) == ((16, 323, 32, 224) if name == "c2" else (8, 299, 32, 224))
+        a = step().logits
+        b = step().logits
+        assert tuple(a.shape) == (batch, S, 32011) and bool(torch.isfinite(a.float()).all())
+        assert torch.equal(a, b), f"two runs of the {name} step differ"
+        vis, ids, mask = bench.make_inputs(cfg, batch, bench.WORKLOADS[name][1], DEV, 0, ragged=(name == "c2"), video=video)
+        if name == "c2":
+            lens = mask.sum(1).tolist()
+            assert min(lens) == 259 + 32 and max(lens) == 259 + 64 and len(set(lens)) > 8            # really ragged
+        else:
+            assert tuple(vis.shape) == (8, 3, 8, 224, 224)
+        full = model.forward(input_ids=ids, attention_mask=mask, output_hidden_states=True, **{kw: vis})
+        assert torch.equal(full.logits, a)
+        cfg3 = C.UllavaCoreConfig(vision_config=dict(image_size=224, patch_size=14), vision_hidden_layer=-2, projector_type="mlp",
+                                  mm_token_ids=dict(bench.MM), vocab_size=32011, num_hidden_layers=3)
+        m3 = M.UllavaCoreForCausalLM(cfg3, device=DEV)
+        sd = model.state_dict()
+        m3.load_state_dict({k: v for k, v in sd.items() if not k.startswith("model.layers.") or int(k.split(".")[2]) < 3}, strict=True)
+        m3.strict_checks = False
+        o3 = m3.forward(input_ids=ids, attention_mask=mask, output_hidden_states=True, **{kw: vis})
+        for li in (0, 1, 2):
+            assert torch.equal(o3.hidden_states[li], full.hidden_states[li]), f"hidden state {li} of the 32-layer model != 3-layer model"
+        bsel = 3                                                                                   # (C2: a row with padding)
+        one = model.forward(input_ids=ids[bsel:bsel + 1], attention_mask=mask[bsel:bsel + 1], output_hidden_states=True, **{kw: vis[bsel:bsel + 1]})
+        s_emb = _stats(full.hidden_states[0][bsel], one.hidden_states[0][0])
+        s_l1 = _stats(full.hidden_states[1][bsel], one.hidden_states[1][0])
+        valid = mask[bsel].bool()
+        s32 = _stats(full.logits[bsel][valid], one.logits[0][valid])
+        agree = float((full.logits[bsel][valid].argmax(-1) == one.logits[0][valid].argmax(-1)).float().mean())
+        rec = dict(embeds=s_emb, layer0=s_l1, logits_32_layers=s32, argmax_agree=agree)
+        if name == "c2":
+            n = int(mask[bsel].sum())
+            assert n < S
+            cut = model.forward(input_ids=ids[bsel:bsel + 1, :n], attention_mask=mask[bsel:bsel + 1, :n], images=vis[bsel:bsel + 1])
+            rec["truncated_row"] = st = _stats(full.logits[bsel, :n], cut.logits[0])
+            assert st["max"] <= 2.0 ** -6 * st["ref_max"] and st["mean"] <= 2.0 ** -8 * st["ref_std"]
+    print(f"{name} full depth, sample {bsel} in B={batch} vs alone:", json.dumps(rec))
+    assert s_emb["max"] == 0.0 and s_l1["max"] == 0.0
+    assert s32["max"] <= 2.0 ** -6 * s32["ref_max"] and s32["mean"] <= 2.0 ** -8 * s32["ref_std"]
+    assert agree >= 0.99
+
+
 @pytest.mark.parametrize("case", ["c4_336", "c5_video"])
 def test_c4_c5_shapes_full_depth_against_oracle(case):
     """The other two core-path configs of BASELINE.json at full depth and batch 1 against the oracle (bf16 + fp32 truth), same rule as
@@ -269,6 +325,44 @@ def test_c1_greedy_ids_match_oracle_where_gated(dt):
     assert torch.equal(hip.argmax(-1), want[0, L0:]), "teacher-forced HIP argmax differs from the oracle's ids at a gated step"
     assert torch.equal(got_nc.cpu(), want), "generate() without a KV cache: token ids differ from the oracle's greedy loop"
     assert torch.equal(got_kv.cpu(), want), "generate() with the KV cache: token ids differ from the oracle's greedy loop"
+
+
+def test_c1_kv_cached_generate_returns_the_no_cache_last_step_states_full_depth():
+    """`evaluate()` reads `generate(...).hidden_states[-1][-1]` -- under the reference checkpoints' use_cache=False that is the
+    last-layer (post-norm) state of EVERY position of `sequences[:, :-1]`, i.e. `forward(sequences[:, :-1]).hidden_states[-1]`
+    (models/ullava.py:350-371).  The HIP generate() keeps a KV cache and must hand back the same tensor: on the 32-layer 7 B C1 model,
+    8 greedy steps, `keep_last_step_only=True` (what evaluate() passes):
+      * shape [1, L - 1, 4096]; the prefill rows are BIT-identical to a HIP forward over sequences[:, :-1];
+      * the decode rows (GEMV kernels, a different fp32 summation order) and the whole tensor are as close to the oracle's fp32 forward over
+        the same ids as the oracle's own bf16 forward is (x3 rule);
+      * the no-cache generate() returns the forward's tensor bit for bit."""
+    import bench
+    from oracle import ullava_oracle as O
+    sd, model = _c1_fixture()
+    cfg, ids, mask, img = bench.c1_case(seed=C1_GREEDY_SEED)
+    L0 = ids.shape[1]
+    torch.set_num_threads(min(os.cpu_count(), 64))
+    with torch.no_grad():
+        kv = model.generate(input_ids=ids.to(DEV), images=img.to(DEV), max_new_tokens=8, do_sample=False, use_cache=True, eos_token_id=-1,
+                            output_hidden_states=True, return_dict_in_generate=True, keep_last_step_only=True)
+        nc = model.generate(input_ids=ids.to(DEV), images=img.to(DEV), max_new_tokens=8, do_sample=False, use_cache=False, eos_token_id=-1,
+                            output_hidden_states=True, return_dict_in_generate=True, keep_last_step_only=True)
+        assert torch.equal(kv.sequences, nc.sequences) and kv.sequences.shape[1] == L0 + 8
+        seq = kv.sequences[:, :-1]
+        fwd = model.forward(input_ids=seq, images=img.to(DEV), output_hidden_states=True).hidden_states[-1]
+        h_kv, h_nc = kv.hidden_states[-1][-1], nc.hidden_states[-1][-1]
+        assert tuple(h_kv.shape) == tuple(h_nc.shape) == tuple(fwd.shape) == (1, L0 + 7, 4096)
+        assert torch.equal(h_nc, fwd), "no-cache generate(): last-step states != forward(sequences[:, :-1])"
+        assert torch.equal(h_kv[:, :L0], fwd[:, :L0]), "KV-cached generate(): prefill rows differ from forward(sequences[:, :-1])"
+        sc = seq.cpu()
+        ref = O.core_forward(sd, cfg, sc, torch.ones_like(sc), img)["hidden_states"][-1]
+        truth = O.core_forward(bench.F32View(sd), cfg, sc, torch.ones_like(sc), img.float())["hidden_states"][-1]
+    e_ref, e_kv, e_fwd = _rel(ref, truth), _rel(h_kv, truth), _rel(fwd, truth)
+    e_dec_ref, e_dec_kv = _rel(ref[:, L0:], truth[:, L0:]), _rel(h_kv[:, L0:], truth[:, L0:])
+    print("C1 evaluate() states, KV cache vs forward vs oracle:", json.dumps(dict(
+        oracle_bf16_err=round(e_ref, 5), hip_kv_err=round(e_kv, 5), hip_forward_err=round(e_fwd, 5), decode_rows_oracle_err=round(e_dec_ref, 5),
+        decode_rows_hip_kv_err=round(e_dec_kv, 5), kv_vs_forward_decode_rows=round(_rel(h_kv[:, L0:], fwd[:, L0:]), 5))))
+    assert e_kv <= max(3.0 * e_ref, 2.0 ** -7) and e_dec_kv <= max(3.0 * e_dec_ref, 2.0 ** -7)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, pytest.param(torch.float16, marks=pytest.mark.skipif(
