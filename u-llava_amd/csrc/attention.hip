@@ -47,7 +47,17 @@ struct AttnArgs {
     // the qkv bias): K / V rows of such keys come from k_pad / v_pad.
     int img_h, img_w, nwy, nwx;
     const elem_t* k_pad; const elem_t* v_pad;   // K / V part of the pad token's row (+ h * k_hs)
+#ifdef ULL_ATTN_STAMPS
+    unsigned long long* stamps;         // debug build only (tools/attn_phase_times.py): per-wave cycle totals of attn_reg_kernel's phases
+#endif
 };
+#ifdef ULL_ATTN_STAMPS
+unsigned long long* ull_attn_stamp_host_ptr = nullptr;
+#define ULL_ATT_T() __builtin_readcyclecounter()
+#define ULL_ATT_ACC(slot, t0) do { const unsigned long long t1_ = __builtin_readcyclecounter(); stamp_acc[slot] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define ULL_ATT_ACC(slot, t0) ((void)0)
+#endif
 
 // ull_sam_window_attention: window b = (img * nwy + wy) * nwx + wx -> (image, first token row, first token column).  The divisors are
 // run-time values; a / d goes through the host-computed m = ceil(2^32 / d): exact while a * d < 2^32 (the dispatcher checks), m = 0
@@ -109,7 +119,12 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
 template <int FL>
 ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& lo, uint32_t& hi, float* row_max = nullptr) {
     if constexpr (FL == FL_LLAMA || FL == FL_CLIP) {
-        const uint32_t a01 = pack2e(acc[0], acc[1]), a23 = pack2e(acc[2], acc[3]);
+        // (the packed pairs are made opaque: seeing through pack -> unpack, the compiler converts every value on its own again --
+        //  4 single conversions + 4 shifts instead of 2 packed conversions + 2 shifts + 2 ands; census in profiles/r05_attn_prefill_census.txt)
+        uint32_t a01 = pack2e(acc[0], acc[1]), a23 = pack2e(acc[2], acc[3]);
+#ifndef ULL_ATTN_NO_OPAQUE_PAIRS
+        asm volatile("" : "+v"(a01), "+v"(a23));
+#endif
         const f32x2_t x01 = f32x2_t{pk_lo(a01), pk_hi(a01)} * p.scale, x23 = f32x2_t{pk_lo(a23), pk_hi(a23)} * p.scale;
         if (row_max) *row_max = fmaxf(fmaxf(fmaxf(*row_max, x01.x), x01.y), fmaxf(x23.x, x23.y));
         lo = pack2e(x01.x, x01.y);
@@ -354,7 +369,8 @@ constexpr int attn_reg_nbuf() {
 //   VROW (LLaMA / CLIP prefill): the V tiles are DMA'd ROW-major from V itself ([64 keys][head dim], like the K tiles) and the V^T
 //   operand of P*V comes out of them through ds_read_b64_tr_b16: no V^T pass in front of the attention.
 template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool VROW = false>
-__global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)) ? 4 : 2) void attn_reg_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)) ? 4 : (VROW && HDP == 128 && NT <= 11 && NWV <= 4) ? 3 : 2)
+void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefill: three blocks per CU = at most 168 registers)
     extern __shared__ __attribute__((aligned(256))) char smem[];     // (256: the V fragment addresses below XOR bits 5..7)
     static_assert(!VROW || ((FL == FL_LLAMA || FL == FL_CLIP) && HDP >= 64), "VROW: flavors that pin hd = HDP");
     constexpr int PM = HDP / 16 >= 8 ? 7 : HDP / 16 - 1;      // VROW: XOR mask of the 32-byte pair index (pairs per row - 1, at most 7)
@@ -377,6 +393,12 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
     const int b = head / p.H, h = head % p.H;
     const int q0 = qt * BQ;
     const int koff = p.Sk - p.Sq;
+#ifdef ULL_ATTN_STAMPS
+    // slots: 0 prologue, 1 phase-1 wait (vmcnt + barrier + DMA issue), 2 phase-1 compute, 3 softmax, 4 phase-3 wait, 5 phase-3 compute, 6 epilogue
+    unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = ULL_ATT_T();
+    const unsigned long long stamp_start = stamp_t;
+#endif
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     constexpr int NBUF = attn_reg_nbuf<HDP, NT, NWV, EXACT, VROW>();   // EXACT: [K tiles 0..NT) [V^T tiles 0..NT); else a ring of tile buffers
@@ -513,6 +535,7 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
     float mrow = -INFINITY;               // running maximum of this lane's scores
+    ULL_ATT_ACC(0, stamp_t);
 
     uint32_t sp[NT][8];                   // [tile][2*ns + half]: bf16 pairs for keys kt*64 + ns*16 + 4*fg + {0,1 | 2,3}
     // LDS fragment addressing, per lane and ONCE: the K fragment of k-step ks sits at kfo[ks] inside rows fr, fr + 16, ... of a tile (the
@@ -552,8 +575,42 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
             if constexpr (!EXACT) stream_step(kt);
+            ULL_ATT_ACC(1, stamp_t);
             if (kt < nkt_w) {
                 const char* tb = smem + (EXACT ? kt : (kt % NBUF)) * TILE;
+#ifndef ULL_ATTN_NO_TILE_PATH
+                if constexpr (VROW) {
+                    // a whole tile of real keys, no key mask, entirely below the diagonal for each of the wave's 16 queries (all but the last
+                    // tile or two of a wave): ONE wave-uniform branch per tile, then straight-line code -- the four 16-key groups' accumulator
+                    // chains interleave (no MFMA waits for the one before it) and the four score epilogues follow without look-ups
+                    if (p.key_mask == nullptr && kt * KT + KT <= p.Sk && (FL != FL_LLAMA || kt * KT + KT - 1 <= q0 + wave * 16 + koff)) {
+#ifndef ULL_ATTN_CHAINS
+#define ULL_ATTN_CHAINS 2               // accumulator chains in flight (4: 12 more registers, spills at the 168 of three blocks per CU)
+#endif
+#pragma unroll
+                        for (int n0 = 0; n0 < 4; n0 += ULL_ATTN_CHAINS) {
+                            f32x4_t accn[ULL_ATTN_CHAINS];
+#pragma unroll
+                            for (int c = 0; c < ULL_ATTN_CHAINS; ++c) accn[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                                for (int c = 0; c < ULL_ATTN_CHAINS; ++c) {
+                                    const uint4 kf = *(const uint4*)(tb + (n0 + c) * 16 * KROW + kfo[ks]);
+                                    accn[c] = mfma16(kf, qf[ks], accn[c]);
+                                }
+#pragma unroll
+                            for (int c = 0; c < ULL_ATTN_CHAINS; ++c)
+                                score_quad_clean<FL>(p, accn[c], sp[kt][(n0 + c) * 2], sp[kt][(n0 + c) * 2 + 1], &mrow);
+                        }
+#ifdef ULL_ATTN_STAMPS
+                        asm volatile("" :: "v"(sp[kt][0]), "v"(sp[kt][7]), "v"(mrow));
+                        ULL_ATT_ACC(2, stamp_t);
+#endif
+                        continue;
+                    }
+                }
+#endif
 #pragma unroll
                 for (int ns = 0; ns < 4; ++ns) {
                     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -585,6 +642,10 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
                     if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#ifdef ULL_ATTN_STAMPS
+            asm volatile("" :: "v"(sp[kt][0]), "v"(sp[kt][7]), "v"(mrow));
+            ULL_ATT_ACC(2, stamp_t);
+#endif
         }
     }
 
@@ -622,6 +683,10 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
             }
     }
 
+#ifdef ULL_ATTN_STAMPS
+    asm volatile("" :: "v"(sp[0][0]), "v"(sp[NT - 1][7]));
+    ULL_ATT_ACC(3, stamp_t);
+#endif
     // ---- phase 3: O^T = V^T P^T; P feeds the MFMA B operand straight from registers ---------------------
     // V^T tiles are stored with keys permuted inside every 32-key block (slot 8g+4a+r <- key 16a+4g+r, see
     // transpose_v_kernel) so that the k-slot <-> key map of the A operand equals the one the P registers already have.
@@ -636,6 +701,7 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
             if constexpr (!EXACT) stream_step(nkt + kt);
+            ULL_ATT_ACC(4, stamp_t);
             if constexpr (VROW) {
                 if (kt < nkt_w) {
                     const uint32_t vb = lds_base + (EXACT ? NT + kt : ((nkt + kt) % NBUF)) * TILE + vfo;
@@ -676,8 +742,41 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
                     if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#ifdef ULL_ATTN_STAMPS
+            asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[NDS - 1][3]));
+            ULL_ATT_ACC(5, stamp_t);
+#endif
         }
     }
+#ifndef ULL_ATTN_NO_LDS_EPILOGUE
+    if constexpr (VROW && !EXACT && NBUF == 2) {
+        // O through LDS, stored as whole rows.  A lane holds 4 head dims of ONE query per block of 16: stored from the registers that is 8-byte
+        // pieces at a row stride (every store instruction touches 16 rows x 4 x 32 B).  Instead each wave writes its 16 x hd block into
+        // the ring buffer nobody reads any more (the last step lives in the other one; every wave has passed that step's barrier) and
+        // reads it back as 16-byte pieces of consecutive rows: CPR / 4 stores of 4 (hd 128) or 8 (hd 64) full rows each.
+        char* ob = smem + ((2 * nkt - 2) % NBUF) * TILE + wave * 16 * KROW;
+        constexpr int SM = CPR >= 16 ? 15 : CPR - 1;
+        int ln = lane;                                    // (opaque: the per-lane addresses below are computed HERE, not hoisted to the
+        asm volatile("" : "+v"(ln));                      //  kernel entry and kept -- or spilled -- through the three phases)
+        const int er = ln & 15, eg = ln >> 4;
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            uint2 pk;
+            pk.x = pack2e(oacc[ds][0], oacc[ds][1]);
+            pk.y = pack2e(oacc[ds][2], oacc[ds][3]);
+            *(uint2*)(ob + er * KROW + ((((ds * 2 + (eg >> 1)) ^ (er & SM))) << 4) + ((eg & 1) << 3)) = pk;
+        }
+        constexpr int RPI = 64 / CPR;                     // rows per store instruction
+        elem_t* ow = p.O + (long)b * p.o_bs + (long)h * p.o_hs;
+#pragma unroll
+        for (int it = 0; it < 16 / RPI; ++it) {
+            const int r = it * RPI + ln / CPR, c = ln % CPR;
+            const uint4 v = *(const uint4*)(ob + r * KROW + ((c ^ (r & SM)) << 4));
+            const int q = q0 + wave * 16 + r;
+            if (q < p.Sq) *(uint4*)(ow + (long)q * p.o_ss + c * 8) = v;
+        }
+    } else
+#endif
     if (qi < p.Sq) {
         elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
@@ -690,6 +789,22 @@ __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)
             }
         }
     }
+#ifdef ULL_ATTN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ULL_ATT_ACC(6, stamp_t);
+    if (p.stamps && lane == 0) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NWV + wave) * 12;
+        for (int i = 0; i < 7; ++i) o[i] = stamp_acc[i];
+        o[7] = stamp_t - stamp_start;
+        o[8] = (unsigned long long)nkt_w | ((unsigned long long)nkt << 16) | ((unsigned long long)qt << 32);
+        o[9] = stamp_start;
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(20, 0, 32)" : "=s"(xcc));
+        o[10] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+        o[11] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1819,7 +1934,13 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
+#ifdef ULL_ATTN_STAMPS
+    AttnArgs as = a;
+    as.stamps = ull_attn_stamp_host_ptr;
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, VROW>), grid, dim3(NWV * 64), lds, st, as);
+#else
     hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, VROW>), grid, dim3(NWV * 64), lds, st, a);
+#endif
     return ull_check_launch();
 }
 
@@ -1887,7 +2008,10 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
     if (a.v_rows) {                      // V handed over row-major: the kernels that transpose on the fly (see the C entry)
         if constexpr (HDP == 128) {
-            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, 4, false, true>(a, st);
+#ifndef ULL_ATTN_NWV
+#define ULL_ATTN_NWV 4
+#endif
+            if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, ULL_ATTN_NWV, false, true>(a, st);
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, true>(a, st);
             if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16 &&
                 64 * a.k_ss * 2 < (1L << 31) && 64 * a.vt_ds * 2 < (1L << 31))         // (32-bit per-lane DMA offsets inside a tile)
@@ -1951,6 +2075,10 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
 // Strides are in elements.  Q/K rows are head_dim-contiguous; Vt rows (one per head dim) are key-contiguous with
 // `vt_len` readable, finite columns (multiple of 8; keys >= Sk must be zero).  key_mask: int32 [B, Sk] or null.
 // scale_mode 0: S = bf16(QK^T); 1: bf16(bf16(QK^T) * scale); 2: bf16(bf16(QK^T) / scale).
+#ifdef ULL_ATTN_STAMPS
+extern "C" int ULL_FN(ull_debug_attn_stamps_)(void* buf) { ull_attn_stamp_host_ptr = (unsigned long long*)buf; return ULL_OK; }
+#endif
+
 extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs,
                                   int64_t k_ss, const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O,
                                   int64_t o_bs, int64_t o_hs, int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq,
