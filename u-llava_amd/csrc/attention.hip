@@ -18,6 +18,7 @@
 // Also here: the QKV post-processing kernels (RoPE in place on q|k, V -> V^T with zero padding).
 #include "ull_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -1625,6 +1626,330 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// SAM global attention (image_encoder.py:196-260 with the decomposed rel-pos bias :354-392 on the 64 x 64 grid: 4096 keys, hd 80, raw
+// rel_pos_h / rel_pos_w [127, 80], q | k | v consumed in place, V as rows) -- attn_stream_kernel<128, SAM, HOIST 2, VROW>'s arithmetic,
+// statement for statement per query (same rounding points, same fp32 summation orders: the outputs are bit-identical, tools/global_attn_ab.py),
+// on a different decomposition: a wave owns 32 queries (two groups of 16, one MFMA column block each) instead of 16, a block is 4 waves
+// (128 queries as before) instead of 8, and the tile loop is software-pipelined (S of tile kt + 1 beside the softmax of tile kt, P V of
+// tile kt beside the score epilogue of tile kt + 1; K runs two tiles ahead of V in its own ring).
+//   * every K fragment (ds_read_b128) and every V fragment (two ds_read_b64_tr_b16) feeds TWO MFMAs: the LDS array is busy 1.41e8 cycles per
+//     launch instead of 2.35e8, waves wait half as long (profiles/r05_sam_global_attention.txt);
+//   * four waves meet at the tile barrier instead of eight;
+//   * the rel_h values of a wave's 32 queries (all in one grid row) are a [64][32] table in LDS, one 2-byte read per (group, tile), instead
+//     of 16 registers and a shuffle ladder; rel_w stays in registers (16 per group: the lane's key columns are the same in every tile).
+// 80 KB of LDS per block (K ring + V ring + the rel_h tables): two blocks per CU, two waves per SIMD.
+// What it did NOT buy is time (1.17-1.22 ms per layer at B = 8 for either form): the kernel is bound by the vector + matrix ISSUE of one SIMD,
+// which on gfx950 add up instead of overlapping (tools/probes/valu_rate.hip: one 16x16x32 MFMA 16.1 cycles, + 2.4 per v_add beside it; cvt_pk /
+// shifts / max / packed fp32 4.3 cycles, v_exp 8.2) -- 24 MFMAs + ~190 vector instructions per 16 queries x 64 keys is ~1000 cycles = 0.98 ms
+// per layer, and the instruction count is pinned by the reference's three roundings per score.
+#ifndef ULL_SAMG_OLD
+#ifndef ULL_SAMG_VA
+#define ULL_SAMG_VA 5
+#endif
+#ifndef ULL_SAMG_VB
+#define ULL_SAMG_VB 8
+#endif
+__global__ __launch_bounds__(256, 2) void sam_global_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    constexpr int NWV = 4, NG = 2, BQ = 16 * NG * NWV, HDP = 128, hd = 80;
+    constexpr int KROW = HDP * 2, NKS = 3 /* 96 = 3 x 32 >= hd */, NDS = 5 /* 80 = 5 x 16 */;
+    constexpr int TILE = 64 * KROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nq = p.Sq / BQ;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int head = (slot / nq) * 8 + xcd;
+    if (head >= p.B * p.H) return;
+    const int qt = slot % nq;
+    const int b = head / p.H, h = head % p.H;
+    const int q0 = qt * BQ + wave * 16 * NG;                   // this wave's first query; its 32 queries share the grid row qy
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    elem_t* ghl = (elem_t*)(smem + 4 * TILE) + wave * (64 * 16 * NG);     // [64 key rows][32 queries]: rel_h, 16-bit (a tile's read = 64 B)
+
+    uint4 qf[NG][NKS];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const elem_t* qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs + (long)(q0 + g * 16 + fr) * p.q_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 32 + fg * 8;
+            qf[g][ks] = d < hd ? *(const uint4*)(qp + d) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // G[q][t] = 16-bit(q . rel_pos[t]) on the MFMA (A = table rows, B = the UNSCALED query fragments): rel_w[q][kw] = Gw[q][qx - kw + 63],
+    // rel_h[q][kh] = Gh[q][qy - kh + 63].  Gw: all 127 rows -> this wave's pad (aliases the tile slots, not in use yet) -> 16 registers per
+    // group; Gh: the 64 rows qy - kh + 63 -> the wave's LDS table.
+    float rw[NG][16];
+    {
+        elem_t* gw = (elem_t*)(smem + wave * (NG * 4096));      // [group][16 queries][128]
+        const int qy = q0 >> 6;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll 2
+            for (int st = 0; st < 8; ++st) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                const elem_t* tr = p.rel_w + (long)min(st * 16 + fr, 126) * hd + fg * 8;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const uint4 a = (ks * 32 + fg * 8 < hd) ? *(const uint4*)(tr + ks * 32) : make_uint4(0, 0, 0, 0);
+                    acc = mfma16(a, qf[g][ks], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[g * 2048 + fr * 128 + st * 16 + fg * 4 + r] = f2e(acc[r]);   // G[t = st*16 + 4*fg + r][query fr]
+            }
+#pragma unroll 2
+            for (int st = 0; st < 4; ++st) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                const elem_t* tr = p.rel_h + (long)(qy - (st * 16 + fr) + 63) * hd + fg * 8;               // row of key-grid row kh = st*16 + fr
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const uint4 a = (ks * 32 + fg * 8 < hd) ? *(const uint4*)(tr + ks * 32) : make_uint4(0, 0, 0, 0);
+                    acc = mfma16(a, qf[g][ks], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ghl[(st * 16 + fg * 4 + r) * (16 * NG) + g * 16 + fr] = f2e(acc[r]);  // Gh[kh = st*16 + 4*fg + r][query fr]
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own pad only
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int qx = (q0 + g * 16 + fr) & 63;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rw[g][i] = e2f(gw[g * 2048 + fr * 128 + qx - ((i >> 2) * 16 + fg * 4 + (i & 3)) + 63]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (p.q_scale != 1.0f) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) qf[g][ks] = scale_q8(qf[g][ks], p.q_scale);
+    }
+    __builtin_amdgcn_s_barrier();                              // every wave is done with its pad before tile 0 is DMA'd over it
+
+    // LDS: K ring [2][64 x 256 B] at 0, V ring [2][64 x 256 B] at 2 TILE, rel_h tables behind.  DMA: a tile is 16 pieces of 1 KiB (4 key rows x
+    // 16 chunks); a wave issues 4 K + 4 V pieces per step.  The per-lane byte offset of every piece is the same for all 64 tiles; the six
+    // chunks of a row that are head-dim padding are not transferred: chunks 10 / 11 of every K row (dims 80..95, read by the last QK k-step)
+    // are zeroed once per buffer, the rest is never read.
+    const elem_t* kbase = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+    const elem_t* vbase = p.Vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+    uint32_t dko[4], dvo[4];
+    bool dk_real[4], dv_real[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = wave + j * NWV, row = i * 4 + (lane >> 4), cpos = lane & 15;
+        const int ck = cpos ^ (row & 15), cv = ((((cpos >> 1) ^ (row & 7)) << 1) | (cpos & 1));
+        dko[j] = (uint32_t)(((long)row * p.k_ss + ck * 8) * 2);
+        dvo[j] = (uint32_t)(((long)row * p.vt_ds + cv * 8) * 2);
+        dk_real[j] = ck * 8 < hd;
+        dv_real[j] = cv * 8 < hd;
+    }
+    for (int t = tid; t < 2 * 64 * 2; t += 64 * NWV) {
+        const int sl = t >> 7, row = (t & 127) >> 1, c = 10 + (t & 1);
+        *(uint4*)(smem + sl * TILE + row * KROW + ((c ^ (row & 15)) << 4)) = make_uint4(0, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the first barrier below orders these writes before every read)
+    auto issue_k = [&](int kt) {
+        if (kt >= 64) return;
+        const uint32_t dst = lds_base + (kt & 1) * TILE;
+        const elem_t* tk = kbase + (long)kt * KT * p.k_ss;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (dk_real[j]) glds16s(tk, dko[j], dst + (wave + j * NWV) * 1024);
+    };
+    auto issue_v = [&](int kt) {
+        if (kt >= 64) return;
+        const uint32_t dst = lds_base + (2 + (kt & 1)) * TILE;
+        const elem_t* tv = vbase + (long)kt * KT * p.vt_ds;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (dv_real[j]) glds16s(tv, dvo[j], dst + (wave + j * NWV) * 1024);
+    };
+    // LDS fragment addresses, per lane and once: K fragment of k-step ks in rows fr, fr + 16, ... (the swizzle term of row 16 ns + fr is fr);
+    // V fragment base of the transposing reads (see attn_reg_kernel)
+    uint32_t kfo[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) kfo[ks] = fr * KROW + (((ks * 4 + fg) ^ fr) << 4);
+    const int swr = 4 * (fg & 1) + (fr >> 2);
+    const uint32_t vfo = 2 * TILE + (4 * fg + (fr >> 2)) * KROW + ((fr & 2) << 3) + ((fr & 1) << 3);
+
+    f32x4_t oacc[NG][NDS], lacc[NG];
+    float m[NG], mn[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        m[g] = -INFINITY;
+        lacc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) oacc[g][ds] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#ifdef ULL_ELEM_F16
+    const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+#else
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#endif
+    // S tile kt on the matrix pipe: 4 x 3 K fragments, each into both groups' chains (24 MFMAs)
+    auto qk = [&](int kt, f32x4_t (&acc)[NG][4]) {
+        const char* tb = smem + (kt & 1) * TILE;
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const uint4 kf = *(const uint4*)(tb + ns * 16 * KROW + kfo[ks]);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g][ns] = mfma16(kf, qf[g][ks], acc[g][ns]);
+            }
+        }
+    };
+    // score epilogue of tile kt: rnd(rnd(rnd(acc) + rel_h) + rel_w) as 16-bit pairs sq[g][2 ns + half] (keys 16 ns + 4 fg + {0,1 | 2,3}), the
+    // tile maximum folded into mn[g] = the row maximum including tile kt; returns whether some query of the wave saw a new maximum
+    auto scores = [&](int kt, const f32x4_t (&acc)[NG][4], uint32_t (&sq)[NG][8]) -> bool {
+        bool grew = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float rh = e2f(ghl[kt * (16 * NG) + g * 16 + fr]);
+            float tm = -INFINITY;
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns)
+                score_quad_win(acc[g][ns], rh, f32x2_t{rw[g][ns * 4], rw[g][ns * 4 + 1]}, f32x2_t{rw[g][ns * 4 + 2], rw[g][ns * 4 + 3]}, sq[g][ns * 2],
+                               sq[g][ns * 2 + 1], tm);
+            tm = rnd(tm);
+            tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            mn[g] = fmaxf(m[g], tm);                           // finite from tile 0 on
+            grew = grew || mn[g] > m[g];
+        }
+        return __builtin_amdgcn_ballot_w64(grew) != 0;
+    };
+    // The tile loop is software-pipelined by hand: while the matrix pipe computes S of tile kt + 1 the vector pipe turns the scores of tile
+    // kt into probabilities, and while it multiplies P(kt) into V(kt) the vector pipe does the score epilogue of tile kt + 1 -- the two
+    // halves of a step are independent instruction streams inside one wave (the 16-query form left that overlap to chance between waves,
+    // and its phases added up).  Step kt therefore needs K(kt + 1) and V(kt): K runs two tiles ahead of V in its own ring.
+    issue_k(0);
+    issue_k(1);
+    issue_v(0);
+    f32x4_t acc[NG][4];
+    uint32_t sq[NG][8];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    qk(0, acc);
+    bool grew = scores(0, acc, sq);
+    // one step; LAST: tile 63 (nothing left to prefetch, no S(kt + 1))
+    auto step = [&](int kt, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (this wave's pieces of K(kt + 1) and V(kt))
+        __builtin_amdgcn_s_barrier();                          // ... and everybody's; every wave is done with K(kt) and V(kt - 1)
+        if constexpr (!LAST) {
+            issue_k(kt + 2);
+            issue_v(kt + 1);
+        }
+        if (grew) {                                            // some query of this wave has a new maximum (alpha = 1 exactly for the others)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const float alpha = __expf(m[g] - mn[g]);      // exp(-inf) = 0 on the first tile
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lacc[g][r] *= alpha;
+#pragma unroll
+                for (int ds = 0; ds < NDS; ++ds)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[g][ds][r] *= alpha;
+                m[g] = mn[g];
+            }
+        }
+        // ---- first half: S(kt + 1) on the MFMA, P(kt) on the VALU (one basic block, independent streams)
+        if constexpr (!LAST) qk(kt + 1, acc);
+        uint32_t pk[NG][8];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x2_t t = (f32x2_t{pk_lo(sq[g][i]), pk_hi(sq[g][i])} - m[g]) * 1.4426950408889634f;
+                pk[g][i] = pack2e(__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y));
+            }
+        }
+#ifdef ULL_SAMG_SGB                 // explicit MFMA / VALU interleave: measured no faster than the scheduler's own order (MFMA and VALU issue add up on a gfx950 SIMD)
+        if constexpr (!LAST) {
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // the 16-key group's three K fragments
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x402, ULL_SAMG_VA, 0);   // vector instructions (exponentials included) in its shadow
+                }
+            }
+        }
+#endif
+        // ---- second half: l += sum P(kt), O += V(kt)^T P(kt) on the MFMA  ||  score epilogue of tile kt + 1 on the VALU
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            // the row sum runs over the ROUNDED probabilities: one more "V^T row" of ones through the MFMA
+            lacc[g] = mfma16(ones, make_uint4(pk[g][0], pk[g][1], pk[g][2], pk[g][3]), lacc[g]);
+            lacc[g] = mfma16(ones, make_uint4(pk[g][4], pk[g][5], pk[g][6], pk[g][7]), lacc[g]);
+        }
+        const uint32_t vb = lds_base + (kt & 1) * TILE + vfo;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x2_t va[4], vc[4], wa[1], wc[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t ad = vb + ((j ^ swr) << 5);
+                if (kk == 0) { va[j] = lds_tr_b64<0>(ad); vc[j] = lds_tr_b64<16 * KROW>(ad); }
+                else { va[j] = lds_tr_b64<32 * KROW>(ad); vc[j] = lds_tr_b64<48 * KROW>(ad); }
+            }
+            {
+                const uint32_t ad = vb + ((4 ^ swr) << 5);
+                if (kk == 0) { wa[0] = lds_tr_b64<0>(ad); wc[0] = lds_tr_b64<16 * KROW>(ad); }
+                else { wa[0] = lds_tr_b64<32 * KROW>(ad); wc[0] = lds_tr_b64<48 * KROW>(ad); }
+            }
+            lds_tr_wait<4, 2>(va, vc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 vf = make_uint4(va[j].x, va[j].y, vc[j].x, vc[j].y);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    oacc[g][j] = mfma16(vf, make_uint4(pk[g][4 * kk], pk[g][4 * kk + 1], pk[g][4 * kk + 2], pk[g][4 * kk + 3]), oacc[g][j]);
+            }
+            lds_tr_wait<1, 0>(wa, wc);
+            {
+                const uint4 vf = make_uint4(wa[0].x, wa[0].y, wc[0].x, wc[0].y);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    oacc[g][4] = mfma16(vf, make_uint4(pk[g][4 * kk], pk[g][4 * kk + 1], pk[g][4 * kk + 2], pk[g][4 * kk + 3]), oacc[g][4]);
+            }
+        }
+        if constexpr (!LAST) {
+            grew = scores(kt + 1, acc, sq);
+#ifdef ULL_SAMG_SGB
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);          // one MFMA (l or P V)
+                __builtin_amdgcn_sched_group_barrier(0x402, ULL_SAMG_VB, 1);       // vector instructions of the next tile's score epilogue
+            }
+#endif
+        }
+    };
+#pragma unroll 2
+    for (int kt = 0; kt < 63; ++kt) step(kt, std::false_type{});
+    step(63, std::true_type{});
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const float inv = 1.0f / lacc[g][0];      // every accumulator row holds the same sum over all keys for query fr
+        elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)(q0 + g * 16 + fr) * p.o_ss;
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            uint2 o;
+            o.x = pack2e(oacc[g][ds][0] * inv, oacc[g][ds][1] * inv);
+            o.y = pack2e(oacc[g][ds][2] * inv, oacc[g][ds][3] * inv);
+            *(uint2*)(op + ds * 16 + fg * 4) = o;
+        }
+    }
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // At most 16 queries per (batch, head): KV-cached decoding (1 query against the whole cache) and the mask decoder's
 // token -> image attention (7..16 queries against 4096 keys).  The kernels above give such a call ONE working wave per head
 // that walks the key tiles one barrier at a time (measured 32 us per LLaMA decode layer, 234 us per mask-decoder call); here the
@@ -1974,6 +2299,18 @@ int launch_stream(const AttnArgs& a, hipStream_t st) {
     return ull_check_launch();
 }
 
+#ifndef ULL_SAMG_OLD
+int launch_sam_global(const AttnArgs& a, hipStream_t st) {
+    constexpr int LDS = 4 * 64 * 256 + 4 * 32 * 64 * 2;        // K ring + V ring + the rel_h tables = 80 KB: two blocks per CU
+    static UllOncePerDevice once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)sam_global_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int nq = a.Sq / 128;
+    const dim3 grid(((a.B * a.H + 7) / 8) * 8 * nq);
+    hipLaunchKernelGGL(sam_global_kernel, grid, dim3(256), LDS, st, a);
+    return ull_check_launch();
+}
+#endif
+
 template <int HDP, int FL, int TPW>
 int launch_fewq_t(const AttnArgs& a, int nwv, hipStream_t st) {
     const int lds = 2 * 16 * 16 * 4 + nwv * HDP * 16 * 4;
@@ -2014,8 +2351,12 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, ULL_ATTN_NWV, false, true>(a, st);
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, true>(a, st);
             if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16 &&
-                64 * a.k_ss * 2 < (1L << 31) && 64 * a.vt_ds * 2 < (1L << 31))         // (32-bit per-lane DMA offsets inside a tile)
+                64 * a.k_ss * 2 < (1L << 31) && 64 * a.vt_ds * 2 < (1L << 31)) {       // (32-bit per-lane DMA offsets inside a tile)
+#ifndef ULL_SAMG_OLD
+                if ((a.Sq & 127) == 0 && a.hd == 80 && !a.key_mask && !a.causal) return launch_sam_global(a, st);
+#endif
                 return launch_stream<128, FL_SAM_ENC, 2, true>(a, st);
+            }
         }
         if constexpr (HDP == 64) {
             if (fl == FL_CLIP && a.Sq > 16 && nt <= 5) return launch_attn<64, 5, FL_CLIP, 8, false, true>(a, st);
