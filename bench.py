@@ -132,32 +132,69 @@ def gemm_sources_sha():
     return h.hexdigest()[:16]
 
 
+def in_situ_kernel_times():
+    """Average duration of the GEMM launches whose kernel instantiation names them (gate/up + SwiGLU = gemm256w4_kernel<true, false>, q|k|v + RoPE
+    = <false, true>) inside the C4 step, from the newest committed `profiles/rNN_c4_kernel_stats.md` (rocprofv3 --kernel-trace --stats of
+    `bench.py --steps 3`, tools/prof_r05.sh).  o_proj / down share one instantiation with the CLIP launches and cannot be told apart by name."""
+    out = {}
+    try:
+        fns = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_c4_kernel_stats.md"))
+        if not fns:
+            return out
+        for ln in open(os.path.join(ROOT, "profiles", fns[-1])):
+            c = [t.strip() for t in ln.split("|")]
+            if len(c) < 6:
+                continue
+            for key, tag in (("gate_up+swiglu", "gemm256w4_kernel<true, false>"), ("qkv+rope", "gemm256w4_kernel<false, true>")):
+                if tag in c[1]:
+                    out[key] = {"avg_us": float(c[4]), "calls": int(c[2]), "record": "profiles/" + fns[-1]}
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def gemm_roofline(cfg, tokens, device, iters=40, warm=10):
     """Time the four GEMM launches of one LLaMA layer at the benchmark's token count with HIP events on the launch stream.
     The chip runs these kernels against its socket power cap (1.4 kW: tools/hot_power.sh), and the clock needs a few launches to settle
     after the host-side set-up of each shape, so every shape gets `warm` untimed launches and the average is taken over `iters`."""
     ops = importlib.import_module("u-llava_amd.ops")
     D, I = cfg.hidden_size, cfg.intermediate_size
-    shapes = [("qkv", 3 * D, D, False), ("o_proj", D, D, False), ("gate_up+swiglu", 2 * I, D, True), ("down", D, I, False)]
+    shapes = [("qkv+rope", 3 * D, D, False), ("o_proj", D, D, False), ("gate_up+swiglu", 2 * I, D, True), ("down", D, I, False)]
     g = torch.Generator(device="cuda").manual_seed(7)
     per = []
     tot_t = tot_f = 0.0
+    in_situ = in_situ_kernel_times()
     for name, N, K, sw in shapes:
         x = (torch.randn(tokens, K, device=device, generator=g)).to(torch.bfloat16)
         w = (torch.randn(N, K, device=device, generator=g) * 0.02).to(torch.bfloat16)
         ops.register_tiled(w)
         out = torch.empty(tokens, N // 2 if sw else N, device=device, dtype=torch.bfloat16)
+        if name == "qkv+rope":
+            # the launch the model makes: q | k | v projection with RoPE in the epilogue (the plain projection the probe timed up to round 4
+            # is 4-5 % shorter than what runs in the step)
+            pos = torch.arange(tokens, device=device, dtype=torch.int64) % 643
+            inv = (1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float) / 128))).to(device)
+            cs, sn = ops.rope_table(pos, inv, torch.bfloat16)
+            fn = lambda: ops.linear_qkv_rope(x, w, cs, sn, 2 * D, 128, out=out)
+        else:
+            fn = lambda: ops.linear(x, w, swiglu=sw, out=out)
         for _ in range(warm):
-            ops.linear(x, w, swiglu=sw, out=out)
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.linear(x, w, swiglu=sw, out=out)
+            fn()
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / iters
         fl = 2.0 * tokens * N * K
-        per.append(dict(gemm=name, M=tokens, N=N, K=K, ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
+        rec = dict(gemm=name, M=tokens, N=N, K=K, ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1))
+        situ = in_situ.get(name) if tokens == 32 * 643 else None
+        if situ:                                                   # the same launch inside the C4 step, from the committed rocprofv3 kernel trace
+            rec["in_situ_us"] = situ["avg_us"]
+            rec["in_situ_tflops"] = round(fl / situ["avg_us"] / 1e6, 1)
+            rec["in_situ_record"] = situ["record"]
+        per.append(rec)
         tot_t += ms
         tot_f += fl
     achieved = tot_f / tot_t / 1e9

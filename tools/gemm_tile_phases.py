@@ -30,8 +30,14 @@ e0.record(); ops.linear(x, w, swiglu=sw, out=out); e1.record()
 torch.cuda.synchronize()
 assert lib.ull_debug_gemm_stamps_bf16(ctypes.c_void_p(0)) == 0
 st = stamps.cpu()
-used = st[:, 0] != 0
+used = (st[:, :6] != 0).all(dim=1)                   # a block that never reached a stamp (stream-K helper blocks, blocks of another launch's
+dropped = int((st[:, 0] != 0).sum()) - int(used.sum())  # shape) leaves zeros behind: its differences are wrapped garbage, not durations
 st = st[used]
+mono = (st[:, 1:6] >= st[:, 0:5]).all(dim=1)          # ... and so is a row whose stamps are not monotone (two launches writing the same slot)
+dropped += int((~mono).sum())
+st = st[mono]
+if dropped:
+    print(f"  ({dropped} block rows with missing / non-monotone stamps dropped)")
 print(f"M {M} N {N} K {K}{' swiglu' if sw else ''}: {int(used.sum())} blocks, launch {e0.elapsed_time(e1) * 1e3:.1f} us")
 t0 = st[:, 0].min()
 us = lambda v: float(v) / 100.0                     # 10-ns ticks -> us
