@@ -567,8 +567,14 @@ void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefi
         if (NBUF >= 4 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW) : "memory");
         else if (NBUF >= 3 && later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (timing-only ablations, wrong results: -DULL_ATTN_ABL_NO_BARRIER 302 -> 296 us, -DULL_ATTN_ABL_NO_DMA 308 -> 243 us on the C4 shape: the
+        //  step barriers cost 2 %, REQUESTING the tiles 21 % -- profiles/r05_attn_prefill_census.txt)
+#ifndef ULL_ATTN_ABL_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
+#ifndef ULL_ATTN_ABL_NO_DMA
         if (s + NBUF - 1 < total) issue(s + NBUF - 1);
+#endif
     };
 
     // ---- phase 1: S = bf16(K Q^T) (+scale, +mask), kept in registers -----------------------------------
