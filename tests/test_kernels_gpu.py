@@ -316,7 +316,9 @@ def test_attention(B, H, S, hd, causal, masked):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,S,hd,causal,masked", [(2, 3, 643, 128, True, True), (1, 2, 1000, 128, True, False), (2, 2, 130, 128, True, False),
                                                     (2, 3, 577, 64, False, False), (3, 2, 257, 64, False, False), (1, 2, 50, 64, False, False),
-                                                    (1, 2, 1500, 128, True, False), (1, 2, 196, 80, False, False), (2, 4, 11, 16, True, True)])
+                                                    (1, 2, 1500, 128, True, False), (1, 2, 196, 80, False, False), (2, 4, 11, 16, True, True),
+                                                    # every CU busy with the 8-wave forms (a block's O rows must not be staged over a tile other waves still read)
+                                                    (8, 32, 1000, 128, True, False), (32, 16, 257, 64, False, False)])
 def test_attention_takes_v_as_rows(B, H, S, hd, causal, masked, dt):
     """V handed over as rows of the fused q|k|v buffer (C-ABI vt_len = 0): the LLaMA / CLIP prefill kernels read it through the
     transposing LDS load -- same operands in the same MFMA slots as with the V^T image, so the result is identical to the last bit;

@@ -370,7 +370,11 @@ constexpr int attn_reg_nbuf() {
 //   VROW (LLaMA / CLIP prefill): the V tiles are DMA'd ROW-major from V itself ([64 keys][head dim], like the K tiles) and the V^T
 //   operand of P*V comes out of them through ds_read_b64_tr_b16: no V^T pass in front of the attention.
 template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool VROW = false>
-__global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)) ? 4 : (VROW && HDP == 128 && NT <= 11 && NWV <= 4) ? 3 : 2)
+__global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)) ? 4 : (VROW && HDP == 128 && NT <= 11 && NWV <= 4) ? 3 :
+#ifdef ULL_ATTN_NWV8_OCC4
+                                       (VROW && HDP == 128 && NT <= 11 && NWV == 8) ? 4 :
+#endif
+                                       2)
 void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefill: three blocks per CU = at most 168 registers)
     extern __shared__ __attribute__((aligned(256))) char smem[];     // (256: the V fragment addresses below XOR bits 5..7)
     static_assert(!VROW || ((FL == FL_LLAMA || FL == FL_CLIP) && HDP >= 64), "VROW: flavors that pin hd = HDP");
@@ -756,7 +760,7 @@ void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefi
         }
     }
 #ifndef ULL_ATTN_NO_LDS_EPILOGUE
-    if constexpr (VROW && !EXACT && NBUF == 2) {
+    if constexpr (VROW && !EXACT && NBUF == 2 && NWV * 16 * KROW <= TILE) {    // (the block's 16 NWV rows must fit ONE ring buffer: NWV <= 4)
         // O through LDS, stored as whole rows.  A lane holds 4 head dims of ONE query per block of 16: stored from the registers that is 8-byte
         // pieces at a row stride (every store instruction touches 16 rows x 4 x 32 B).  Instead each wave writes its 16 x hd block into
         // the ring buffer nobody reads any more (the last step lives in the other one; every wave has passed that step's barrier) and
