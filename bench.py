@@ -75,7 +75,7 @@ def init_random_(model, seed):
             p.data.normal_(0.0, 0.02, generator=g)
 
 
-DTYPE = torch.bfloat16            # --dtype fp16: the reference's evaluation dtype (a side check; the contract line is bf16)
+DTYPE = torch.bfloat16            # --dtype fp16: the reference's --dtype fp16 option (a side check; its default and the contract line are bf16)
 
 
 def build_model(image_size, device, seed=0, with_sam=False):
@@ -711,7 +711,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="fp16 = the reference's evaluation dtype (side check)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="fp16 = the reference's --dtype fp16 option (side check; default bf16 like inference_ullava.py:165)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-res", action="store_true", help="skip the C3 RES sub-record of the default (c4) run")

@@ -241,7 +241,7 @@ def _rel(a, b):
 def test_c1_full_depth_against_oracle(dt):
     """BASELINE.json configs[0] at FULL depth -- 1 x 224x224 image + 32-token prompt, S = 291, 23 CLIP + 32 LLaMA-7B layers, V = 32011, the
     very weights on both sides -- HIP forward vs the CPU oracle (same 16-bit dtype) vs the oracle in fp32, in bf16 (the reference's training
-    dtype) and fp16 (its evaluation dtype, inference_ullava.py:26):
+    dtype) and fp16 (its `--dtype fp16` option, inference_ullava.py:26,164-168; the default there is bf16):
       * hidden states 0 / 8 / 16 / 24 / 32 and the logits are as close to the fp32 truth as the oracle's own 16-bit run is (x3), the rule of
         tests/test_model_gpu.py, now through all 32 layers;
       * margin-gated exact token ids (bench.parity_stats): wherever the fp32 top-1 / top-2 gap exceeds 4 standard deviations of that
@@ -292,7 +292,7 @@ def test_c1_greedy_ids_match_oracle_where_gated(dt):
     import bench
     from oracle import ullava_oracle as O
     sd, model = _c1_fixture()
-    if dt != torch.bfloat16:                                       # fp16 (the reference's evaluation dtype): same weights rounded to fp16
+    if dt != torch.bfloat16:                                       # fp16 (the reference's --dtype fp16 option): same weights rounded to fp16
         sd = {k: v.to(dt) for k, v in sd.items()}
         with torch.no_grad():
             model = bench.c1_hip_model(sd, DEV, dtype=dt)
@@ -369,7 +369,7 @@ def test_c1_kv_cached_generate_returns_the_no_cache_last_step_states_full_depth(
     os.environ.get("ULL_SLOW_TESTS") != "1", reason="the CPU oracle's fp16 SAM ViT-H + LLaMA-7B forward takes ~5 min (measured record: "
                                                     "profiles/r04_parity_res_full_depth.json); ULL_SLOW_TESTS=1 runs it"))])
 def test_res_full_depth_against_oracle(dt):
-    """BASELINE.json configs[2] at FULL depth and batch 1 (bf16, and fp16 = the reference's evaluation dtype): ViT-L/14-224 + 32 LLaMA-7B layers + SAM ViT-H (32 blocks, d = 1280, 1024 x 1024) +
+    """BASELINE.json configs[2] at FULL depth and batch 1 (bf16, and fp16 = the reference's --dtype fp16 option): ViT-L/14-224 + 32 LLaMA-7B layers + SAM ViT-H (32 blocks, d = 1280, 1024 x 1024) +
     prompt encoder + two-way MaskDecoder + postprocess, three [SEG] / [LOC] rounds, the very weights on both sides (random init made on the
     GPU, copied to the host for the oracle): `UllavaForCausalLM.forward(inference=True)` vs `O.ullava_forward` in bf16 vs the oracle in fp32.
     SAM image embedding, LLaMA logits, mask logits (fp32 [3, 480, 640]) and boxes must be as close to the fp32 truth as the oracle's own
@@ -498,5 +498,7 @@ def test_bench_runs_with_rccl_process_group_at_one_gpu():
                         "--no-res", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert rec["n_gpus"] == 1 and rec["process_group"] == "nccl" and rec["outputs_finite"] is True
+    assert rec["n_gpus"] == 1 and rec["outputs_finite"] is True
+    assert rec["process_group"] == {"backend": "nccl", "rccl_world_size": 1, "rank": 0}          # what RCCL itself reports, not what was asked for
+    assert rec["probes"]["order"] == "after destroy_process_group" and rec["per_rank_ms_per_step"]["min"] <= rec["ms_per_step"] + 0.01
     assert rec["config"]["per_gpu_batch"] == 4 and rec["value"] > 0 and abs(rec["value"] - 4 * 2 / (rec["ms_per_step"] * 2e-3)) < 0.05 * rec["value"]
