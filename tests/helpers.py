@@ -39,6 +39,7 @@ def assert_close_bf16(a, b, ulps=2.0, floor=None, what="", outlier_frac=0.0, out
         a_, b_ = a.detach().float().cpu(), b.detach().float().cpu()
         fl = float(b_.abs().max()) * 0.02 if floor is None else floor
         bad = (a_ - b_).abs() > ulps * 2.0 ** -7 * torch.maximum(b_.abs(), torch.full_like(b_, fl))
+        print(f"{what}: {float(bad.float().mean()):.2e} of the elements beyond the tight bound (allowed {outlier_frac:.1e})")
         assert float(bad.float().mean()) <= outlier_frac, f"{what}: {int(bad.sum())}/{bad.numel()} elements beyond the tight bound"
         return assert_close_bf16(a, b, ulps, outlier_floor, what)
     """|a-b| <= ulps * 2^-7 * max(|b|, floor).  One bf16 ulp is between 2^-8 and 2^-7 of the value, so `ulps=1` admits a

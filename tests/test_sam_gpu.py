@@ -173,7 +173,8 @@ def test_sam_encoder_attention(side, hd, nH, NB):
     ops.attention(qkv, qkv[:, C:], vt, att, NB, nH, S, S, hd, strides, strides, (S * C, hd, C), None, causal=False, scale_mode=0,
                   q_scale=hd ** -0.5, rel_h=rel_h, rel_w=rel_w)
     vmax = float(qkv[:, 2 * C:].float().abs().max())
-    frac = 2e-3 if S <= 1024 else 6e-3
+    # measured on MI355X (round 5, printed on every run): windows 0, global hd 80: 3.3e-3 of the elements beyond the 2-ulp bound, global hd 32: 0
+    frac = 5e-4 if S <= 1024 else 4.5e-3
     assert_close_bf16(att, ref, ulps=2.0, what=f"sam attention side={side}", outlier_frac=frac, outlier_floor=vmax)
     truth = O.sam_attention({k: v.float() for k, v in sd.items()}, "", x.float(), nH).reshape(NB * S, C)
     e_ours = float((att.float().cpu() - truth).pow(2).mean().sqrt())
