@@ -327,3 +327,35 @@ def test_fp16_neck_runs_in_fp32_where_an_fp16_neck_overflows():
         print(f"overflow case, sample {i}: mask err vs oracle {em:.2e}")
         RESULTS.append(dict(test="fp16_neck_overflow_case", sample=i, mask_vs_oracle=em, neck0_scale=scale))
         assert em <= 4e-3
+
+
+def test_sam_global_attention_fp16_rows_form_equals_vt_form():
+    """SAM global attention (64 x 64 grid, hd 80) in fp16: the 32-query `sam_global_kernel` (V handed over as rows of q|k|v) against the 16-query
+    streaming kernel on the V^T image -- the same arithmetic per query, identical bits -- and both against the eager recipe."""
+    ops = pkg("ops")
+    side, hd, nH, NB = 64, 80, 2, 2
+    S, C = side * side, nH * hd
+    g = torch.Generator().manual_seed(21)
+    qkv = (0.5 * torch.randn(NB * S, 3 * C, generator=g)).to(H).to(DEV)
+    rph = (0.3 * torch.randn(2 * side - 1, hd, generator=g)).to(H).to(DEV)
+    rpw = (0.3 * torch.randn(2 * side - 1, hd, generator=g)).to(H).to(DEV)
+    st = (S * 3 * C, hd, 3 * C)
+    vt = ops.transpose_v(qkv[:, 2 * C:], S * 3 * C, 3 * C, NB, S, nH, hd)
+    a = torch.empty(NB * S, C, device=DEV, dtype=H)
+    b = torch.full((NB * S, C), float("nan"), device=DEV, dtype=H)
+    kw = dict(causal=False, scale_mode=0, q_scale=hd ** -0.5, rel_h=rph, rel_w=rpw, rel_pos_hw=(side, side))
+    ops.attention(qkv, qkv[:, C:], vt, a, NB, nH, S, S, hd, st, st, (S * C, hd, C), None, **kw)
+    ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], b, NB, nH, S, S, hd, st, st, (S * C, hd, C), None, v_strides=st, **kw)
+    assert torch.equal(a, b)
+    x = qkv.cpu().view(NB, S, 3, nH, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0].float(), x[1].float(), x[2].float()
+    sd = {"rel_pos_h": rph.cpu().float(), "rel_pos_w": rpw.cpu().float()}
+    att = (q * hd ** -0.5) @ k.transpose(-1, -2)
+    Rh, Rw = O.get_rel_pos(side, side, sd["rel_pos_h"]), O.get_rel_pos(side, side, sd["rel_pos_w"])
+    rq = q.reshape(NB * nH, side, side, hd)
+    att = (att.view(NB * nH, side, side, side, side) + torch.einsum("bhwc,hkc->bhwk", rq, Rh)[:, :, :, :, None] +
+           torch.einsum("bhwc,wkc->bhwk", rq, Rw)[:, :, :, None, :]).view(NB, nH, S, S)
+    ref = (att.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(NB * S, C)
+    e = float((b.float().cpu() - ref).abs().max()) / float(ref.abs().max())
+    print("fp16 SAM global attention vs fp32 recipe:", e)
+    assert e < 4e-3
