@@ -2363,7 +2363,7 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
             if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16 &&
                 64 * a.k_ss * 2 < (1L << 31) && 64 * a.vt_ds * 2 < (1L << 31)) {       // (32-bit per-lane DMA offsets inside a tile)
 #ifndef ULL_SAMG_OLD
-                if ((a.Sq & 127) == 0 && a.hd == 80 && !a.key_mask && !a.causal) return launch_sam_global(a, st);
+                if ((a.Sq & 127) == 0 && a.Sq == a.Sk && a.hd == 80 && !a.key_mask && !a.causal) return launch_sam_global(a, st);   // (queries = the key grid)
 #endif
                 return launch_stream<128, FL_SAM_ENC, 2, true>(a, st);
             }
