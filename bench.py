@@ -613,8 +613,9 @@ def timed_steps(step, steps, warmup, dist, batch, device):
     sync()
     elapsed = time.perf_counter() - t0
     check_finite(last)                                                        # outside the timed region: the last step's outputs
-    rate, total, t_max = D.global_rate(float(batch * steps), elapsed, device=device)     # (images/s whole job, images, max elapsed)
-    lo, hi = D.elapsed_spread(busy, device=device)                            # fastest / slowest rank's own time: where skew comes from
+    agg_dev = torch.device("cpu") if (dist is not None and dist.get_backend() == "gloo") else device
+    rate, total, t_max = D.global_rate(float(batch * steps), elapsed, device=agg_dev)    # (images/s whole job, images, max elapsed)
+    lo, hi = D.elapsed_spread(busy, device=agg_dev)                           # fastest / slowest rank's own time: where skew comes from
     return rate, total, t_max, {"min": round(lo / steps * 1e3, 3), "max": round(hi / steps * 1e3, 3)}
 
 
@@ -721,6 +722,7 @@ def main():
     ap.add_argument("--init-pg", action="store_true", help="initialise the process group (RCCL) even at --gpus 1, so that the barrier and the "
                     "two scalar all-reduces of the aggregation run through RCCL on a single-GPU box")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to CPU sets")
+    ap.add_argument("--share-gpu", action="store_true", help="tests only: rank r computes on cuda:(r %% device_count); needs --backend gloo")
     ap.add_argument("--train-config", default="full", choices=sorted(TRAIN_CONFIGS), help="--workload train: which trainable set / batch")
     a = ap.parse_args()
     global DTYPE
@@ -735,11 +737,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
+    if a.share_gpu and a.backend != "gloo":
+        raise SystemExit("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
     if a.stub:
         dev = torch.device("cpu")
     else:
-        torch.cuda.set_device(local)
-        dev = torch.device("cuda", local)
+        # --share-gpu (tests only, with --backend gloo): the ranks run their real HIP steps on the devices there are (a 1-GPU box: all on
+        # cuda:0; RCCL refuses two ranks on one device, gloo carries the barrier and the scalar aggregation instead)
+        gpu = local % torch.cuda.device_count() if a.share_gpu else local
+        torch.cuda.set_device(gpu)
+        dev = torch.device("cuda", gpu)
     affinity = None if a.no_pin else pin_rank_to_cpus(local, world, use_gpu_topology=not a.stub)
     dist = None
     if world > 1 or a.init_pg:

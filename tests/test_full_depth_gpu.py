@@ -502,3 +502,26 @@ def test_bench_runs_with_rccl_process_group_at_one_gpu():
     assert rec["process_group"] == {"backend": "nccl", "rccl_world_size": 1, "rank": 0}          # what RCCL itself reports, not what was asked for
     assert rec["probes"]["order"] == "after destroy_process_group" and rec["per_rank_ms_per_step"]["min"] <= rec["ms_per_step"] + 0.01
     assert rec["config"]["per_gpu_batch"] == 4 and rec["value"] > 0 and abs(rec["value"] - 4 * 2 / (rec["ms_per_step"] * 2e-3)) < 0.05 * rec["value"]
+
+
+def test_bench_two_ranks_with_real_steps_on_one_gpu():
+    """The N > 1 protocol of `bench.py` with REAL HIP steps: two ranks launched by the script itself (`--gpus 2`), both computing on cuda:0
+    (`--share-gpu`; RCCL refuses two ranks on one device -- profiles/r04_rccl_two_ranks_one_gpu.txt -- so gloo carries the barriers and the
+    scalar aggregation), C2 at batch 4, timed regions for C2 only.  The line must report two ranks seen by the collective layer, the SUM of
+    the ranks' images over the MAX of their times, the per-rank range, and the probes after the process group is gone."""
+    env = _env()
+    for k in ("MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--workload", "c2",
+                        "--batch", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-pin"],
+                       capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["process_group"] == {"backend": "gloo", "rccl_world_size": 2, "rank": 0}
+    assert rec["config"]["per_gpu_batch"] == 4 and rec["config"]["global_batch"] == 8 and rec["outputs_finite"] is True
+    sp = rec["per_rank_ms_per_step"]
+    assert 0 < sp["min"] <= sp["max"] <= rec["ms_per_step"] + 0.01
+    assert abs(rec["value"] - 8 * 3 / (rec["ms_per_step"] * 3e-3)) < 0.05 * rec["value"]            # SUM(images) / MAX(elapsed)
+    assert rec["probes"]["order"] == "after destroy_process_group"
