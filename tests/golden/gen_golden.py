@@ -432,6 +432,8 @@ def gen_sam_blocks(name, dtype, seed):
     sd32 = W.seeded_state_dict(shapes, seed, torch.float32)
     enc.load_state_dict({k[len("visual_model.image_encoder."):]: v for k, v in sd32.items()}, strict=True)
     enc.to(dtype)
+    if dtype == torch.float16:
+        _emulate_fp16_neck_autocast(enc)          # image_encoder.py:117-124 at the REAL widths (1280 -> 256, 3x3 over 2304): fp32 neck
     sd = {k: v.to(dtype) for k, v in sd32.items()}
     g = torch.Generator().manual_seed(seed + 29)
     img = torch.randn(1, 3, 1024, 1024, generator=g).to(dtype)
@@ -741,6 +743,8 @@ if __name__ == "__main__":
         gen_full("g8_full_tiny_fp16.pt", torch.float16, 8)
     if want("samblocks"):
         gen_sam_blocks("g9_sam_blocks_bf16.pt", torch.bfloat16, 9)
+    if want("samblocks16"):
+        gen_sam_blocks("g9_sam_blocks_fp16.pt", torch.float16, 9)
     if want("perop"):
         gen_per_op("g6_per_op_bf16.pt", torch.bfloat16, 6)
         gen_per_op("g6_per_op_fp16.pt", torch.float16, 6)

@@ -123,12 +123,15 @@ def test_training_losses_g10(name):
         assert torch.equal(ol[k].float(), ref), k
 
 
-def test_sam_encoder_blocks_g9():
-    """one windowed + one global ViT-H block at d=1280 on a 1024x1024 image (patch embed, pos embed, rel-pos bias, neck)."""
-    fx = load_fixture("g9_sam_blocks_bf16.pt")
+@pytest.mark.parametrize("name,dt", [("g9_sam_blocks_bf16.pt", torch.bfloat16), ("g9_sam_blocks_fp16.pt", torch.float16)])
+def test_sam_encoder_blocks_g9(name, dt):
+    """one windowed + one global ViT-H block at d=1280 on a 1024x1024 image (patch embed, pos embed, rel-pos bias, neck).  The fp16 fixture
+    pins the fp32 neck of image_encoder.py:117-124 at the real widths (reference modules promoted to fp32: see gen_golden._AutocastFp32Neck)."""
+    fx = load_fixture(name)
+    assert fx["dtype"] == str(dt) and (dt != torch.float16 or "fp16_neck" in fx["meta"])
     sd = fixture_state_dict(fx)
     g = torch.Generator().manual_seed(fx["image_seed"])
-    img = torch.randn(1, 3, 1024, 1024, generator=g).to(torch.bfloat16)
+    img = torch.randn(1, 3, 1024, 1024, generator=g).to(dt)
     torch.set_num_threads(8)
     o = O.sam_image_encoder(sd, fx["cfg"], img)
     _eq(o[:, ::2, ::2, ::2].contiguous(), fx["embedding_sample"])
