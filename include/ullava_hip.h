@@ -38,6 +38,8 @@ extern "C" {
 #define ULL_EPI_RESID 8                 /* out = bf16(R + bf16(linear)) : residual adds of LlamaDecoderLayer / CLIPEncoderLayer */
 #define ULL_EPI_SWIGLU 16               /* W = gate/up rows interleaved in groups of 16; out[N/2] = silu(gate)*up (hf: LlamaMLP.forward) */
 #define ULL_EPI_OUT_F32 32              /* C is float32 */
+#define ULL_EPI_W_TILED 64                /* W stored tile-major (see below) */
+#define ULL_EPI_X_TILED 128               /* X stored tile-major */
 #define ULL_EPI_BIAS_ROUNDED 256        /* with ULL_EPI_BIAS: out = round(round(X W^T) + bias), at::linear's unfused matmul + add_ path
                                          * (non-contiguous 3-D input: SAM TwoWayTransformer layer 0 k/v/q projections of the image keys) */
 
@@ -420,6 +422,67 @@ int ull_adamw_step_f32(void* master, void* m, void* v, const void* grad, int gra
 /* out[0] (fp32 on the device, caller-zeroed) += sum of squares of n gradient elements: the local part of clip_grad_norm_'s total norm. */
 int ull_sumsq_f32(const void* g, int grad_dtype, int64_t n, void* out, void* stream);
 
+/* ---- coarse entries (round 6): ONE call enqueues a whole stack of layers on the stream --------------------------------------------------
+ * Host-side composition of the per-op entries above (u-llava_amd/csrc/layers.hip holds no kernel): the same launches, the same dispatch rules
+ * as the per-op path, bit-identical results; what they remove is a host round trip per launch (8 Python ranks share one host).
+ * A Linear is described once: */
+typedef struct ull_linear {
+    const void* w;       /* [n, k] row-major, row pitch ldw (what the GEMV / skinny kernels and the 128 x 128 GEMM read) */
+    const void* w_tiled; /* its ULL_EPI_W_TILED copy for the 256 x 256 kernel, or NULL */
+    const void* bias;    /* [n] or NULL */
+    int64_t n, k, ldw;
+} ull_linear;
+typedef struct ull_llama_layer { /* hf LlamaDecoderLayer: input_layernorm, q|k|v (one [3D, D] matrix), o_proj, post_attention_layernorm, gate|up */
+    const void* ln1;             /* (interleaved in 16-row groups, ULL_EPI_SWIGLU), down_proj */
+    const void* ln2;
+    ull_linear qkv, o, gu, down;
+} ull_llama_layer;
+typedef struct ull_clip_layer { /* hf CLIPEncoderLayer: layer_norm1, q|k|v (one [3D, D] matrix + bias), out_proj, layer_norm2, fc1 (quick_gelu), fc2 */
+    const void *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    ull_linear qkv, out, fc1, fc2;
+} ull_clip_layer;
+typedef struct ull_sam_block { /* image_encoder.py:128-193 Block: norm1, attn.qkv, attn.proj, norm2, mlp.lin1 (GELU), mlp.lin2 */
+    const void *n1_w, *n1_b, *n2_w, *n2_b;
+    ull_linear qkv, proj, lin1, lin2;
+    const void* rel_pos_h; /* [2 * side - 1, hd] with side = window (14) or the grid (64): already resized to that length */
+    const void* rel_pos_w;
+    int64_t window;        /* 14, or 0 = global attention */
+} ull_sam_block;
+
+/* hf LlamaModel.forward's layer loop at prefill shapes (modeling_llama.py:347-419 via models/ullava_core.py:312-322): per layer RMSNorm ->
+ * q|k|v GEMM with RoPE epilogue -> causal attention on the fused q|k|v buffer -> o_proj + residual -> RMSNorm -> gate|up GEMM + SwiGLU ->
+ * down_proj + residual.  x_in [T = B * S, D] is read only; layer l's output goes to x_out[l] ([T, D]; pointers may repeat, an entry must not
+ * alias x_in while x_in is still the layer's input, i.e. for l = 0); x_mid [T, D], xn [T, D], qkv [T, 3D], att [T, D], act [T, I] are scratch.
+ * rope_cos / rope_sin [T, 64] from ull_rope_table_bf16; key_mask int32 [B, S] or NULL.  hd = 128, 16 < S <= 1024, D % 64 == 0 (anything else:
+ * ULL_ERR_SHAPE -- use the per-op entries).  ws / ws_bytes / sk_min_k: the stream-K policy of ull_gemm_bf16 (split where K >= sk_min_k;
+ * sk_min_k < 0 = never). */
+int ull_llama_prefill_layers_bf16(const ull_llama_layer* layers, int64_t n_layers, const void* x_in, void* const* x_out, void* x_mid, void* xn,
+                                  void* qkv, void* att, void* act, const void* rope_cos, const void* rope_sin, const void* key_mask, int64_t B,
+                                  int64_t S, int64_t H, int64_t hd, int64_t I, float eps, void* ws, int64_t ws_bytes, int64_t sk_min_k,
+                                  const void* zeros, void* stream);
+
+/* The same loop for generation steps (T = B * S <= 4 new tokens on a filled KV cache; models/ullava_core.py:357-395): per layer
+ * ull_gemv_qkv_rope_append_bf16 -> split-key attention over the cache -> o_proj -> RMSNorm + gate|up + SwiGLU -> down_proj, the GEMV / skinny-GEMM
+ * choice per Linear as in the per-op path.  k_cache[l] [B, H, smax, hd], vt_cache[l] [B, H, hd, smax] (permuted, see ull_transpose_v_bf16);
+ * q [T, D], att [T, D], xn [T, max(D, I)], act [T, I], x_mid [T, D] scratch; rope tables [T, hd / 2] of the step's positions. */
+int ull_llama_decode_layers_bf16(const ull_llama_layer* layers, int64_t n_layers, const void* x_in, void* const* x_out, void* x_mid, void* xn,
+                                 void* q, void* att, void* act, const void* rope_cos, const void* rope_sin, const void* key_mask,
+                                 void* const* k_cache, void* const* vt_cache, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t I, int64_t smax,
+                                 int64_t past, float eps, const void* zeros, void* stream);
+
+/* hf CLIPEncoder.forward's layer loop (modeling_clip.py:353-384; models/ullava_core.py:146-158 reads hidden_states[-2], so the caller passes
+ * the first 23 layers): h [T = n_img * S, D] is updated in place; h_mid [T, D], y [T, D], qkv [T, 3D], att [T, D], f [T, I] scratch.
+ * hd = 64, 16 < S <= 704. */
+int ull_clip_layers_bf16(const ull_clip_layer* layers, int64_t n_layers, void* h, void* h_mid, void* y, void* qkv, void* att, void* f, int64_t n_img,
+                         int64_t S, int64_t H, int64_t hd, int64_t I, float eps, void* ws, int64_t ws_bytes, int64_t sk_min_k, const void* zeros,
+                         void* stream);
+
+/* ImageEncoderViT.forward's block loop (image_encoder.py:110-116; Block.forward :165-193) on image-order tokens x [B * g * g, C], in place:
+ * 14 x 14 window blocks through ull_sam_window_attention_bf16, global blocks through ull_attention_bf16 (rel_mode 2).  g = 64, hd = 80. */
+int ull_sam_blocks_bf16(const ull_sam_block* blocks, int64_t n_blocks, void* x, void* x_mid, void* y, void* qkv, void* att, void* f, int64_t B,
+                        int64_t g, int64_t nH, int64_t hd, int64_t I, float eps, void* ws, int64_t ws_bytes, int64_t sk_min_k, const void* zeros,
+                        void* stream);
+
 /* ==== BEGIN fp16 twins (generated by tools/gen_header_f16.py) ==== */
 /* IEEE binary16 build of every dtype-dependent entry point: same arguments, layouts, flags and rounding points as the *_bf16
  * function of the same name; every 16-bit element is an fp16 instead of a bf16 (the reference's `--dtype fp16`,
@@ -478,6 +541,10 @@ int ull_mask_matmul_bwd_f16(const void* hyper, const void* up, const void* dmask
 int ull_sum_slabs_f16(const void* x, void* out, int64_t R, int64_t n, float scale, void* stream);
 int ull_colsum_f16(const void* x, int64_t ld, int64_t rows, int64_t N, void* out, void* stream);
 int ull_transpose2d_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t R, int64_t C, void* stream);
+int ull_llama_prefill_layers_f16(const ull_llama_layer* layers, int64_t n_layers, const void* x_in, void* const* x_out, void* x_mid, void* xn, void* qkv, void* att, void* act, const void* rope_cos, const void* rope_sin, const void* key_mask, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t I, float eps, void* ws, int64_t ws_bytes, int64_t sk_min_k, const void* zeros, void* stream);
+int ull_llama_decode_layers_f16(const ull_llama_layer* layers, int64_t n_layers, const void* x_in, void* const* x_out, void* x_mid, void* xn, void* q, void* att, void* act, const void* rope_cos, const void* rope_sin, const void* key_mask, void* const* k_cache, void* const* vt_cache, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t I, int64_t smax, int64_t past, float eps, const void* zeros, void* stream);
+int ull_clip_layers_f16(const ull_clip_layer* layers, int64_t n_layers, void* h, void* h_mid, void* y, void* qkv, void* att, void* f, int64_t n_img, int64_t S, int64_t H, int64_t hd, int64_t I, float eps, void* ws, int64_t ws_bytes, int64_t sk_min_k, const void* zeros, void* stream);
+int ull_sam_blocks_f16(const ull_sam_block* blocks, int64_t n_blocks, void* x, void* x_mid, void* y, void* qkv, void* att, void* f, int64_t B, int64_t g, int64_t nH, int64_t hd, int64_t I, float eps, void* ws, int64_t ws_bytes, int64_t sk_min_k, const void* zeros, void* stream);
 /* ==== END fp16 twins ==== */
 
 #ifdef __cplusplus

@@ -99,6 +99,9 @@ def build_reference(full, dtype):
             setattr(mod, leaf, inv.float().clone())            # fp32, as a from_pretrained(torch_dtype=...) load leaves it (see gen_golden.load_seeded)
         elif leaf == "position_ids":
             setattr(mod, leaf, torch.arange(buf.shape[-1]).expand((1, -1)))
+        elif leaf in ("pixel_mean", "pixel_std"):               # Sam's input normalisation constants (build_sam.py:100-101; unused on this path)
+            vals = [123.675, 116.28, 103.53] if leaf == "pixel_mean" else [58.395, 57.12, 57.375]
+            setattr(mod, leaf, torch.tensor(vals).view(-1, 1, 1).to(buf.dtype))
         else:
             raise RuntimeError(f"non-persistent buffer {name} has no rebuild rule")
     log(f"reference built: {n / 1e9:.3f} B parameters in {dtype}")

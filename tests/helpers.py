@@ -82,7 +82,7 @@ def run_core_fixture(name, device="cuda:0"):
     e_hip = rel_err(out.logits, truth["logits"])
     stats = dict(logits_err_vs_ref=rel_err(out.logits, fx["logits"]), ref_err_vs_fp32=e_ref, hip_err_vs_fp32=e_hip,
                  hidden_err_vs_ref=[round(rel_err(h, r), 5) for h, r in zip(out.hidden_states, fx["hidden_states"])],
-                 tol=max(3.0 * e_ref, 2.0 ** -6))
+                 tol=max(1.5 * e_ref, 2.0 ** -6))
     if "greedy_prompt" in fx:
         seq = model.generate(input_ids=fx["greedy_prompt"].to(device), images=images[:1], max_new_tokens=8, do_sample=False)
         stats["greedy_equal"] = bool(torch.equal(seq.cpu(), fx["greedy_sequences"]))

@@ -1,7 +1,7 @@
 """GPU: the HIP backward kernels (csrc/backward.hip + Linear backward as transposed-operand GEMMs) against torch autograd of the
 oracle's ops on the CPU, and the full training path of UllavaCoreForCausalLM against the reference's gradients (G12 fixtures,
 tests/golden/gen_golden.py::gen_core_grads).  Tolerance: gradients are compared in relative L2 norm; for the model-level test the
-HIP bf16 gradients must be as close to the reference's fp32 gradients as the reference's own bf16 backward is (x3)."""
+HIP bf16 gradients must be as close to the reference's fp32 gradients as the reference's own bf16 backward is (x1.5)."""
 import math
 import os
 
@@ -152,7 +152,7 @@ def test_cross_entropy_and_embedding_backward():
 def test_core_training_path_matches_reference_gradients_g12():
     """UllavaCoreForCausalLM.forward(labels=...).loss.backward() on the HIP path vs the reference's loss.backward():
     same loss as the inference path, every trainable parameter gets a gradient, and each gradient is as close to the reference's
-    fp32 gradient as the reference's own bf16 backward is (x3; floor 2 %)."""
+    fp32 gradient as the reference's own bf16 backward is (x1.5; floor 2 %)."""
     from helpers import core_model_from_fixture
     fx, fx32 = load_fixture("g12_core_grads_bf16.pt"), load_fixture("g12_core_grads_fp32.pt")
     model, sd = core_model_from_fixture(fx, DEV)
@@ -174,7 +174,7 @@ def test_core_training_path_matches_reference_gradients_g12():
         e_ref, e_hip = rel_l2(fx["grads"][n], truth), rel_l2(g, truth)
         cos = float(F.cosine_similarity(g.float().cpu().flatten(), truth.flatten(), dim=0))
         print(f"{n:55s} HIP {e_hip:.4f}  reference-bf16 {e_ref:.4f}  cos {cos:.5f}")
-        assert e_hip <= max(3.0 * e_ref, 0.02), n
+        assert e_hip <= max(1.5 * e_ref, 0.02), n
         assert cos >= 0.999, n
         worst = max(worst, e_hip)
     print("worst relative L2 error of a HIP gradient vs the fp32 reference gradient:", worst)
@@ -209,7 +209,7 @@ def test_embedding_gradient_routing_matches_reference_g14(stage):
         assert g is not None, n
         e_ref, e_hip = rel_l2(fx["grads"][n], truth), rel_l2(g, truth)
         print(f"{stage} {n:40s} HIP {e_hip:.4f} reference-bf16 {e_ref:.4f}")
-        assert e_hip <= max(3.0 * e_ref, 0.02), n
+        assert e_hip <= max(1.5 * e_ref, 0.02), n
     for n, nrm in fx32["grad_norms"].items():
         g = dict(model.named_parameters())[n].grad
         assert g is not None and abs(float(g.float().norm()) - nrm) <= 0.05 * nrm + 1e-6, n
@@ -296,7 +296,7 @@ def test_full_training_path_matches_reference_gradients_g13():
     """UllavaForCausalLM.forward(inference=False)['loss'].backward() on the HIP path (language model, projector, seg / det heads, SAM mask
     decoder through postprocess and the BCE / dice / L1 / GIoU losses) vs the reference's gradients (G13): loss value, the set of
     parameters that receive a gradient, and per-parameter closeness to the reference's fp32 gradients -- at least as good as the
-    reference's own bf16 backward (x3, floor 3 %) on the strided samples, and matching L2 norms."""
+    reference's own bf16 backward (x1.5, floor 3 %) on the strided samples, and matching L2 norms."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_sam_gpu import _full_model
@@ -332,7 +332,7 @@ def test_full_training_path_matches_reference_gradients_g13():
             continue
         e_norm = abs(float(got[n].float().norm()) - nrm32) / max(nrm32, 1e-12)
         e_norm_ref = abs(fx["grad_norms"][n] - nrm32) / max(nrm32, 1e-12)
-        assert e_norm <= max(3.0 * e_norm_ref, 0.03), (n, e_norm, e_norm_ref)
+        assert e_norm <= max(1.5 * e_norm_ref, 0.03), (n, e_norm, e_norm_ref)
     for n, rec in fx32["grads"].items():
         if n in noise:
             continue
@@ -341,7 +341,7 @@ def test_full_training_path_matches_reference_gradients_g13():
         e_ref, e_hip = rel_l2(fx["grads"][n]["sample"], truth), rel_l2(mine, truth)
         if e_hip > worst[1]:
             worst = (n, e_hip)
-        assert e_hip <= max(3.0 * e_ref, 0.03), (n, e_hip, e_ref)
+        assert e_hip <= max(1.5 * e_ref, 0.03), (n, e_hip, e_ref)
     print("worst sampled gradient:", worst)
 
 

@@ -206,7 +206,7 @@ def test_full_forward_fp16_fixture_g8():
     valid = fx["attention_mask"].bool()
     el = rel_err(out["logits"].cpu()[valid], fx["logits"][valid])
     print("fp16 logits err vs reference", el)
-    assert el < 4e-3
+    assert el < 2.5e-3                                          # measured 1.5e-3 (round 6: was 4e-3)
     assert [m.shape[0] for m in out["pred_masks"]] == [2, 1] and [b.shape[0] for b in out["pred_boxes"]] == [1, 2]
     for i in range(2):
         ref = fx["pred_mask_samples"][i]
@@ -214,7 +214,7 @@ def test_full_forward_fp16_fixture_g8():
         eb = rel_err(out["pred_boxes"][i], fx["pred_boxes"][i])
         print(f"fp16 sample {i}: mask err {em:.2e} box err {eb:.2e}")
         RESULTS.append(dict(test="g8_fp16", sample=i, mask_vs_reference=em, box_vs_reference=eb, logits=el))
-        assert em <= 4e-3 and eb <= 2e-3
+        assert em <= 2e-3 and eb <= 2e-3                          # measured 1.15-1.21e-3 / <= 1.3e-3 (round 6: masks were 4e-3)
 
 
 def test_core_forward_fp16_vs_oracle_and_greedy_ids():
@@ -319,14 +319,14 @@ def test_fp16_neck_runs_in_fp32_where_an_fp16_neck_overflows():
                 resize_list=fx["resize_list"], bbox_list=[None, None], inference=True)
     ee = rel_err(eng_emb.view(2, 64, 64, -1).permute(0, 3, 1, 2), emb)
     print("fp16 model, fp32 neck: image embedding err vs oracle", ee)
-    assert ee < 4e-3
+    assert ee < 2e-3                                            # measured 1.24e-3
     for i in range(2):
         pm = out["pred_masks"][i].cpu()
         assert bool(torch.isfinite(pm).all()), "masks must stay finite"
         em = float((pm - o["pred_masks"][i]).abs().max()) / float(o["low_res_masks"][i].float().abs().max())
         print(f"overflow case, sample {i}: mask err vs oracle {em:.2e}")
         RESULTS.append(dict(test="fp16_neck_overflow_case", sample=i, mask_vs_oracle=em, neck0_scale=scale))
-        assert em <= 4e-3
+        assert em <= 2.5e-3                                       # measured 1.7-1.9e-3 (an fp16 neck that overflows: larger activations)
 
 
 def test_sam_global_attention_fp16_rows_form_equals_vt_form():

@@ -20,7 +20,7 @@ import sys
 import pytest
 import torch
 
-from helpers import pkg
+from helpers import load_fixture, pkg
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -175,8 +175,8 @@ def test_c4_c5_shapes_full_depth_against_oracle(case):
     e0_ref, e0_hip = _rel(ref["hidden_states"][0], truth["hidden_states"][0]), _rel(out.hidden_states[0], truth["hidden_states"][0])
     st = bench.parity_stats(out.logits[0], ref["logits"][0], truth["logits"][0])
     print(f"{case} full depth vs oracle:", json.dumps(dict(S=int(ids.shape[1]), spliced_embeds=dict(oracle_bf16_err=round(e0_ref, 5), hip_err=round(e0_hip, 5)), logits=st)))
-    assert e0_hip <= max(3.0 * e0_ref, 2.0 ** -7)                # the CLIP tower + projector + splice (hidden state 0)
-    assert st["hip_err_vs_fp32"] <= max(3.0 * st["oracle_err_vs_fp32"], 2.0 ** -6)
+    assert e0_hip <= max(1.5 * e0_ref, 2.0 ** -7)                # the CLIP tower + projector + splice (hidden state 0)
+    assert st["hip_err_vs_fp32"] <= max(1.5 * st["oracle_err_vs_fp32"], 2.0 ** -6)
     assert st["gated_exact"] and st["positions_gated"] >= st["positions"] // 10, st
     assert st["hip_rms_vs_fp32"] <= 1.25 * st["oracle_rms_vs_fp32"], st
     if case == "c4_336":
@@ -242,7 +242,7 @@ def test_c1_full_depth_against_oracle(dt):
     """BASELINE.json configs[0] at FULL depth -- 1 x 224x224 image + 32-token prompt, S = 291, 23 CLIP + 32 LLaMA-7B layers, V = 32011, the
     very weights on both sides -- HIP forward vs the CPU oracle (same 16-bit dtype) vs the oracle in fp32, in bf16 (the reference's training
     dtype) and fp16 (its `--dtype fp16` option, inference_ullava.py:26,164-168; the default there is bf16):
-      * hidden states 0 / 8 / 16 / 24 / 32 and the logits are as close to the fp32 truth as the oracle's own 16-bit run is (x3), the rule of
+      * hidden states 0 / 8 / 16 / 24 / 32 and the logits are as close to the fp32 truth as the oracle's own 16-bit run is (x1.5), the rule of
         tests/test_model_gpu.py, now through all 32 layers;
       * margin-gated exact token ids (bench.parity_stats): wherever the fp32 top-1 / top-2 gap exceeds 4 standard deviations of that
         position's 16-bit noise on a logit difference, argmax(HIP) == argmax(oracle 16-bit) == argmax(fp32) -- and a meaningful share of the
@@ -266,11 +266,11 @@ def test_c1_full_depth_against_oracle(dt):
     for li in (0, 8, 16, 24, 32):
         e_ref, e_hip = _rel(ref["hidden_states"][li], truth["hidden_states"][li]), _rel(out.hidden_states[li], truth["hidden_states"][li])
         rec[f"hidden_{li}"] = dict(oracle_16bit_err=round(e_ref, 5), hip_err=round(e_hip, 5), hip_vs_oracle=round(_rel(out.hidden_states[li], ref["hidden_states"][li]), 5))
-        assert e_hip <= max(3.0 * e_ref, 2.0 ** -7), (li, e_hip, e_ref)
+        assert e_hip <= max(1.5 * e_ref, 2.0 ** -7), (li, e_hip, e_ref)
     st = bench.parity_stats(out.logits[0], ref["logits"][0], truth["logits"][0])
     rec["logits"] = st
     print(f"C1 full depth vs oracle ({dt}):", json.dumps(rec))
-    assert st["hip_err_vs_fp32"] <= max(3.0 * st["oracle_err_vs_fp32"], 2.0 ** -6)
+    assert st["hip_err_vs_fp32"] <= max(1.5 * st["oracle_err_vs_fp32"], 2.0 ** -6)
     assert st["gated_exact"], st                                   # token ids EQUAL wherever the margin clears the 16-bit noise
     assert st["positions_gated"] >= 29, st                         # ... which is not a vacuous set (>= 10 % of the positions)
     # (all positions, gated or not: the HIP run agrees with the fp32 truth at least as often as the oracle's own 16-bit run does, minus 3 %)
@@ -334,7 +334,7 @@ def test_c1_kv_cached_generate_returns_the_no_cache_last_step_states_full_depth(
     8 greedy steps, `keep_last_step_only=True` (what evaluate() passes):
       * shape [1, L - 1, 4096]; the prefill rows are BIT-identical to a HIP forward over sequences[:, :-1];
       * the decode rows (GEMV kernels, a different fp32 summation order) and the whole tensor are as close to the oracle's fp32 forward over
-        the same ids as the oracle's own bf16 forward is (x3 rule);
+        the same ids as the oracle's own bf16 forward is (x1.5 rule);
       * the no-cache generate() returns the forward's tensor bit for bit."""
     import bench
     from oracle import ullava_oracle as O
@@ -362,21 +362,24 @@ def test_c1_kv_cached_generate_returns_the_no_cache_last_step_states_full_depth(
     print("C1 evaluate() states, KV cache vs forward vs oracle:", json.dumps(dict(
         oracle_bf16_err=round(e_ref, 5), hip_kv_err=round(e_kv, 5), hip_forward_err=round(e_fwd, 5), decode_rows_oracle_err=round(e_dec_ref, 5),
         decode_rows_hip_kv_err=round(e_dec_kv, 5), kv_vs_forward_decode_rows=round(_rel(h_kv[:, L0:], fwd[:, L0:]), 5))))
-    assert e_kv <= max(3.0 * e_ref, 2.0 ** -7) and e_dec_kv <= max(3.0 * e_dec_ref, 2.0 ** -7)
+    assert e_kv <= max(1.5 * e_ref, 2.0 ** -7) and e_dec_kv <= max(1.5 * e_dec_ref, 2.0 ** -7)
 
 
-@pytest.mark.parametrize("dt", [torch.bfloat16, pytest.param(torch.float16, marks=pytest.mark.skipif(
-    os.environ.get("ULL_SLOW_TESTS") != "1", reason="the CPU oracle's fp16 SAM ViT-H + LLaMA-7B forward takes ~5 min (measured record: "
-                                                    "profiles/r04_parity_res_full_depth.json); ULL_SLOW_TESTS=1 runs it"))])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_res_full_depth_against_oracle(dt):
     """BASELINE.json configs[2] at FULL depth and batch 1 (bf16, and fp16 = the reference's --dtype fp16 option): ViT-L/14-224 + 32 LLaMA-7B layers + SAM ViT-H (32 blocks, d = 1280, 1024 x 1024) +
     prompt encoder + two-way MaskDecoder + postprocess, three [SEG] / [LOC] rounds, the very weights on both sides (random init made on the
     GPU, copied to the host for the oracle): `UllavaForCausalLM.forward(inference=True)` vs `O.ullava_forward` in bf16 vs the oracle in fp32.
     SAM image embedding, LLaMA logits, mask logits (fp32 [3, 480, 640]) and boxes must be as close to the fp32 truth as the oracle's own
-    bf16 run is (x3, with a floor of a few bf16 ulps) -- the C3 path against the oracle at the size bench.py times it, not only through
+    bf16 run is (x1.5, with a floor of a few bf16 ulps) -- the C3 path against the oracle at the size bench.py times it, not only through
     properties."""
     import bench
     from oracle import ullava_oracle as O
+    if dt == torch.float16:
+        # fp16 (the reference's --dtype fp16 option): the CPU oracle's fp16 SAM ViT-H + LLaMA-7B forward takes ~5 min on the GPU box's host, so
+        # this case reads the committed G16 fixture instead -- the REFERENCE ITSELF run once at this size on the build container (fp16 with the
+        # fp32 neck, and fp32), reference == oracle asserted bit for bit there (tests/golden/gen_golden_full_depth.py).  Round 6: no skip.
+        return _res_against_reference_fixture("fp16", dt)
     with torch.no_grad():
         model, cfg = bench.build_model(224, DEV, seed=3, with_sam=True)
         if dt != torch.bfloat16:
@@ -414,12 +417,152 @@ def test_res_full_depth_against_oracle(dt):
     print(f"RES full depth vs oracle ({dt}):", json.dumps(rec))
     assert tuple(out["pred_masks"][0].shape) == (3, 480, 640) and out["pred_masks"][0].dtype == torch.float32
     for name, floor in (("sam_image_embedding", 2.0 ** -5), ("logits", 2.0 ** -6), ("pred_masks", 2.0 ** -5), ("pred_boxes", 2.0 ** -5)):
-        assert rec[name]["hip_err"] <= max(3.0 * rec[name]["oracle_bf16_err"], floor), (name, rec[name])
+        assert rec[name]["hip_err"] <= max(1.5 * rec[name]["oracle_bf16_err"], floor), (name, rec[name])
     # mask SIGNS (the segmentation itself): where the fp32 logit is at least 4 x the oracle's bf16 error away from zero, all three agree
     hm, rm, tm = out["pred_masks"][0].cpu(), ref["pred_masks"][0].float(), truth["pred_masks"][0]
     clear = tm.abs() > 4.0 * float((rm - tm).abs().max())
     assert bool(((hm > 0) == (tm > 0))[clear].all()) and bool(((rm > 0) == (tm > 0))[clear].all())
     print(f"mask pixels decided with margin: {float(clear.float().mean()) * 100:.1f} %, sign agreement there: exact")
+
+
+# ---- G15 / G16: the REFERENCE ITSELF at full depth (tests/golden/gen_golden_full_depth.py ran /root/reference on the build container's CPU, in
+# bf16, fp16 and fp32, and asserted reference == oracle bit for bit on every output) -------------------------------------------------------------
+_REF = {}
+
+
+def _ref_models():
+    """{dtype: HIP UllavaForCausalLM} holding the fixtures' weights: `weights.seeded_tensor(name, shape, 15, hf_init=True)` per tensor (`llm.*`
+    under the core model's names), generated ONCE in fp32 on the host by a thread pool and rounded once into the bf16 and the fp16 model."""
+    if _REF:
+        return _REF
+    import bench
+    from concurrent.futures import ThreadPoolExecutor
+    C, MU, W = pkg("configuration"), pkg("modeling_ullava"), pkg("weights")
+    fx = load_fixture("g16_res_full_depth_bf16.pt")
+    llm = dict(vision_config=dict(image_size=224, patch_size=14), vision_hidden_layer=-2, projector_type="mlp", projector_from_scratch=False,
+               mm_token_ids=dict(bench.MM), vocab_size=32011)
+    models = {}
+    with torch.no_grad():
+        for dt in (torch.bfloat16, torch.float16):
+            m = MU.UllavaForCausalLM(C.UllavaConfig(llm_config=llm, seg_token_idx=bench.SEG, loc_token_idx=bench.LOC), device=DEV, dtype=dt)
+            m.llm.strict_checks = False
+            models[dt] = m
+        sds = {dt: m.state_dict(keep_vars=True) for dt, m in models.items()}       # the parameters / buffers themselves
+        shapes = {k: tuple(v) for k, v in fx["shapes"].items()}
+        assert {k: tuple(v.shape) for k, v in sds[torch.bfloat16].items()} == shapes, "state-dict keys / shapes differ from the reference's"
+        keys = list(shapes)
+
+        def gen(k):
+            return k, W.seeded_tensor(k[4:] if k.startswith("llm.") else k, shapes[k], fx["seed"], torch.float32, hf_init=True)
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
+            for i in range(0, len(keys), 48):
+                for k, t in ex.map(gen, keys[i:i + 48]):
+                    for dt in models:
+                        sds[dt][k].data.copy_(t.to(dt))
+        for m in models.values():
+            m.llm._packed = None                                   # (the re-layouts are made from the filled parameters on first use)
+            if hasattr(m, "_sam"):
+                m._sam.invalidate()
+    _REF.update(models)
+    return _REF
+
+
+def _sample_err(hip, ref, truth, absmax):
+    h, r, t = (x.detach().float().cpu() for x in (hip, ref, truth))
+    return float((h - t).abs().max()) / absmax, float((r - t).abs().max()) / absmax, float((h - t).pow(2).mean().sqrt()), float((r - t).pow(2).mean().sqrt())
+
+
+def _check_logits_against_reference(logits, rec, what):
+    """HIP logits [S, V] against the fixture's record of the reference's 16-bit logits and its fp32 logits: errors on the SAME samples (whole rows at
+    12 positions, every 64th column at all positions), and token ids EQUAL to the reference's (16-bit and fp32, which agree there) at every position
+    whose fp32 top-1 / top-2 gap exceeds 4 standard deviations of the reference's own 16-bit noise on a logit difference."""
+    rows = rec["rows"]
+    e_hip_r, e_ref_r, rms_hip_r, rms_ref_r = _sample_err(logits[rows], rec["ref_rows"], rec["truth_rows"], rec["truth_absmax"])
+    cs = rec["col_stride"]
+    e_hip_c, e_ref_c, rms_hip_c, rms_ref_c = _sample_err(logits[:, ::cs], rec["ref_cols"], rec["truth_cols"], rec["truth_absmax"])
+    gap = rec["truth_top_values"][:, 0] - rec["truth_top_values"][:, 1]
+    gated = gap > 4.0 * rec["sigma"]
+    ah = logits.float().argmax(-1).cpu()
+    at, ar = rec["truth_argmax"].long(), rec["ref_argmax"].long()
+    mism = int(((ah != at) | (ah != ar))[gated].sum())
+    out = dict(rows=dict(hip_err=round(e_hip_r, 5), ref_err=round(e_ref_r, 5), hip_rms=round(rms_hip_r, 5), ref_rms=round(rms_ref_r, 5)),
+               cols=dict(hip_err=round(e_hip_c, 5), ref_err=round(e_ref_c, 5), hip_rms=round(rms_hip_c, 5), ref_rms=round(rms_ref_c, 5)),
+               positions=int(gap.numel()), positions_gated=int(gated.sum()), gated_mismatches=mism,
+               argmax_agree_hip_fp32=round(float((ah == at).float().mean()), 4), argmax_agree_ref_fp32=round(float((ar == at).float().mean()), 4),
+               argmax_agree_hip_ref=round(float((ah == ar).float().mean()), 4), reference_full_tensor=rec["full_stats"])
+    print(f"{what} logits vs the reference:", json.dumps(out))
+    for k in ("rows", "cols"):
+        assert out[k]["hip_err"] <= max(1.5 * out[k]["ref_err"], 2.0 ** -6), (k, out[k])
+        assert out[k]["hip_rms"] <= 1.25 * out[k]["ref_rms"], (k, out[k])
+    assert mism == 0, f"{what}: token ids differ from the reference's at {mism} margin-gated positions"
+    assert int(gated.sum()) >= gap.numel() // 10
+    assert out["argmax_agree_hip_fp32"] >= out["argmax_agree_ref_fp32"] - 0.03
+    return out
+
+
+@pytest.mark.parametrize("tag,dt", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
+def test_c1_full_depth_against_reference_fixture(tag, dt):
+    """G15: BASELINE.json configs[0] at FULL size against the reference itself (`UllavaCoreForCausalLM.forward`, models/ullava_core.py:279-355, run
+    on the build container's CPU): hidden states 0 / 8 / 16 / 24 / 32 and the logits as close to the reference's fp32 run as the reference's own
+    16-bit run is (x1.5) on the committed samples, and margin-gated token ids equal to the reference's."""
+    fx = load_fixture(f"g15_c1_full_depth_{tag}.pt")
+    model = _ref_models()[dt].llm
+    with torch.no_grad():
+        out = model.forward(input_ids=fx["input_ids"].to(DEV), attention_mask=fx["attention_mask"].to(DEV), images=fx["images"].to(DEV),
+                            output_hidden_states=True)
+    assert tuple(out.logits.shape) == (1, 291, 32011) and out.logits.dtype == dt and len(out.hidden_states) == 33
+    rec = {}
+    st = fx["hid_stride"]
+    for li in fx["hid_layers"]:
+        e_hip, e_ref, _, _ = _sample_err(out.hidden_states[li][0, :, ::st], fx["ref_hidden"][li], fx["truth_hidden"][li], fx["truth_hidden_absmax"][li])
+        rec[f"hidden_{li}"] = dict(hip_err=round(e_hip, 5), ref_err=round(e_ref, 5))
+        assert e_hip <= max(1.5 * e_ref, 2.0 ** -7), (li, e_hip, e_ref)
+    print(f"G15 ({tag}) hidden states vs the reference:", json.dumps(rec))
+    _check_logits_against_reference(out.logits[0], fx["logits"], f"G15 ({tag})")
+
+
+def _res_against_reference_fixture(tag, dt):
+    """G16: batch-1 C3 at FULL size against the reference itself (`UllavaForCausalLM.forward(inference=True)`, models/ullava.py:152-268; SAM ViT-H
+    image_encoder.py:110-125 -- in fp16 with its fp32 neck, :117-124): SAM image embedding, mask logits, boxes and LLaMA logits as close to the
+    reference's fp32 run as the reference's own 16-bit run is (x1.5) on the committed samples; mask SIGNS equal wherever the fp32 logit clears
+    4x the reference's own 16-bit error; margin-gated token ids equal."""
+    from helpers import digest_matches
+    fx = load_fixture(f"g16_res_full_depth_{tag}.pt")
+    model = _ref_models()[dt]
+    g = torch.Generator().manual_seed(fx["inputs_seed"])                      # gen_golden_full_depth.c3_inputs: ids, image, then the SAM image
+    torch.randint(5, 32000, (120,), generator=g)
+    torch.randn(1, 3, 224, 224, generator=g)
+    images_sam = torch.randn(1, 3, 1024, 1024, generator=g).to(dt)
+    assert digest_matches(images_sam, fx["images_sam_digest"]), "the regenerated SAM input differs from the one the reference saw"
+    sizes, resizes = [tuple(x) for x in fx["size_list"]], [tuple(x) for x in fx["resize_list"]]
+    with torch.no_grad():
+        out = model.forward(images_sam=images_sam.to(DEV), images=fx["images"].to(DEV), input_ids=fx["input_ids"].to(DEV), labels=None,
+                            attention_mask=fx["attention_mask"].to(DEV), mask_list=[None], size_list=sizes, resize_list=resizes, bbox_list=[None],
+                            inference=True)
+        emb = model.get_visual_embs(images_sam.to(DEV))
+    pm = out["pred_masks"][0]
+    assert tuple(pm.shape) == (3, 480, 640) and pm.dtype == torch.float32 and tuple(out["pred_boxes"][0].shape) == (3, 4)
+    rec = {}
+    for name, hip, r_, t_, amax, floor in (
+            ("sam_image_embedding", emb[:, ::8, ::2, ::2], fx["ref_emb"], fx["truth_emb"], fx["truth_emb_absmax"], 2.0 ** -5 if dt == torch.bfloat16 else 2.0 ** -8),
+            ("pred_masks", pm[:, ::4, ::4], fx["ref_masks"], fx["truth_masks"], fx["truth_masks_absmax"], 2.0 ** -5 if dt == torch.bfloat16 else 2.0 ** -8),
+            ("pred_boxes", out["pred_boxes"][0], fx["ref_boxes"], fx["truth_boxes"], float(fx["truth_boxes"].float().abs().max()),
+             2.0 ** -5 if dt == torch.bfloat16 else 2.0 ** -8)):
+        e_hip, e_ref, rms_hip, rms_ref = _sample_err(hip, r_, t_, amax)
+        rec[name] = dict(hip_err=round(e_hip, 5), ref_err=round(e_ref, 5), hip_rms=round(rms_hip, 6), ref_rms=round(rms_ref, 6))
+        assert e_hip <= max(1.5 * e_ref, floor), (name, rec[name])
+    tm, hm, rm = fx["truth_masks"], pm[:, ::4, ::4].cpu(), fx["ref_masks"]
+    clear = tm.abs() > fx["mask_sign_margin"]
+    assert bool(((hm > 0) == (tm > 0))[clear].all()) and bool(((rm > 0) == (tm > 0))[clear].all())
+    rec["mask_pixels_decided_with_margin"] = round(float(clear.float().mean()), 4)
+    rec["reference_full_tensor"] = fx["ref_err_full"]
+    print(f"G16 ({tag}) RES full depth vs the reference:", json.dumps(rec))
+    _check_logits_against_reference(out["logits"][0], fx["logits"], f"G16 ({tag})")
+
+
+@pytest.mark.parametrize("tag,dt", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
+def test_res_full_depth_against_reference_fixture(tag, dt):
+    _res_against_reference_fixture(tag, dt)
 
 
 RCCL_SCRIPT = r"""

@@ -416,7 +416,7 @@ def test_training_loss_dict_fixture_g10():
 @pytest.mark.parametrize("dt", [BF, torch.float16])
 def test_full_width_sam_encoder_against_oracle(dt):
     """SAM ViT-H widths (1280 wide, 16 heads, 14x14 windows, 64x64 global grid, 1024x1024 image) with one windowed and one global
-    block: HIP encoder vs the CPU oracle; the embedding must be as close to an fp32 evaluation as the oracle's 16-bit run (x3).
+    block: HIP encoder vs the CPU oracle; the embedding must be as close to an fp32 evaluation as the oracle's 16-bit run (x1.5).
     Exercises the resident window kernel, the single-pass global kernel with in-kernel rel-pos, the fused patch embed and the
     neck at production sizes -- in fp16 the neck of image_encoder.py:117-124: fp32 convolutions (1280 -> 256, 3x3 over K = 2304 as a
     two-term split GEMM) and fp32 LayerNorm2d, only the result cast back."""
@@ -438,7 +438,7 @@ def test_full_width_sam_encoder_against_oracle(dt):
     truth = O.sam_image_encoder({k: v.float() for k, v in osd.items()}, scfg, img.float())
     e_ref, e_hip = rel_err(ref, truth), rel_err(got, truth)
     print(f"SAM encoder (full width, 2 blocks, {dt}): HIP err vs fp32 {e_hip:.5f}, oracle 16-bit {e_ref:.5f}, HIP vs oracle {rel_err(got, ref):.5f}")
-    assert got.dtype == dt and e_hip <= max(3.0 * e_ref, 2.0 ** -6 if dt == BF else 2.0 ** -9)
+    assert got.dtype == dt and e_hip <= max(1.5 * e_ref, 2.0 ** -6 if dt == BF else 2.0 ** -9)
 
 
 def test_forward_with_no_seg_or_loc_tokens():

@@ -12,6 +12,25 @@ LIB_PATH = os.environ.get("ULL_LIB_PATH", os.path.join(_HERE, "csrc", "libullava
 
 _i64, _i32, _f32, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
+
+# the structs of include/ullava_hip.h's coarse entries (one call = a whole stack of layers)
+class Linear(ctypes.Structure):
+    _fields_ = [("w", _ptr), ("w_tiled", _ptr), ("bias", _ptr), ("n", _i64), ("k", _i64), ("ldw", _i64)]
+
+
+class LlamaLayer(ctypes.Structure):
+    _fields_ = [("ln1", _ptr), ("ln2", _ptr), ("qkv", Linear), ("o", Linear), ("gu", Linear), ("down", Linear)]
+
+
+class ClipLayer(ctypes.Structure):
+    _fields_ = [("ln1_w", _ptr), ("ln1_b", _ptr), ("ln2_w", _ptr), ("ln2_b", _ptr), ("qkv", Linear), ("out", Linear), ("fc1", Linear), ("fc2", Linear)]
+
+
+class SamBlock(ctypes.Structure):
+    _fields_ = [("n1_w", _ptr), ("n1_b", _ptr), ("n2_w", _ptr), ("n2_b", _ptr), ("qkv", Linear), ("proj", Linear), ("lin1", Linear), ("lin2", Linear),
+                ("rel_pos_h", _ptr), ("rel_pos_w", _ptr), ("window", _i64)]
+
+
 # name -> argtypes (restype is int = ULL_OK / ULL_ERR_* unless listed in VALUE_RETURNING)
 SIGNATURES = {
     "ull_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr, _i64, _ptr],
@@ -53,6 +72,12 @@ SIGNATURES = {
     "ull_gemv_qkv_rope_append_bf16": [_ptr, _i64, _ptr, _f32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                       _ptr],
     "ull_rmsnorm_bf16": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
+    "ull_llama_prefill_layers_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _ptr,
+                                      _i64, _i64, _ptr, _ptr],
+    "ull_llama_decode_layers_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64,
+                                     _i64, _i64, _f32, _ptr, _ptr],
+    "ull_clip_layers_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _ptr, _i64, _i64, _ptr, _ptr],
+    "ull_sam_blocks_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _ptr, _i64, _i64, _ptr, _ptr],
     "ull_shifted_cross_entropy_bf16": [_ptr, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr],
     "ull_layernorm_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "ull_clip_embed_ln_bf16": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],

@@ -20,6 +20,7 @@ import weakref
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import autograd_ops as A
 from . import ops
 from .configuration import UllavaCoreConfig
@@ -177,6 +178,13 @@ class KVCache:
 
     def __bool__(self):
         return self.length > 0
+
+    def c_ptrs(self):
+        """(void* array of the K buffers, void* array of the V^T buffers) for the coarse decode entry; built once per cache."""
+        if getattr(self, "_c_ptrs", None) is None:
+            import ctypes
+            self._c_ptrs = ((ctypes.c_void_p * len(self.k))(*[t.data_ptr() for t in self.k]), (ctypes.c_void_p * len(self.vt))(*[t.data_ptr() for t in self.vt]))
+        return self._c_ptrs
 
     def __len__(self):
         return len(self.k)
@@ -491,7 +499,19 @@ class UllavaCoreForCausalLM(nn.Module):
         S = P + 1
         h = ops.clip_embed_ln(patches, ve.embeddings.class_embedding, ve.embeddings.position_embedding.weight,
                               ve.pre_layrnorm.weight, ve.pre_layrnorm.bias, n, S, vc.layer_norm_eps).view(n * S, Dv)
-        for li in range(self._selected_layer_count()):
+        nsel = self._selected_layer_count()
+        I = vc.intermediate_size
+        coarse = ops.coarse_ok() and nsel > 0 and hd == 64 and n * S > 16 and 16 < S <= 704 and Dv % 64 == 0 and I % 64 == 0
+        if coarse:
+            # one C call for the tower's layers (csrc/layers.hip): the same launches as the loop below, bit-identical results
+            stack = pk.get("_c_clip")
+            if stack is None:
+                stack = pk["_c_clip"] = ops.LayerStack(_lib.ClipLayer, [dict(ln1_w=w["ln1"].weight, ln1_b=w["ln1"].bias, ln2_w=w["ln2"].weight,
+                                                                              ln2_b=w["ln2"].bias, qkv=(w["w_qkv"], w["b_qkv"]), out=(w["w_out"], w["b_out"]),
+                                                                              fc1=(w["fc1"].weight, w["fc1"].bias), fc2=(w["fc2"].weight, w["fc2"].bias))
+                                                                         for w in pk["clip"]])
+            ops.clip_layers(stack, nsel, h, n, S, H, hd, I, vc.layer_norm_eps)
+        for li in range(0 if coarse else nsel):
             w = pk["clip"][li]
             y = ops.layernorm(h, w["ln1"].weight, w["ln1"].bias, vc.layer_norm_eps)
             qkv = ops.linear(y, w["w_qkv"], w["b_qkv"])
@@ -818,7 +838,32 @@ class UllavaCoreForCausalLM(nn.Module):
         fuse_append = cache is not None and past > 0 and T <= 4 and hd % 2 == 0 and D % 8 == 0 and T * D * 2 <= 32768
         rope_cs = ops.rope_table(pos, inv_freq, x.dtype) if (fuse_rope or fuse_append) else None
         all_h = []
-        for li, w in enumerate(pk["llama"]):
+        I = cfg.intermediate_size
+        coarse = None
+        if ops.coarse_ok() and pk["llama"]:
+            if fuse_append and I % 8 == 0:
+                coarse = "decode"
+            elif fuse_rope and cache is None and T > 16 and 16 < S <= 1024 and I % 64 == 0:
+                coarse = "prefill"
+        if coarse is not None:
+            # one C call for the whole layer stack (csrc/layers.hip): the same launches as the loop below, bit-identical results
+            stack = pk.get("_c_llama")
+            if stack is None:
+                stack = pk["_c_llama"] = ops.LayerStack(_lib.LlamaLayer, [dict(ln1=w["ln1"], ln2=w["ln2"], qkv=(w["w_qkv"], None), o=(w["w_o"], None),
+                                                                                gu=(w["w_gu"], None), down=(w["w_down"], None)) for w in pk["llama"]])
+            L = len(pk["llama"])
+            if output_hidden_states:
+                outs = [torch.empty(T, D, device=dev, dtype=x.dtype) for _ in range(L)]
+                all_h = [x.view(B, S, D)] + [o.view(B, S, D) for o in outs[:-1]]
+            else:
+                outs = [torch.empty(T, D, device=dev, dtype=x.dtype)] * L
+            if coarse == "decode":
+                ops.llama_decode_layers(stack, x, outs, rope_cs[0], rope_cs[1], key_mask, cache.c_ptrs()[0], cache.c_ptrs()[1], B, S, H, hd, I, cache.smax,
+                                        past, cfg.rms_norm_eps)
+            else:
+                ops.llama_prefill_layers(stack, x, outs, rope_cs[0], rope_cs[1], key_mask, B, S, H, hd, I, cfg.rms_norm_eps)
+            x = outs[-1]
+        for li, w in enumerate(pk["llama"] if coarse is None else ()):
             if output_hidden_states:
                 all_h.append(x.view(B, S, D))
             decode = cache is not None and past > 0

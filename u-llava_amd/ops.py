@@ -1017,3 +1017,146 @@ def sumsq(g: torch.Tensor, out: torch.Tensor) -> None:
         raise RuntimeError("u-llava_amd.sumsq: contiguous GPU tensor (fp32 / bf16 / fp16) required")
     if g.numel():
         _lib.call("ull_sumsq_f32", _p(g), DT_CODE[g.dtype], g.numel(), _p(out), _stream())
+
+
+# ---- coarse entries (include/ullava_hip.h "coarse entries", csrc/layers.hip): one C call enqueues a whole stack of layers ---------------------
+# The per-op wrappers above cost a ctypes round trip + Python marshalling per LAUNCH (~15 us); a C4 step has ~400 launches, a decode step ~160.
+# A LayerStack holds the ctypes array of per-layer structs (weight / bias / norm pointers) and refreshes it when a pointer it recorded has
+# moved (a re-made tile-major copy after an optimizer step, a re-pack).  Results are bit-identical to the per-op path: same entries, same
+# dispatch rules (layers.hip `lin` / `lin_decode` mirror `linear` above).
+COARSE = [True]     # `with ops.per_op_layers():` = the per-op path (tests A/B the two)
+
+
+class per_op_layers:
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = COARSE[0]
+        COARSE[0] = not self.on
+        return self
+
+    def __exit__(self, *exc):
+        COARSE[0] = self.prev
+        return False
+
+
+def coarse_ok() -> bool:
+    return COARSE[0] and not _SMALL_M_SPLIT_K[0]
+
+
+class LayerStack:
+    """`kind`: _lib.LlamaLayer / ClipLayer / SamBlock; `layers`: one dict per layer, field name -> tensor (pointer fields) or
+    (weight, bias-or-None) (ull_linear fields) or int (plain fields)."""
+
+    def __init__(self, kind, layers):
+        self.kind, self.layers = kind, layers
+        self.arr = (kind * len(layers))()
+        self._lin_fields = [n for n, t in kind._fields_ if t is _lib.Linear]
+        self._seen = None
+        self.refresh()
+
+    def _fingerprint(self):
+        fp = []
+        for d in self.layers:
+            for n in self._lin_fields:
+                w = d[n][0]
+                wt = _tiled_of(w)
+                fp.append(w.data_ptr())
+                fp.append(0 if wt is None else wt.data_ptr())
+        return fp
+
+    def refresh(self):
+        fp = self._fingerprint()
+        if fp == self._seen:
+            return self.arr
+        for i, d in enumerate(self.layers):
+            s = self.arr[i]
+            for n, t in self.kind._fields_:
+                v = d[n]
+                if t is _lib.Linear:
+                    w, b = v
+                    if w.dim() != 2 or w.stride(1) != 1:
+                        raise RuntimeError("u-llava_amd: coarse entries need row-major 2-D weights")
+                    wt = _tiled_of(w)
+                    setattr(s, n, _lib.Linear(w.data_ptr(), None if wt is None else wt.data_ptr(), _p(b), w.shape[0], w.shape[1], w.stride(0)))
+                elif isinstance(v, int):
+                    setattr(s, n, v)
+                else:
+                    setattr(s, n, v.data_ptr())
+        self._seen = fp
+        return self.arr
+
+
+def _sk_args(device):
+    """(ws pointer, ws bytes, min_k) of the current stream-K policy for a coarse entry."""
+    min_k = _SK_MIN_K[0]
+    if min_k is None:
+        return None, 0, -1
+    ws = _streamk_ws(device, _stream())
+    return ws.data_ptr(), ws.numel(), int(min_k)
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def llama_prefill_layers(stack: LayerStack, x_in: torch.Tensor, x_out, rope_cos, rope_sin, key_mask, B: int, S: int, H: int, hd: int, I: int,
+                         eps: float):
+    """x_in [B*S, D]; x_out: list of n_layers [B*S, D] tensors (may repeat; x_out[0] must not be x_in).  See ull_llama_prefill_layers_bf16."""
+    _chk(x_in, "x_in")
+    T, D = x_in.shape
+    dev, dt = x_in.device, x_in.dtype
+    x_mid = torch.empty(T, D, device=dev, dtype=dt)
+    xn = torch.empty(T, D, device=dev, dtype=dt)
+    qkv = torch.empty(T, 3 * D, device=dev, dtype=dt)
+    att = torch.empty(T, D, device=dev, dtype=dt)
+    act = torch.empty(T, I, device=dev, dtype=dt)
+    ws, wsb, mk = _sk_args(dev)
+    _lib.call("ull_llama_prefill_layers_" + _SFX[dt], stack.refresh(), len(stack.layers), _p(x_in), _ptr_array(x_out), _p(x_mid), _p(xn), _p(qkv), _p(att),
+              _p(act), _p(rope_cos), _p(rope_sin), _p(key_mask), B, S, H, hd, I, float(eps), ws, wsb, mk, _zeros(dev).data_ptr(), _stream())
+
+
+def llama_decode_layers(stack: LayerStack, x_in: torch.Tensor, x_out, rope_cos, rope_sin, key_mask, k_ptrs, vt_ptrs, B: int, S: int, H: int, hd: int,
+                        I: int, smax: int, past: int, eps: float):
+    """One generation step through all layers (T = B*S <= 4).  k_ptrs / vt_ptrs: ctypes void* arrays of the per-layer caches."""
+    _chk(x_in, "x_in")
+    T, D = x_in.shape
+    dev, dt = x_in.device, x_in.dtype
+    scratch = torch.empty(T * (4 * D + 2 * max(D, I)), device=dev, dtype=dt)
+    x_mid, q, att = scratch[:T * D], scratch[T * D:2 * T * D], scratch[2 * T * D:3 * T * D]
+    xn = scratch[3 * T * D:3 * T * D + T * max(D, I)]
+    act = scratch[3 * T * D + T * max(D, I):3 * T * D + T * max(D, I) + T * I]
+    _lib.call("ull_llama_decode_layers_" + _SFX[dt], stack.refresh(), len(stack.layers), _p(x_in), _ptr_array(x_out), _p(x_mid), _p(xn), _p(q), _p(att),
+              _p(act), _p(rope_cos), _p(rope_sin), _p(key_mask), k_ptrs, vt_ptrs, B, S, H, hd, I, smax, past, float(eps), _zeros(dev).data_ptr(), _stream())
+
+
+def clip_layers(stack: LayerStack, n_layers: int, h: torch.Tensor, n_img: int, S: int, H: int, hd: int, I: int, eps: float):
+    """The first n_layers CLIP encoder layers on h [n_img*S, D], in place."""
+    _chk(h, "h")
+    T, D = h.shape
+    dev, dt = h.device, h.dtype
+    h_mid = torch.empty(T, D, device=dev, dtype=dt)
+    y = torch.empty(T, D, device=dev, dtype=dt)
+    qkv = torch.empty(T, 3 * D, device=dev, dtype=dt)
+    att = torch.empty(T, D, device=dev, dtype=dt)
+    f = torch.empty(T, I, device=dev, dtype=dt)
+    ws, wsb, mk = _sk_args(dev)
+    _lib.call("ull_clip_layers_" + _SFX[dt], stack.refresh(), n_layers, _p(h), _p(h_mid), _p(y), _p(qkv), _p(att), _p(f), n_img, S, H, hd, I, float(eps),
+              ws, wsb, mk, _zeros(dev).data_ptr(), _stream())
+
+
+def sam_blocks(stack: LayerStack, x: torch.Tensor, B: int, g: int, nH: int, hd: int, I: int, eps: float = 1e-6):
+    """All SAM encoder blocks on image-order tokens x [B*g*g, C], in place."""
+    _chk(x, "x")
+    T, C = x.shape
+    dev, dt = x.device, x.dtype
+    x_mid = torch.empty(T, C, device=dev, dtype=dt)
+    y = torch.empty(T, C, device=dev, dtype=dt)
+    qkv = torch.empty(T, 3 * C, device=dev, dtype=dt)
+    att = torch.empty(T, C, device=dev, dtype=dt)
+    f = torch.empty(T, I, device=dev, dtype=dt)
+    ws, wsb, mk = _sk_args(dev)
+    _lib.call("ull_sam_blocks_" + _SFX[dt], stack.refresh(), len(stack.layers), _p(x), _p(x_mid), _p(y), _p(qkv), _p(att), _p(f), B, g, nH, hd, I, float(eps),
+              ws, wsb, mk, _zeros(dev).data_ptr(), _stream())

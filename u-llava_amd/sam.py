@@ -13,6 +13,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import autograd_ops as A
 from . import ops
 from .configuration import SamConfig
@@ -166,7 +167,22 @@ class SamEngine:
         x = ops.add_rows(x, pk["pos"])
         if trace is not None:
             trace["embed"] = x.view(B, g, g, C)
-        for i, blk in enumerate(enc.blocks):
+        I = enc.blocks[0].mlp.lin1.weight.shape[0] if len(enc.blocks) else 0
+        coarse = (trace is None and ops.coarse_ok() and len(enc.blocks) > 0 and hd == 80 and g == 64 and cfg.window_size == 14 and C % 64 == 0
+                  and I % 64 == 0 and all(b.attn.qkv.bias is not None for b in enc.blocks))
+        if coarse:
+            # one C call for all blocks (csrc/layers.hip): the same launches as the loop below, bit-identical results
+            stack = pk.get("_c_blocks")
+            if stack is None:
+                def rel(t, glob):
+                    return ops.fit_rel_pos(t, g if glob else cfg.window_size)
+                stack = pk["_c_blocks"] = ops.LayerStack(_lib.SamBlock, [dict(
+                    n1_w=b.norm1.weight, n1_b=b.norm1.bias, n2_w=b.norm2.weight, n2_b=b.norm2.bias, qkv=(b.attn.qkv.weight, b.attn.qkv.bias),
+                    proj=(b.attn.proj.weight, b.attn.proj.bias), lin1=(b.mlp.lin1.weight, b.mlp.lin1.bias), lin2=(b.mlp.lin2.weight, b.mlp.lin2.bias),
+                    rel_pos_h=rel(b.attn.rel_pos_h, i in cfg.global_attn_indexes), rel_pos_w=rel(b.attn.rel_pos_w, i in cfg.global_attn_indexes),
+                    window=0 if i in cfg.global_attn_indexes else cfg.window_size) for i, b in enumerate(enc.blocks)])
+            ops.sam_blocks(stack, x, B, g, nH, hd, I, 1e-6)
+        for i, blk in enumerate(() if coarse else enc.blocks):
             glob = i in cfg.global_attn_indexes
             ws = 0 if glob else cfg.window_size
             y = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, 1e-6)
