@@ -613,10 +613,30 @@ def timed_steps(step, steps, warmup, dist, batch, device):
     sync()
     elapsed = time.perf_counter() - t0
     check_finite(last)                                                        # outside the timed region: the last step's outputs
+    host_ms = None
+    if device.type == "cuda":
+        # host time to ENQUEUE one step (idle GPU, no synchronize inside): what a rank's Python thread costs per step -- eight of them share a
+        # host at N = 8.  `coarse` = the shipped path (one C call per layer stack, csrc/layers.hip), `per_op` = one ctypes call per launch.
+        ops = importlib.import_module("u-llava_amd.ops")
+        host_ms = {}
+        for label, ctx in (("coarse", ops.per_op_layers(False)), ("per_op", ops.per_op_layers(True))):
+            best = None
+            with ctx:
+                for _ in range(3):
+                    sync()
+                    h0 = time.perf_counter()
+                    step()
+                    h = time.perf_counter() - h0
+                    best = h if best is None else min(best, h)
+            host_ms[label] = round(best * 1e3, 3)
+        sync()
     agg_dev = torch.device("cpu") if (dist is not None and dist.get_backend() == "gloo") else device
     rate, total, t_max = D.global_rate(float(batch * steps), elapsed, device=agg_dev)    # (images/s whole job, images, max elapsed)
     lo, hi = D.elapsed_spread(busy, device=agg_dev)                           # fastest / slowest rank's own time: where skew comes from
-    return rate, total, t_max, {"min": round(lo / steps * 1e3, 3), "max": round(hi / steps * 1e3, 3)}
+    spread = {"min": round(lo / steps * 1e3, 3), "max": round(hi / steps * 1e3, 3)}
+    if host_ms is not None:
+        spread["host_enqueue_ms"] = host_ms
+    return rate, total, t_max, spread
 
 
 TRAIN_CONFIGS = {"full": 16, "lora": 32, "qv": 8}          # per-GPU batch (configs/train/ullava.yaml:148, ullava_lora.yaml:148)
@@ -800,6 +820,7 @@ def main():
 
     def sub_record(svalue, ssteps, selapsed, sspread, sbatch, sS, sdesc, sflops, **cfg_extra):
         return {"value": round(svalue, 3), "unit": "images/sec (whole job)", "steps": ssteps, "ms_per_step": round(selapsed / ssteps * 1e3, 3),
+                "host_enqueue_ms_per_step": sspread.pop("host_enqueue_ms", None),
                 "per_rank_ms_per_step": sspread, "images_per_sec_per_gpu": round(svalue / world, 3),
                 "config": dict({"workload": sdesc, "per_gpu_batch": sbatch, "global_batch": sbatch * world, "seq_len": sS}, **cfg_extra),
                 "model_tflops_per_image": round(sflops / 1e12, 3),
@@ -844,7 +865,8 @@ def main():
 
     if rank == 0:
         line = {"metric": METRIC, "value": round(value, 3), "unit": "images/sec (whole job, all GPUs)", "cpu_affinity": affinity,
-                "outputs_finite": True, "process_group": pg, "per_rank_ms_per_step": spread,
+                "outputs_finite": True, "process_group": pg, "host_enqueue_ms_per_step": spread.pop("host_enqueue_ms", None),
+                "per_rank_ms_per_step": spread,
                 "probes": {"order": "after destroy_process_group", "ranks_running": 1},
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",

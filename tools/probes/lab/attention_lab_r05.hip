@@ -48,8 +48,17 @@ struct AttnArgs {
     // the qkv bias): K / V rows of such keys come from k_pad / v_pad.
     int img_h, img_w, nwy, nwx;
     const elem_t* k_pad; const elem_t* v_pad;   // K / V part of the pad token's row (+ h * k_hs)
+#ifdef ULL_ATTN_STAMPS
+    unsigned long long* stamps;         // debug build only (tools/attn_phase_times.py): per-wave cycle totals of attn_reg_kernel's phases
+#endif
 };
+#ifdef ULL_ATTN_STAMPS
+unsigned long long* ull_attn_stamp_host_ptr = nullptr;
+#define ULL_ATT_T() __builtin_readcyclecounter()
+#define ULL_ATT_ACC(slot, t0) do { const unsigned long long t1_ = __builtin_readcyclecounter(); stamp_acc[slot] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
 #define ULL_ATT_ACC(slot, t0) ((void)0)
+#endif
 
 // ull_sam_window_attention: window b = (img * nwy + wy) * nwx + wx -> (image, first token row, first token column).  The divisors are
 // run-time values; a / d goes through the host-computed m = ceil(2^32 / d): exact while a * d < 2^32 (the dispatcher checks), m = 0
@@ -114,7 +123,9 @@ ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& l
         // (the packed pairs are made opaque: seeing through pack -> unpack, the compiler converts every value on its own again --
         //  4 single conversions + 4 shifts instead of 2 packed conversions + 2 shifts + 2 ands; census in profiles/r05_attn_prefill_census.txt)
         uint32_t a01 = pack2e(acc[0], acc[1]), a23 = pack2e(acc[2], acc[3]);
+#ifndef ULL_ATTN_NO_OPAQUE_PAIRS
         asm volatile("" : "+v"(a01), "+v"(a23));
+#endif
         const f32x2_t x01 = f32x2_t{pk_lo(a01), pk_hi(a01)} * p.scale, x23 = f32x2_t{pk_lo(a23), pk_hi(a23)} * p.scale;
         if (row_max) *row_max = fmaxf(fmaxf(fmaxf(*row_max, x01.x), x01.y), fmaxf(x23.x, x23.y));
         lo = pack2e(x01.x, x01.y);
@@ -350,7 +361,9 @@ ULL_DEV void lds_tr_wait(u32x2_t (&a)[N], u32x2_t (&b)[N]) {      // ties the va
 // of DMA pieces per tile) streams through a ring of ULL_ATTN_RING (2: measured best); everything else through two
 template <int HDP, int NT, int NWV, bool EXACT, bool VROW>
 constexpr int attn_reg_nbuf() {
-constexpr int ULL_ATTN_RING = 2;
+#ifndef ULL_ATTN_RING
+#define ULL_ATTN_RING 2
+#endif
     return EXACT ? 2 * NT : ((VROW && (HDP / 8) % NWV == 0 && NT >= 2) ? ULL_ATTN_RING : 2);
 }
 
@@ -358,6 +371,9 @@ constexpr int ULL_ATTN_RING = 2;
 //   operand of P*V comes out of them through ds_read_b64_tr_b16: no V^T pass in front of the attention.
 template <int HDP, int NT, int FL, int NWV, bool EXACT = false, bool VROW = false>
 __global__ __launch_bounds__(NWV * 64, (EXACT || (VROW && HDP == 64 && NWV == 4)) ? 4 : (VROW && HDP == 128 && NT <= 11 && NWV <= 4) ? 3 :
+#ifdef ULL_ATTN_NWV8_OCC4
+                                       (VROW && HDP == 128 && NT <= 11 && NWV == 8) ? 4 :
+#endif
                                        2)
 void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefill: three blocks per CU = at most 168 registers)
     extern __shared__ __attribute__((aligned(256))) char smem[];     // (256: the V fragment addresses below XOR bits 5..7)
@@ -382,6 +398,12 @@ void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefi
     const int b = head / p.H, h = head % p.H;
     const int q0 = qt * BQ;
     const int koff = p.Sk - p.Sq;
+#ifdef ULL_ATTN_STAMPS
+    // slots: 0 prologue, 1 phase-1 wait (vmcnt + barrier + DMA issue), 2 phase-1 compute, 3 softmax, 4 phase-3 wait, 5 phase-3 compute, 6 epilogue
+    unsigned long long stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = ULL_ATT_T();
+    const unsigned long long stamp_start = stamp_t;
+#endif
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
     constexpr int NBUF = attn_reg_nbuf<HDP, NT, NWV, EXACT, VROW>();   // EXACT: [K tiles 0..NT) [V^T tiles 0..NT); else a ring of tile buffers
@@ -551,8 +573,12 @@ void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefi
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (timing-only ablations, wrong results: -DULL_ATTN_ABL_NO_BARRIER 302 -> 296 us, -DULL_ATTN_ABL_NO_DMA 308 -> 243 us on the C4 shape: the
         //  step barriers cost 2 %, REQUESTING the tiles 21 % -- profiles/r05_attn_prefill_census.txt)
+#ifndef ULL_ATTN_ABL_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
+#ifndef ULL_ATTN_ABL_NO_DMA
         if (s + NBUF - 1 < total) issue(s + NBUF - 1);
+#endif
     };
 
     // ---- phase 1: S = bf16(K Q^T) (+scale, +mask), kept in registers -----------------------------------
@@ -563,12 +589,15 @@ void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefi
             ULL_ATT_ACC(1, stamp_t);
             if (kt < nkt_w) {
                 const char* tb = smem + (EXACT ? kt : (kt % NBUF)) * TILE;
+#ifndef ULL_ATTN_NO_TILE_PATH
                 if constexpr (VROW) {
                     // a whole tile of real keys, no key mask, entirely below the diagonal for each of the wave's 16 queries (all but the last
                     // tile or two of a wave): ONE wave-uniform branch per tile, then straight-line code -- the four 16-key groups' accumulator
                     // chains interleave (no MFMA waits for the one before it) and the four score epilogues follow without look-ups
                     if (p.key_mask == nullptr && kt * KT + KT <= p.Sk && (FL != FL_LLAMA || kt * KT + KT - 1 <= q0 + wave * 16 + koff)) {
-constexpr int ULL_ATTN_CHAINS = 2;               // accumulator chains in flight (4: 12 more registers, spills at the 168 of three blocks per CU)
+#ifndef ULL_ATTN_CHAINS
+#define ULL_ATTN_CHAINS 2               // accumulator chains in flight (4: 12 more registers, spills at the 168 of three blocks per CU)
+#endif
 #pragma unroll
                         for (int n0 = 0; n0 < 4; n0 += ULL_ATTN_CHAINS) {
                             f32x4_t accn[ULL_ATTN_CHAINS];
@@ -585,9 +614,14 @@ constexpr int ULL_ATTN_CHAINS = 2;               // accumulator chains in flight
                             for (int c = 0; c < ULL_ATTN_CHAINS; ++c)
                                 score_quad_clean<FL>(p, accn[c], sp[kt][(n0 + c) * 2], sp[kt][(n0 + c) * 2 + 1], &mrow);
                         }
+#ifdef ULL_ATTN_STAMPS
+                        asm volatile("" :: "v"(sp[kt][0]), "v"(sp[kt][7]), "v"(mrow));
+                        ULL_ATT_ACC(2, stamp_t);
+#endif
                         continue;
                     }
                 }
+#endif
 #pragma unroll
                 for (int ns = 0; ns < 4; ++ns) {
                     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -619,6 +653,10 @@ constexpr int ULL_ATTN_CHAINS = 2;               // accumulator chains in flight
                     if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#ifdef ULL_ATTN_STAMPS
+            asm volatile("" :: "v"(sp[kt][0]), "v"(sp[kt][7]), "v"(mrow));
+            ULL_ATT_ACC(2, stamp_t);
+#endif
         }
     }
 
@@ -656,6 +694,10 @@ constexpr int ULL_ATTN_CHAINS = 2;               // accumulator chains in flight
             }
     }
 
+#ifdef ULL_ATTN_STAMPS
+    asm volatile("" :: "v"(sp[0][0]), "v"(sp[NT - 1][7]));
+    ULL_ATT_ACC(3, stamp_t);
+#endif
     // ---- phase 3: O^T = V^T P^T; P feeds the MFMA B operand straight from registers ---------------------
     // V^T tiles are stored with keys permuted inside every 32-key block (slot 8g+4a+r <- key 16a+4g+r, see
     // transpose_v_kernel) so that the k-slot <-> key map of the A operand equals the one the P registers already have.
@@ -711,8 +753,13 @@ constexpr int ULL_ATTN_CHAINS = 2;               // accumulator chains in flight
                     if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#ifdef ULL_ATTN_STAMPS
+            asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[NDS - 1][3]));
+            ULL_ATT_ACC(5, stamp_t);
+#endif
         }
     }
+#ifndef ULL_ATTN_NO_LDS_EPILOGUE
     if constexpr (VROW && !EXACT && NBUF == 2 && NWV * 16 * KROW <= TILE) {    // (the block's 16 NWV rows must fit ONE ring buffer: NWV <= 4)
         // O through LDS, stored as whole rows.  A lane holds 4 head dims of ONE query per block of 16: stored from the registers that is 8-byte
         // pieces at a row stride (every store instruction touches 16 rows x 4 x 32 B).  Instead each wave writes its 16 x hd block into
@@ -740,6 +787,7 @@ constexpr int ULL_ATTN_CHAINS = 2;               // accumulator chains in flight
             if (q < p.Sq) *(uint4*)(ow + (long)q * p.o_ss + c * 8) = v;
         }
     } else
+#endif
     if (qi < p.Sq) {
         elem_t* op = p.O + (long)b * p.o_bs + (long)h * p.o_hs + (long)qi * p.o_ss;
 #pragma unroll
@@ -752,6 +800,22 @@ constexpr int ULL_ATTN_CHAINS = 2;               // accumulator chains in flight
             }
         }
     }
+#ifdef ULL_ATTN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ULL_ATT_ACC(6, stamp_t);
+    if (p.stamps && lane == 0) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NWV + wave) * 12;
+        for (int i = 0; i < 7; ++i) o[i] = stamp_acc[i];
+        o[7] = stamp_t - stamp_start;
+        o[8] = (unsigned long long)nkt_w | ((unsigned long long)nkt << 16) | ((unsigned long long)qt << 32);
+        o[9] = stamp_start;
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(20, 0, 32)" : "=s"(xcc));
+        o[10] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+        o[11] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1588,8 +1652,13 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 // which on gfx950 add up instead of overlapping (tools/probes/valu_rate.hip: one 16x16x32 MFMA 16.1 cycles, + 2.4 per v_add beside it; cvt_pk /
 // shifts / max / packed fp32 4.3 cycles, v_exp 8.2) -- 24 MFMAs + ~190 vector instructions per 16 queries x 64 keys is ~1000 cycles = 0.98 ms
 // per layer, and the instruction count is pinned by the reference's three roundings per score.
-constexpr int ULL_SAMG_VA = 5;
-constexpr int ULL_SAMG_VB = 8;
+#ifndef ULL_SAMG_OLD
+#ifndef ULL_SAMG_VA
+#define ULL_SAMG_VA 5
+#endif
+#ifndef ULL_SAMG_VB
+#define ULL_SAMG_VB 8
+#endif
 __global__ __launch_bounds__(256, 2) void sam_global_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     constexpr int NWV = 4, NG = 2, BQ = 16 * NG * NWV, HDP = 128, hd = 80;
@@ -1810,6 +1879,19 @@ __global__ __launch_bounds__(256, 2) void sam_global_kernel(AttnArgs p) {
                 pk[g][i] = pack2e(__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y));
             }
         }
+#ifdef ULL_SAMG_SGB                 // explicit MFMA / VALU interleave: measured no faster than the scheduler's own order (MFMA and VALU issue add up on a gfx950 SIMD)
+        if constexpr (!LAST) {
+#pragma unroll
+            for (int ns = 0; ns < 4; ++ns) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // the 16-key group's three K fragments
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x402, ULL_SAMG_VA, 0);   // vector instructions (exponentials included) in its shadow
+                }
+            }
+        }
+#endif
         // ---- second half: l += sum P(kt), O += V(kt)^T P(kt) on the MFMA  ||  score epilogue of tile kt + 1 on the VALU
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -1850,6 +1932,13 @@ __global__ __launch_bounds__(256, 2) void sam_global_kernel(AttnArgs p) {
         }
         if constexpr (!LAST) {
             grew = scores(kt + 1, acc, sq);
+#ifdef ULL_SAMG_SGB
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);          // one MFMA (l or P V)
+                __builtin_amdgcn_sched_group_barrier(0x402, ULL_SAMG_VB, 1);       // vector instructions of the next tile's score epilogue
+            }
+#endif
         }
     };
 #pragma unroll 2
@@ -1868,6 +1957,7 @@ __global__ __launch_bounds__(256, 2) void sam_global_kernel(AttnArgs p) {
         }
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // At most 16 queries per (batch, head): KV-cached decoding (1 query against the whole cache) and the mask decoder's
@@ -2179,7 +2269,13 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     const int nq = (a.Sq + 16 * NWV - 1) / (16 * NWV);
     const int nheads = a.B * a.H;
     const dim3 grid(((nheads + 7) / 8) * 8 * nq);
+#ifdef ULL_ATTN_STAMPS
+    AttnArgs as = a;
+    as.stamps = ull_attn_stamp_host_ptr;
+    hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, VROW>), grid, dim3(NWV * 64), lds, st, as);
+#else
     hipLaunchKernelGGL((attn_reg_kernel<HDP, NT, FL, NWV, EXACT, VROW>), grid, dim3(NWV * 64), lds, st, a);
+#endif
     return ull_check_launch();
 }
 
@@ -2213,6 +2309,7 @@ int launch_stream(const AttnArgs& a, hipStream_t st) {
     return ull_check_launch();
 }
 
+#ifndef ULL_SAMG_OLD
 int launch_sam_global(const AttnArgs& a, hipStream_t st) {
     constexpr int LDS = 4 * 64 * 256 + 4 * 32 * 64 * 2;        // K ring + V ring + the rel_h tables = 80 KB: two blocks per CU
     static UllOncePerDevice once;
@@ -2222,6 +2319,7 @@ int launch_sam_global(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(sam_global_kernel, grid, dim3(256), LDS, st, a);
     return ull_check_launch();
 }
+#endif
 
 template <int HDP, int FL, int TPW>
 int launch_fewq_t(const AttnArgs& a, int nwv, hipStream_t st) {
@@ -2257,12 +2355,16 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
     if (a.v_rows) {                      // V handed over row-major: the kernels that transpose on the fly (see the C entry)
         if constexpr (HDP == 128) {
-constexpr int ULL_ATTN_NWV = 4;
+#ifndef ULL_ATTN_NWV
+#define ULL_ATTN_NWV 4
+#endif
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, ULL_ATTN_NWV, false, true>(a, st);
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, true>(a, st);
             if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16 &&
                 64 * a.k_ss * 2 < (1L << 31) && 64 * a.vt_ds * 2 < (1L << 31)) {       // (32-bit per-lane DMA offsets inside a tile)
+#ifndef ULL_SAMG_OLD
                 if ((a.Sq & 127) == 0 && a.Sq == a.Sk && a.hd == 80 && !a.key_mask && !a.causal) return launch_sam_global(a, st);   // (queries = the key grid)
+#endif
                 return launch_stream<128, FL_SAM_ENC, 2, true>(a, st);
             }
         }
@@ -2324,6 +2426,9 @@ constexpr int ULL_ATTN_NWV = 4;
 // Strides are in elements.  Q/K rows are head_dim-contiguous; Vt rows (one per head dim) are key-contiguous with
 // `vt_len` readable, finite columns (multiple of 8; keys >= Sk must be zero).  key_mask: int32 [B, Sk] or null.
 // scale_mode 0: S = bf16(QK^T); 1: bf16(bf16(QK^T) * scale); 2: bf16(bf16(QK^T) / scale).
+#ifdef ULL_ATTN_STAMPS
+extern "C" int ULL_FN(ull_debug_attn_stamps_)(void* buf) { ull_attn_stamp_host_ptr = (unsigned long long*)buf; return ULL_OK; }
+#endif
 
 extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs,
                                   int64_t k_ss, const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O,

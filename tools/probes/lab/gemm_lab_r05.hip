@@ -59,6 +59,9 @@ struct GemmArgs {
     // transformers' apply_rotary_pos_emb with the per-token tables rope_cos / rope_sin [M, 64] (element type, already rounded)
     const elem_t* rope_cos; const elem_t* rope_sin;
     int rope_cols;
+#ifdef ULL_GEMM_STAMPS
+    unsigned long long* stamps;
+#endif
 };
 
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS[m0 .. m0+1024) (lane-linear).
@@ -139,7 +142,12 @@ ULL_DEV void big_finish8(const EpiCtx& c, float (&a)[8], int m, int n, bool has_
         } else {
             elem_t* cp = (elem_t*)c.p.C + (long)m * c.p.ldc + n;
             if (full && c.c_al) {
+#if defined(ULL_ABL_NOSTORE)
+                const uint4 v_ = pack8(a);
+                asm volatile("" :: "v"(v_.x), "v"(v_.y), "v"(v_.z), "v"(v_.w), "v"(cp));
+#else
                 *(uint4*)cp = pack8(a);
+#endif
             } else if (full) {
                 // rows that are only 2-byte aligned (lm_head: V = 32011): 4-byte stores where the address allows, two 2-byte ends otherwise
                 const uint4 pk = pack8(a);
@@ -338,7 +346,11 @@ ULL_DEV void staged_epilogue(const GemmArgs& p, f32x4_t (&acc)[4][JT], char* reg
                             for (int e = 0; e < 8; ++e) a[e] = rnd(b[e] + a[e]);
                             o = pack8(a);
                         }
+#if defined(ULL_ABL_NOSTORE)
+                        asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(cbase));
+#else
                         if (m < p.M) *(uint4*)(cbase + (long)m * p.ldc) = o;
+#endif
                     }
                 }
             };
@@ -660,7 +672,24 @@ __global__ __launch_bounds__(256, 2) void patchify_gemm_kernel(GemmArgs p, Patch
 //     being read from one LDS slot and tile k+2 is being DMA'd into the other: two slots give a prefetch distance of 2.
 //   * two barriers per BK=64 step and a hand-dealt slot schedule (at the loop): one MFMA per slot, the fragment reads and the DMA
 //     pieces of tile k+2 spread between them so that the memory pipe sees an even stream and is never drained.
+#ifdef ULL_GEMM_STAMPS      // debug build only (tools/gemm_tile_phases.py): per-block timestamps of the 4-wave kernel's phases
+unsigned long long* ull_stamp_host_ptr = nullptr;            // set by ull_debug_gemm_stamps_*, copied into GemmArgs::stamps at launch
+ULL_DEV void ull_stamp(unsigned long long* buf, int slot) {
+    if (buf && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) {     // wave 0, every lane the same store (a wave-uniform branch)
+        unsigned long long t = __builtin_amdgcn_s_memrealtime();            // 100 MHz
+        if (slot == 7) {                                                    // where the block ran: XCC id << 32 | HW_ID
+            uint32_t hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(4, 0, 32)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(20, 0, 32)" : "=s"(xcc));
+            t = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+        }
+        buf[(size_t)blockIdx.x * 8 + slot] = t;
+    }
+}
+#define ULL_STAMP(slot) ull_stamp(p.stamps, slot)
+#else
 #define ULL_STAMP(slot) ((void)0)
+#endif
 
 namespace big {
 
@@ -758,10 +787,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // half first, barrier A, the 8 DMA pieces of tile kt+2 dealt out one per 6 slots (a burst of all 64 pieces of a CU right behind
     // the barrier measured 3-7 % slower end to end: the memory pipe wants an even stream), barrier B with the newest pieces still in
     // flight, then the first-half fragments of tile kt+1.  The last two steps re-fetch the last tile into a 16-KiB dump.
-constexpr int ULL_W8_BAR_A = 14;
-constexpr int ULL_W8_DMA_STRIDE = 6;
-constexpr int ULL_W8_BAR_B = 40;
-constexpr int ULL_W8_FA_STRIDE = 2;
+#ifndef ULL_W8_BAR_A
+#define ULL_W8_BAR_A 14
+#endif
+#ifndef ULL_W8_DMA_STRIDE
+#define ULL_W8_DMA_STRIDE 6
+#endif
+#ifndef ULL_W8_BAR_B
+#define ULL_W8_BAR_B 40
+#endif
+#ifndef ULL_W8_FA_STRIDE
+#define ULL_W8_FA_STRIDE 2
+#endif
     constexpr int W8_BAR_A = ULL_W8_BAR_A, W8_DMA_STRIDE = ULL_W8_DMA_STRIDE, W8_BAR_B = ULL_W8_BAR_B, W8_FA_STRIDE = ULL_W8_FA_STRIDE;
     constexpr int W8_ISSUED = (W8_BAR_B - W8_BAR_A + W8_DMA_STRIDE - 1) / W8_DMA_STRIDE;
     constexpr int W8_INFLIGHT = W8_ISSUED > 8 ? 8 : W8_ISSUED;
@@ -774,7 +811,9 @@ constexpr int ULL_W8_FA_STRIDE = 2;
     };
     auto mma1 = [&](const Frags& f, int s) {
         const int j = s >> 2, i = s & 3;
+#if !defined(ULL_ABL_NOMMA)
         acc[i][j] = mfma16(f.w[i], f.x[j], acc[i][j]);
+#endif
     };
     stage(0);
     stage(1);
@@ -803,17 +842,22 @@ constexpr int ULL_W8_FA_STRIDE = 2;
             if (s < 12) read1(kt, 1, fb, s);
             if (s >= W8_BAR_B && (s - W8_BAR_B) % W8_FA_STRIDE == 0 && (s - W8_BAR_B) / W8_FA_STRIDE < 12)
                 read1(kt + 1, 0, fa, USE_ORDER[(s - W8_BAR_B) / W8_FA_STRIDE]);
+#if !defined(ULL_ABL_NODMA)
             if (s >= W8_BAR_A && (s - W8_BAR_A) % W8_DMA_STRIDE == 0 && (s - W8_BAR_A) / W8_DMA_STRIDE < 8) {
                 const int pc = (s - W8_BAR_A) / W8_DMA_STRIDE;
                 if (pc < 4) glds16(xsrc[pc] + kox, bx + pc * 1024);
                 else glds16(wsrc[pc - 4] + kow, bw + (pc - 4) * 1024);
             }
+#endif
             mma1(s < 32 ? fa : fb, s & 31);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     // (the dump's pieces may still be landing: they touch nothing the epilogue uses, and s_endpgm waits for them)
 
+#if defined(ULL_ABL_NOEPI)
+    if (p.M > 0) return;
+#endif
     // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
     if (split) {
         float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
@@ -857,7 +901,11 @@ struct Frags4 { uint4 w[8]; uint4 x[8]; };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 ULL_DEV void mfma16_inplace(f32x4_t& c, const uint4& a, const uint4& b) {
     const u32x4_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+#if !defined(ULL_ABL_NOMMA)
     asm volatile(ULL_MFMA16_ASM " %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+#else
+    asm volatile("" : "+a"(c) : "v"(av), "v"(bv));
+#endif
 }
 
 
@@ -1116,6 +1164,10 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
     const uint32_t piece_off = wave * 8 * 1024;
     // piece c of tile kt: c < 8 -> X piece, else W piece
     auto dma_piece = [&](const elem_t* xk, const elem_t* wk, uint32_t slot_addr, int c) {
+#if defined(ULL_ABL_DMASAME)     // every piece re-reads the same KiB: the issue cost of the DMA without its memory traffic
+        glds16s(p.X, (uint32_t)lane * 16, slot_addr + c * 1024);
+        return;
+#endif
         if (c < 8) glds16s(xk, xo[c], slot_addr + c * 1024);
         else glds16s(wk, wo[c - 8], slot_addr + OP_BYTES + (c - 8) * 1024);
     };
@@ -1189,13 +1241,27 @@ __global__ __launch_bounds__(256) void gemm256w4_kernel(GemmArgs p) {
     // so the memory pipe is never drained (1.0-1.5 steps for a piece to land) and never sees a burst.  The last two steps have nothing
     // to prefetch: they re-fetch the last tile (L2 hits) into a 16-KiB dump behind the epilogue regions instead of branching.
     // schedule knobs (tools/build_ablations.sh overrides them with -D for sweeps)
-constexpr int ULL_W4_BAR_A = 20;
-constexpr int ULL_W4_BAR_B = 96;
-constexpr int ULL_W4_FB_STRIDE = 1;
-constexpr int ULL_W4_FA_FIRST = 96;
-constexpr int ULL_W4_FA_STRIDE = 2;
-constexpr int ULL_W4_DMA_FIRST = 20;
-constexpr int ULL_W4_DMA_STRIDE = 7;
+#ifndef ULL_W4_BAR_A
+#define ULL_W4_BAR_A 20
+#endif
+#ifndef ULL_W4_BAR_B
+#define ULL_W4_BAR_B 96
+#endif
+#ifndef ULL_W4_FB_STRIDE
+#define ULL_W4_FB_STRIDE 1
+#endif
+#ifndef ULL_W4_FA_FIRST
+#define ULL_W4_FA_FIRST 96
+#endif
+#ifndef ULL_W4_FA_STRIDE
+#define ULL_W4_FA_STRIDE 2
+#endif
+#ifndef ULL_W4_DMA_FIRST
+#define ULL_W4_DMA_FIRST 20
+#endif
+#ifndef ULL_W4_DMA_STRIDE
+#define ULL_W4_DMA_STRIDE 7
+#endif
     constexpr int W4_BAR_A = ULL_W4_BAR_A, W4_BAR_B = ULL_W4_BAR_B, W4_FB_STRIDE = ULL_W4_FB_STRIDE, W4_FA_FIRST = ULL_W4_FA_FIRST,
                   W4_FA_STRIDE = ULL_W4_FA_STRIDE, W4_DMA_FIRST = ULL_W4_DMA_FIRST, W4_DMA_STRIDE = ULL_W4_DMA_STRIDE;
     constexpr int W4_ISSUED = (W4_BAR_B - W4_DMA_FIRST + W4_DMA_STRIDE - 1) / W4_DMA_STRIDE;   // pieces of tile kt+2 issued before barrier B
@@ -1212,8 +1278,15 @@ constexpr int ULL_W4_DMA_STRIDE = 7;
         const int j = s >> 3, h = (s >> 2) & 1, i = s & 3;
         const uint4 &a = f.w[h * 4 + i], &b = f.x[j];
         const u32x4_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
+#if defined(ULL_ABL_NODMA)
+        asm volatile(ULL_MFMA16_ASM " %0, %1, %2, %0" : "+a"(acc[h][i][j]) : "v"(av), "v"(bv));
+#elif defined(ULL_ABL_NOMMA)
+        asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4"
+                     : "+a"(acc[h][i][j]) : "v"(av), "v"(bv), "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+#else
         asm volatile("s_mov_b32 m0, %5\n\t" ULL_MFMA16_ASM " %0, %1, %2, %0\n\tglobal_load_lds_dwordx4 %3, %4"
                      : "+a"(acc[h][i][j]) : "v"(av), "v"(bv), "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+#endif
     };
     uint32_t m0_keep;
     asm volatile("s_mov_b32 %0, m0" : "=s"(m0_keep));        // the loop writes m0 without saving it (the compiler emits nothing that reads it there)
@@ -1230,18 +1303,30 @@ constexpr int ULL_W4_DMA_STRIDE = 7;
         for (int s = 0; s < 128; ++s) {
             if (s == W4_BAR_A) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(ULL_ABL_NOBAR)
                 __builtin_amdgcn_s_barrier();
+#endif
             }
             if (s == W4_BAR_B) {
+#if defined(ULL_W4_NODUMP)
+                if (!with_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
+#endif
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W4_INFLIGHT) : "memory");
+#if !defined(ULL_ABL_NOBAR)
                 __builtin_amdgcn_s_barrier();
+#endif
             }
+#if !defined(ULL_ABL_NOREAD)
             if (s < 16 * W4_FB_STRIDE && s % W4_FB_STRIDE == 0) read_one(kt, 1, fb, s / W4_FB_STRIDE);
             if (s >= W4_FA_FIRST && (s - W4_FA_FIRST) % W4_FA_STRIDE == 0 && (s - W4_FA_FIRST) / W4_FA_STRIDE < 16)
                 read_one(kt + 1, 0, fa, USE_ORDER[(s - W4_FA_FIRST) / W4_FA_STRIDE]);
+#endif
             const Frags4& f = s < 64 ? fa : fb;
             const int pc = (s - W4_DMA_FIRST) / W4_DMA_STRIDE;   // piece: 0..7 of X, 8..15 of W
             if (s >= W4_DMA_FIRST && (s - W4_DMA_FIRST) % W4_DMA_STRIDE == 0 && pc < 16) {
+#if defined(ULL_W4_NODUMP)
+                if (!with_dma) slot_mma(f, s & 63); else
+#endif
                 if (pc < 8) slot_mma_dma(f, s & 63, xk, xo[pc], sa + pc * 1024);
                 else slot_mma_dma(f, s & 63, wk, wo[pc - 8], sw + (pc - 8) * 1024);
             } else slot_mma(f, s & 63);
@@ -1253,6 +1338,9 @@ constexpr int ULL_W4_DMA_STRIDE = 7;
     asm volatile("s_mov_b32 m0, %0" :: "s"(m0_keep) : "memory");   // (the dump's pieces may still be landing: they touch nothing
                                                                     // the epilogue uses, and s_endpgm waits for them)
 
+#if defined(ULL_ABL_NOEPI)
+    if (p.M > 0) return;
+#endif
     // ---- epilogue: acc[h][i][j][r] = D[n = n0 + wn*128 + w4_acc_row(h, i, fg) + r][m = m0 + wm*128 + j*16 + fr] (physical W row n) ------
     if (split) {
         float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
@@ -1568,10 +1656,18 @@ __global__ __launch_bounds__(512) void gemm256d_kernel(GemmArgs p) {
     // half first, barrier A, the 8 DMA pieces of tile kt+2 dealt out one per 6 slots (a burst of all 64 pieces of a CU right behind
     // the barrier measured 3-7 % slower end to end: the memory pipe wants an even stream), barrier B with the newest pieces still in
     // flight, then the first-half fragments of tile kt+1.  The last two steps re-fetch the last tile into a 16-KiB dump.
-constexpr int ULL_W8_BAR_A = 14;
-constexpr int ULL_W8_DMA_STRIDE = 6;
-constexpr int ULL_W8_BAR_B = 40;
-constexpr int ULL_W8_FA_STRIDE = 2;
+#ifndef ULL_W8_BAR_A
+#define ULL_W8_BAR_A 14
+#endif
+#ifndef ULL_W8_DMA_STRIDE
+#define ULL_W8_DMA_STRIDE 6
+#endif
+#ifndef ULL_W8_BAR_B
+#define ULL_W8_BAR_B 40
+#endif
+#ifndef ULL_W8_FA_STRIDE
+#define ULL_W8_FA_STRIDE 2
+#endif
     constexpr int W8_BAR_A = ULL_W8_BAR_A, W8_DMA_STRIDE = ULL_W8_DMA_STRIDE, W8_BAR_B = ULL_W8_BAR_B, W8_FA_STRIDE = ULL_W8_FA_STRIDE;
     constexpr int W8_ISSUED = (W8_BAR_B - W8_BAR_A + W8_DMA_STRIDE - 1) / W8_DMA_STRIDE;
     constexpr int W8_INFLIGHT = W8_ISSUED > 8 ? 8 : W8_ISSUED;
@@ -1584,7 +1680,9 @@ constexpr int ULL_W8_FA_STRIDE = 2;
     };
     auto mma1 = [&](const Frags& f, int s) {
         const int j = s >> 2, i = s & 3;
+#if !defined(ULL_ABL_NOMMA)
         acc[0][i][j] = mfma16(f.w[i], f.x[j], acc[0][i][j]);
+#endif
     };
     stage(0);
     stage(1);
@@ -1613,17 +1711,22 @@ constexpr int ULL_W8_FA_STRIDE = 2;
             if (s < 12) read1(kt, 1, fb, s);
             if (s >= W8_BAR_B && (s - W8_BAR_B) % W8_FA_STRIDE == 0 && (s - W8_BAR_B) / W8_FA_STRIDE < 12)
                 read1(kt + 1, 0, fa, USE_ORDER[(s - W8_BAR_B) / W8_FA_STRIDE]);
+#if !defined(ULL_ABL_NODMA)
             if (s >= W8_BAR_A && (s - W8_BAR_A) % W8_DMA_STRIDE == 0 && (s - W8_BAR_A) / W8_DMA_STRIDE < 8) {
                 const int pc = (s - W8_BAR_A) / W8_DMA_STRIDE;
                 if (pc < 4) glds16(xsrc[pc] + kox, bx + pc * 1024);
                 else glds16(wsrc[pc - 4] + kow, bw + (pc - 4) * 1024);
             }
+#endif
             mma1(s < 32 ? fa : fb, s & 31);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     // (the dump's pieces may still be landing: they touch nothing the epilogue uses, and s_endpgm waits for them)
 
+#if defined(ULL_ABL_NOEPI)
+    if (p.M > 0) return;
+#endif
     // ---- epilogue: acc[i][j][r] = D[n = n0 + wn*64 + i*16 + 4*fg + r][m = m0 + wm*128 + j*16 + fr] ----------
     if (split) {
         float* slab = p.ws + ((long)(bid - p.t_full) * p.sk + slice) * (BM * BN);
@@ -1806,6 +1909,9 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
     a.ldx = ldx; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.flags = flags;
     a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.rope_cols = rope_cols;
+#ifdef ULL_GEMM_STAMPS
+    a.stamps = ull_stamp_host_ptr;
+#endif
     const bool rope = rope_cos != nullptr;
     // short K and fewer than two rounds of 256x256 tiles (ViT patchify: K = 640, 128 / 288 tiles): the 128x128 kernel's 4x finer
     // tiles fill the chip better (measured 61 vs 70 us at B=32, 336^2)
@@ -1898,6 +2004,9 @@ static int gemm_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw,
     return ull_check_launch();
 }
 
+#ifdef ULL_GEMM_STAMPS
+extern "C" int ULL_FN(ull_debug_gemm_stamps_)(void* buf) { ull_stamp_host_ptr = (unsigned long long*)buf; return ULL_OK; }
+#endif
 extern "C" int ULL_FN(ull_gemm_)(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc,
                              const void* bias, const void* R, int64_t ldr,
                              int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream) {
@@ -1940,6 +2049,9 @@ extern "C" int ULL_FN(ull_patchify_)(const void* img, int64_t n_img, int64_t C, 
     a.nbm = (int)((M + BM - 1) / BM); a.nbn = (int)((N + BN - 1) / BN);
     a.t_full = 0; a.sk = 1; a.ws = nullptr; a.group_m = GROUP_M;
     a.rope_cos = a.rope_sin = nullptr; a.rope_cols = 0;
+#ifdef ULL_GEMM_STAMPS
+    a.stamps = nullptr;
+#endif
     int n_cu = 0;
     if (const int rc = gemm_device_state(&n_cu)) return rc;
     // one round of problem-sized strips when the batch allows it (C4: 32 x 576 patches = 64 strips of 288 x 4 column tiles = 256 blocks)
