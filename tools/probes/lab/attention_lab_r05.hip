@@ -112,6 +112,22 @@ ULL_DEV void score_quad(const AttnArgs& p, const f32x4_t& acc, int j0, uint32_t 
     hi = pack2e(o[2], o[3]);
 }
 
+// ---- round-6 experiment (ULL_ATTN_NO_PK): the packed fp32 pairs of the score / softmax chains as two SCALAR VALU instructions each.  The issue
+// probe (profiles/r06_valu_issue_costs_mfma_shadow.txt) prices a v_pk_*_f32 beside an MFMA at +6...+10 cycles where a scalar v_add / v_mul
+// costs +0.5: packed fp32 does not fit the matrix instruction's shadow.
+#ifdef ULL_ATTN_NO_PK
+struct apk_t { float x, y; };
+ULL_DEV float s_mul_(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+ULL_DEV float s_add_(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+ULL_DEV float s_sub_(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+ULL_DEV apk_t operator*(apk_t a, float s) { return apk_t{s_mul_(a.x, s), s_mul_(a.y, s)}; }
+ULL_DEV apk_t operator+(apk_t a, float s) { return apk_t{s_add_(a.x, s), s_add_(a.y, s)}; }
+ULL_DEV apk_t operator-(apk_t a, float s) { return apk_t{s_sub_(a.x, s), s_sub_(a.y, s)}; }
+ULL_DEV apk_t operator+(apk_t a, apk_t b) { return apk_t{s_add_(a.x, b.x), s_add_(a.y, b.y)}; }
+#else
+typedef f32x2_t apk_t;
+#endif
+
 // The same for a quad whose four keys are all attendable for every lane of the wave (no padding, below the causal diagonal, no
 // bias): only the scale + the two roundings remain.  ~85 % of the LLaMA / CLIP score quads take this path.
 // LLaMA / CLIP (S * scale): rnd(acc) two at a time through one packed convert, the scale as one packed multiply, and -- rounding to 16
@@ -126,7 +142,7 @@ ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& l
 #ifndef ULL_ATTN_NO_OPAQUE_PAIRS
         asm volatile("" : "+v"(a01), "+v"(a23));
 #endif
-        const f32x2_t x01 = f32x2_t{pk_lo(a01), pk_hi(a01)} * p.scale, x23 = f32x2_t{pk_lo(a23), pk_hi(a23)} * p.scale;
+        const apk_t x01 = apk_t{pk_lo(a01), pk_hi(a01)} * p.scale, x23 = apk_t{pk_lo(a23), pk_hi(a23)} * p.scale;
         if (row_max) *row_max = fmaxf(fmaxf(fmaxf(*row_max, x01.x), x01.y), fmaxf(x23.x, x23.y));
         lo = pack2e(x01.x, x01.y);
         hi = pack2e(x23.x, x23.y);
@@ -153,14 +169,14 @@ ULL_DEV void score_quad_clean(const AttnArgs& p, const f32x4_t& acc, uint32_t& l
 // two adds are one packed add, the third rounding IS the packed pair that is kept, and the row maximum takes the unrounded sums (rounding
 // is monotone; the caller rounds the maximum once).  wv23 = -inf in the lanes whose columns are the padding slots kw = 14, 15.
 // 21 vector instructions per window row instead of 45, same bits (the kernel is bound by its vector-issue slots: docs/experiments.md).
-ULL_DEV void score_quad_win(const f32x4_t& acc, float hb, const f32x2_t& wv01, const f32x2_t& wv23, uint32_t& lo, uint32_t& hi, float& row_max) {
+ULL_DEV void score_quad_win(const f32x4_t& acc, float hb, const apk_t& wv01, const apk_t& wv23, uint32_t& lo, uint32_t& hi, float& row_max) {
     // (the packed pairs are made opaque: seeing through pack -> unpack, the compiler converts every value on its own again)
     uint32_t a01 = pack2e(acc[0], acc[1]), a23 = pack2e(acc[2], acc[3]);
     asm volatile("" : "+v"(a01), "+v"(a23));
-    const f32x2_t x01 = f32x2_t{pk_lo(a01), pk_hi(a01)} + hb, x23 = f32x2_t{pk_lo(a23), pk_hi(a23)} + hb;
+    const apk_t x01 = apk_t{pk_lo(a01), pk_hi(a01)} + hb, x23 = apk_t{pk_lo(a23), pk_hi(a23)} + hb;
     uint32_t b01 = pack2e(x01.x, x01.y), b23 = pack2e(x23.x, x23.y);
     asm volatile("" : "+v"(b01), "+v"(b23));
-    const f32x2_t y01 = f32x2_t{pk_lo(b01), pk_hi(b01)} + wv01, y23 = f32x2_t{pk_lo(b23), pk_hi(b23)} + wv23;
+    const apk_t y01 = apk_t{pk_lo(b01), pk_hi(b01)} + wv01, y23 = apk_t{pk_lo(b23), pk_hi(b23)} + wv23;
     row_max = fmaxf(fmaxf(fmaxf(row_max, y01.x), y01.y), fmaxf(y23.x, y23.y));
     lo = pack2e(y01.x, y01.y);
     hi = pack2e(y23.x, y23.y);
@@ -175,11 +191,11 @@ ULL_DEV void softmax_win(uint32_t (&sp)[4][8], float mrow) {
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
-    f32x2_t e[28];
+    apk_t e[28];
 #pragma unroll
     for (int i = 0; i < 28; ++i) {
-        const f32x2_t t = (f32x2_t{pk_lo(sp[i / 8][i % 8]), pk_hi(sp[i / 8][i % 8])} - m) * 1.4426950408889634f;   // __expf(x) = exp2(x * log2 e)
-        e[i] = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        const apk_t t = (apk_t{pk_lo(sp[i / 8][i % 8]), pk_hi(sp[i / 8][i % 8])} - m) * 1.4426950408889634f;   // __expf(x) = exp2(x * log2 e)
+        e[i] = apk_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
         sum += e[i].x;
         sum += e[i].y;
     }
@@ -188,7 +204,7 @@ ULL_DEV void softmax_win(uint32_t (&sp)[4][8], float mrow) {
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int i = 0; i < 28; ++i) {
-        const f32x2_t q = e[i] * inv;
+        const apk_t q = e[i] * inv;
         sp[i / 8][i % 8] = pack2e(q.x, q.y);
     }
 }
@@ -672,7 +688,7 @@ void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefi
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     // __expf(x) = v_exp_f32(x * log2(e)), written out so that the subtraction and the multiply pair up (v_pk_*_f32)
-                    const f32x2_t t = (f32x2_t{pk_lo(sp[kt][i]), pk_hi(sp[kt][i])} - m) * 1.4426950408889634f;
+                    const apk_t t = (apk_t{pk_lo(sp[kt][i]), pk_hi(sp[kt][i])} - m) * 1.4426950408889634f;
                     sum += __builtin_amdgcn_exp2f(t.x);
                     sum += __builtin_amdgcn_exp2f(t.y);
                 }
@@ -686,8 +702,8 @@ void attn_reg_kernel(AttnArgs p) {                               // (LLaMA prefi
             if (kt < nkt_w) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const f32x2_t t = (f32x2_t{pk_lo(sp[kt][i]), pk_hi(sp[kt][i])} - m) * 1.4426950408889634f;
-                    const f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * inv;
+                    const apk_t t = (apk_t{pk_lo(sp[kt][i]), pk_hi(sp[kt][i])} - m) * 1.4426950408889634f;
+                    const apk_t e = apk_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * inv;
                     sp[kt][i] = pack2e(e.x, e.y);
                 }
                 if constexpr (EXACT) __builtin_amdgcn_sched_barrier(0);
@@ -968,7 +984,7 @@ __global__ __launch_bounds__(SW_NWV * 64) void sam_window_kernel(AttnArgs p, int
                 uint32_t* w = (uint32_t*)&q[ks];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x2_t v = f32x2_t{pk_lo(w[j]), pk_hi(w[j])} * p.q_scale;
+                    const apk_t v = apk_t{pk_lo(w[j]), pk_hi(w[j])} * p.q_scale;
                     w[j] = pack2e(v.x, v.y);
                 }
             }
@@ -1016,7 +1032,7 @@ __global__ __launch_bounds__(SW_NWV * 64) void sam_window_kernel(AttnArgs p, int
                         acc = mfma16(kf, qf[ks], acc);
                     }
                     const float hb = e2f(*(brow_h - (kt * 4 + ns)));
-                    score_quad_win(acc, hb, f32x2_t{wv[0], wv[1]}, f32x2_t{wv[2], wv[3]}, sp[kt][ns * 2], sp[kt][ns * 2 + 1], mrow);
+                    score_quad_win(acc, hb, apk_t{wv[0], wv[1]}, apk_t{wv[2], wv[3]}, sp[kt][ns * 2], sp[kt][ns * 2 + 1], mrow);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1520,7 +1536,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
             if constexpr (HOIST != 0) {
                 // rnd(rnd(rnd(acc) + rel_h) + rel_w) two values at a time (score_quad_win: packed converts and adds, 21 vector
                 // instructions per quad instead of 45; the maximum is taken on the unrounded sums and rounded once below)
-                score_quad_win(acc, rh, f32x2_t{rw[ns * 4], rw[ns * 4 + 1]}, f32x2_t{rw[ns * 4 + 2], rw[ns * 4 + 3]}, sq[ns * 2], sq[ns * 2 + 1], tm);
+                score_quad_win(acc, rh, apk_t{rw[ns * 4], rw[ns * 4 + 1]}, apk_t{rw[ns * 4 + 2], rw[ns * 4 + 3]}, sq[ns * 2], sq[ns * 2 + 1], tm);
             } else {
                 const uint32_t mk = *(const uint32_t*)(maskb + kt * KT + ns * 16 + fg * 4);
                 score_quad<FL>(p, acc, kt * KT + ns * 16 + fg * 4, mk, qi, koff, brow, bh_off, bw_off, sq[ns * 2], sq[ns * 2 + 1], &tm);
@@ -1544,7 +1560,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_kernel(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             // __expf(x) = v_exp_f32(x * log2(e)), written out so that the subtraction and the multiply pair up (v_pk_*_f32)
-            const f32x2_t t = (f32x2_t{pk_lo(sq[i]), pk_hi(sq[i])} - m) * 1.4426950408889634f;
+            const apk_t t = (apk_t{pk_lo(sq[i]), pk_hi(sq[i])} - m) * 1.4426950408889634f;
             pk[i] = pack2e(__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y));
         }
         // The row sum runs over the ROUNDED probabilities, so that O / l is a true weighted mean of V rows: one more "V^T row" of ones
@@ -1823,7 +1839,7 @@ __global__ __launch_bounds__(256, 2) void sam_global_kernel(AttnArgs p) {
             float tm = -INFINITY;
 #pragma unroll
             for (int ns = 0; ns < 4; ++ns)
-                score_quad_win(acc[g][ns], rh, f32x2_t{rw[g][ns * 4], rw[g][ns * 4 + 1]}, f32x2_t{rw[g][ns * 4 + 2], rw[g][ns * 4 + 3]}, sq[g][ns * 2],
+                score_quad_win(acc[g][ns], rh, apk_t{rw[g][ns * 4], rw[g][ns * 4 + 1]}, apk_t{rw[g][ns * 4 + 2], rw[g][ns * 4 + 3]}, sq[g][ns * 2],
                                sq[g][ns * 2 + 1], tm);
             tm = rnd(tm);
             tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
@@ -1875,7 +1891,7 @@ __global__ __launch_bounds__(256, 2) void sam_global_kernel(AttnArgs p) {
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const f32x2_t t = (f32x2_t{pk_lo(sq[g][i]), pk_hi(sq[g][i])} - m[g]) * 1.4426950408889634f;
+                const apk_t t = (apk_t{pk_lo(sq[g][i]), pk_hi(sq[g][i])} - m[g]) * 1.4426950408889634f;
                 pk[g][i] = pack2e(__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y));
             }
         }

@@ -350,7 +350,7 @@ ULL_DEV void lds_tr_wait(u32x2_t (&a)[N], u32x2_t (&b)[N]) {      // ties the va
 // of DMA pieces per tile) streams through a ring of ULL_ATTN_RING (2: measured best); everything else through two
 template <int HDP, int NT, int NWV, bool EXACT, bool VROW>
 constexpr int attn_reg_nbuf() {
-constexpr int ULL_ATTN_RING = 2;
+    constexpr int ULL_ATTN_RING = 2;
     return EXACT ? 2 * NT : ((VROW && (HDP / 8) % NWV == 0 && NT >= 2) ? ULL_ATTN_RING : 2);
 }
 

@@ -436,22 +436,42 @@ class UllavaCoreForCausalLM(nn.Module):
                     mod.weight.data = torch.empty(0, device=mod.weight.device, dtype=mod.weight.dtype)
         return self
 
+    # The version tuples are read on EVERY forward (a decode step too): walking the module tree for them cost 0.5 ms of host time per step
+    # (nn.Module.__getattr__ is Python).  The tensors are collected once per pack -- whatever re-binds a parameter (`_apply`, load_state_dict,
+    # add_lora / merge_lora) also drops the pack, and with it these lists.
+    def _ver_tensors(self, which: str):
+        cache = self.__dict__.setdefault("_ver_cache", {})
+        pk = self._packed
+        if cache.get("pack") is not pk or pk is None:
+            cache.clear()
+            cache["pack"] = pk
+        lst = cache.get(which)
+        if lst is None:
+            if which == "lora":
+                lst = [p_ for l in self.model.layers for t in ("q_proj", "k_proj", "v_proj") if hasattr(getattr(l.self_attn, t), "lora_A")
+                       for p_ in (getattr(l.self_attn, t).lora_A.weight, getattr(l.self_attn, t).lora_B.weight)]
+            elif which == "llama":
+                lst = [getattr(h, n).weight for l in self.model.layers
+                       for h, ns in ((l.self_attn, ("q_proj", "k_proj", "v_proj")), (l.mlp, ("gate_proj", "up_proj"))) for n in ns]
+            else:
+                ve = self.vision_encoder
+                lst = [ve.embeddings.patch_embedding.weight] + [p_ for l in ve.encoder.layers for n in ("q_proj", "k_proj", "v_proj")
+                                                                  for p_ in (getattr(l.self_attn, n).weight, getattr(l.self_attn, n).bias)]
+            if pk is not None:
+                cache[which] = lst
+        return lst
+
     def _lora_versions(self):
         if getattr(self, "_lora", None) is None:
             return None
-        return tuple(p_._version for l in self.model.layers for t in ("q_proj", "k_proj", "v_proj") if hasattr(getattr(l.self_attn, t), "lora_A")
-                     for p_ in (getattr(l.self_attn, t).lora_A.weight, getattr(l.self_attn, t).lora_B.weight))
+        return tuple(p_._version for p_ in self._ver_tensors("lora"))
 
     def _llama_versions(self):
         """version counters of the LLaMA weights the packs hold COPIES of (q|k|v concatenated, gate|up interleaved)."""
-        return tuple(getattr(h, n).weight._version for l in self.model.layers
-                     for h, ns in ((l.self_attn, ("q_proj", "k_proj", "v_proj")), (l.mlp, ("gate_proj", "up_proj"))) for n in ns)
+        return tuple(p_._version for p_ in self._ver_tensors("llama"))
 
     def _clip_versions(self):
-        ve = self.vision_encoder
-        return (ve.embeddings.patch_embedding.weight._version,) + tuple(
-            p_._version for l in ve.encoder.layers for n in ("q_proj", "k_proj", "v_proj") for p_ in (getattr(l.self_attn, n).weight,
-                                                                                                      getattr(l.self_attn, n).bias))
+        return tuple(p_._version for p_ in self._ver_tensors("clip"))
 
     def _pk(self, for_llama: bool = False):
         """The packed weights, re-made when a parameter they were copied from has been written since (`._version`: an optimizer step's

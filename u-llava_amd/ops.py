@@ -135,8 +135,9 @@ def _streamk_ws(device: torch.device, stream_id: int):
 # Latency mode for single-image prefills (M < 1024): split-K in the 128x128 kernel.  OFF by default: it makes a sample's result depend on
 # the batch it is computed in (the fp32 summation order of K changes with the split), and the path's invariant -- sample b of a batch of
 # 32 equals the single-sample run bit for bit through every layer (tests/test_full_depth_gpu.py) -- is worth more than 5 ms of prefill.
-# ULL_SMALL_M_SPLIT_K=1 or `with ops.small_m_split_k(True):` turns it on (C2 shape at batch 1: 16.9 -> 11.9 ms, 59 -> 84 images/s).
-_SMALL_M_SPLIT_K = [os.environ.get("ULL_SMALL_M_SPLIT_K", "0") == "1"]
+# `with ops.small_m_split_k(True):` turns it on (C2 shape at batch 1: 16.9 -> 11.9 ms, 59 -> 84 images/s).  (Round 6: no environment variable
+# reads this any more -- the product has no environment switches.)
+_SMALL_M_SPLIT_K = [False]
 
 
 class small_m_split_k:
