@@ -483,6 +483,34 @@ int ull_sam_blocks_bf16(const ull_sam_block* blocks, int64_t n_blocks, void* x, 
                         int64_t g, int64_t nH, int64_t hd, int64_t I, float eps, void* ws, int64_t ws_bytes, int64_t sk_min_k, const void* zeros,
                         void* stream);
 
+/* ==== fp32 build of the inference path (u-llava_amd/csrc/f32.hip): `--dtype fp32` of inference_ullava.py:25,164-168 ====
+ * float32 tensors everywhere, no intermediate roundings (the reference's fp32 graph has none); same arguments, layouts and flags as the *_bf16
+ * function of the same name, with these differences: ull_gemm_f32 accepts any M / N / K / strides, ignores ws and refuses the tile-major
+ * flags; ull_attention_f32 takes V either as rows (vt_len = 0) or as the ull_transpose_v image for ANY shape, head_dim <= 128, rel_mode 0 / 1
+ * only.  Contractions run on v_mfma_f32_16x16x4_f32 (IEEE fp32 products and sums).  Correctness path: no fused / tiled fast path has an
+ * fp32 twin (qkv+RoPE epilogue, patchify, window attention, fused mask decoder, coarse layer stacks), and pure data movement (embed_splice,
+ * gather_rows, window_partition) is served by the 16-bit entries on the same bytes viewed as rows of twice as many 16-bit elements. */
+int ull_gemm_f32(const void* X, int64_t ldx, const void* W, int64_t ldw, void* C, int64_t ldc, const void* bias, const void* R, int64_t ldr, int64_t M, int64_t N, int64_t K, int flags, void* ws, int64_t ws_bytes, void* stream);
+int ull_attention_f32(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* K, int64_t k_bs, int64_t k_hs, int64_t k_ss, const void* Vt, int64_t vt_bs, int64_t vt_hs, int64_t vt_ds, int64_t vt_len, void* O, int64_t o_bs, int64_t o_hs, int64_t o_ss, const void* key_mask, int64_t B, int64_t H, int64_t Sq, int64_t Sk, int64_t hd, int causal, int scale_mode, float scale, float q_scale, const void* rel_h, const void* rel_w, int64_t rel_kh, int64_t rel_kw, int rel_mode, const void* zeros, void* stream);
+int ull_transpose_v_f32(const void* v, int64_t v_bs, int64_t v_ss, void* vt, int64_t B, int64_t S, int64_t H, int64_t hd, int64_t pitch, void* stream);
+int ull_rmsnorm_f32(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+int ull_layernorm_f32(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int64_t rows, int64_t D, float eps, void* stream);
+int ull_clip_embed_ln_f32(const void* patch, int64_t ldp, const void* cls, const void* pos, const void* w, const void* b, void* y, int64_t ldy, int64_t n_img, int64_t tokens, int64_t D, float eps, void* stream);
+int ull_layernorm2d_cl_f32(const void* x, const void* w, const void* b, void* y, int64_t rows, int64_t C, float eps, int gelu, void* stream);
+int ull_rope_inplace_f32(void* x, int64_t row_stride, const void* positions, const void* inv_freq, int64_t tokens, int64_t n_heads, int64_t hd, void* stream);
+int ull_rope_append_f32(void* qkv, int64_t row_stride, const void* positions, const void* inv_freq, int64_t B, int64_t S, int64_t H, int64_t hd, void* k_cache, void* vt_cache, int64_t smax, int64_t past, void* stream);
+int ull_im2col_f32(const void* img, void* out, int64_t n_img, int64_t C, int64_t H, int64_t W, int64_t ps, int64_t Kp, void* stream);
+int ull_im2col3x3_f32(const void* x, void* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+int ull_video_pool_f32(const void* f, void* out, int64_t B, int64_t T, int64_t N, int64_t D, int64_t tok_pitch, int64_t tok_off, void* stream);
+int ull_add_rows_f32(const void* a, const void* b, void* out, int64_t rows, int64_t D, int64_t b_rows, void* stream);
+int ull_window_unpartition_add_f32(const void* win, const void* shortcut, void* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t ws, void* stream);
+int ull_sam_relpos_f32(const void* q, int64_t q_bs, int64_t q_hs, int64_t q_ss, const void* rel_pos_h, const void* rel_pos_w, void* out_h, void* out_w, int64_t NB, int64_t nH, int64_t KH, int64_t KW, int64_t hd, void* stream);
+int ull_interp_rows_linear_f32(const void* x, void* y, int64_t L, int64_t M, int64_t C, void* stream);
+int ull_mask_matmul_f32(const void* hyper, const void* up, void* masks, int64_t n, int64_t T, int64_t C, int64_t G, void* stream);
+int ull_greedy_step_f32(const void* logits, int64_t row_stride, int64_t B, int64_t V, void* unfinished, const void* eos, int64_t n_eos, int64_t pad, int has_pad, void* seq, int64_t seq_ld, int64_t pos, void* alive, void* stream);
+int ull_shifted_cross_entropy_f32(const void* logits, int64_t ld, const void* labels, int64_t B, int64_t S, int64_t V, void* out, void* stream);
+/* ==== END fp32 build ==== */
+
 /* ==== BEGIN fp16 twins (generated by tools/gen_header_f16.py) ==== */
 /* IEEE binary16 build of every dtype-dependent entry point: same arguments, layouts, flags and rounding points as the *_bf16
  * function of the same name; every 16-bit element is an fp16 instead of a bf16 (the reference's `--dtype fp16`,

@@ -115,6 +115,10 @@ SIGNATURES = {
 # every dtype-dependent entry point exists twice: ull_*_bf16 (bfloat16 build) and ull_*_f16 (IEEE binary16 build), same signature
 SIGNATURES.update({name[:-4] + "f16": args for name, args in list(SIGNATURES.items()) if name.endswith("_bf16")})
 
+# fp32 build of the inference path (csrc/f32.hip): the same signatures as the bf16 entries of the same name
+F32_TWINS = ['ull_gemm', 'ull_attention', 'ull_transpose_v', 'ull_rmsnorm', 'ull_layernorm', 'ull_clip_embed_ln', 'ull_layernorm2d_cl', 'ull_rope_inplace', 'ull_rope_append', 'ull_im2col', 'ull_im2col3x3', 'ull_video_pool', 'ull_add_rows', 'ull_window_unpartition_add', 'ull_sam_relpos', 'ull_interp_rows_linear', 'ull_mask_matmul', 'ull_greedy_step', 'ull_shifted_cross_entropy']
+SIGNATURES.update({name + "_f32": SIGNATURES[name + "_bf16"] for name in F32_TWINS})
+
 # fp16-only entry points (no bf16 twin): the fp32 neck of an fp16 SAM encoder (image_encoder.py:117-124)
 SIGNATURES["ull_neck_layernorm2d_f32in_f16"] = [_ptr, _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr]
 

@@ -278,9 +278,10 @@ class UllavaCoreForCausalLM(nn.Module):
 
     def __init__(self, config: UllavaCoreConfig, device=None, dtype=BF16):
         super().__init__()
-        if dtype not in (BF16, torch.float16):
-            raise NotImplementedError("the MI355X path has bf16 (reference configs: bf16: true) and fp16 (inference_ullava.py --dtype fp16) "
-                                      "kernel builds; fp32 is not supported")
+        if dtype not in (BF16, torch.float16, torch.float32):
+            raise NotImplementedError("the MI355X path has bf16 (reference configs: bf16: true), fp16 and fp32 (inference_ullava.py --dtype "
+                                      "fp16 / fp32) kernel builds")
+        # (fp32: csrc/f32.hip -- plain kernels for the inference path, no fused / tiled fast paths, no backward)
         self.config = config
         D = config.hidden_size
         self.model = _Holder()
@@ -416,7 +417,8 @@ class UllavaCoreForCausalLM(nn.Module):
         wp[:, :K] = w.reshape(w.shape[0], K)
         pk["patch_w"], pk["patch_Kp"] = wp, Kp
         # fused patchify (A tiles DMA'd from the pixels): (c, ky) segments of 16, see ops.pack_patch_weight
-        pk["patch_wp"] = ops.pack_patch_weight(w) if (vc.patch_size <= 16 and vc.patch_size % 2 == 0 and vc.image_size >= 16) else None
+        pk["patch_wp"] = ops.pack_patch_weight(w) if (vc.patch_size <= 16 and vc.patch_size % 2 == 0 and vc.image_size >= 16 and
+                                                      w.dtype != torch.float32) else None
         # tile-major copies for the prefill-shape GEMM (+13.5 GB for LLaMA-7B; sized for 288 GB of HBM).  The row-major
         # tensors stay: they feed the decode GEMV, which streams whole rows.
         for d in pk["llama"]:
@@ -521,7 +523,8 @@ class UllavaCoreForCausalLM(nn.Module):
                               ve.pre_layrnorm.weight, ve.pre_layrnorm.bias, n, S, vc.layer_norm_eps).view(n * S, Dv)
         nsel = self._selected_layer_count()
         I = vc.intermediate_size
-        coarse = ops.coarse_ok() and nsel > 0 and hd == 64 and n * S > 16 and 16 < S <= 704 and Dv % 64 == 0 and I % 64 == 0
+        coarse = ops.coarse_ok() and nsel > 0 and hd == 64 and n * S > 16 and 16 < S <= 704 and Dv % 64 == 0 and I % 64 == 0 and \
+            h.dtype != torch.float32
         if coarse:
             # one C call for the tower's layers (csrc/layers.hip): the same launches as the loop below, bit-identical results
             stack = pk.get("_c_clip")
@@ -850,12 +853,13 @@ class UllavaCoreForCausalLM(nn.Module):
         T = B * S
         # prefill with LLaMA's head_dim: RoPE runs inside the QKV GEMM's epilogue from one cos / sin table per forward (the
         # positions are the same for every layer); other shapes (tiny test models, decode steps) use the stand-alone kernels
-        fuse_rope = hd == 128 and T > 4 and D % 64 == 0 and not (cache is not None and past > 0)
+        f32 = x.dtype == torch.float32       # fp32 build: stand-alone RoPE kernels, one generic GEMM / attention (csrc/f32.hip)
+        fuse_rope = hd == 128 and T > 4 and D % 64 == 0 and not (cache is not None and past > 0) and not f32
         # generation steps of at most 4 tokens (the GEMV shapes): RoPE and the cache append run in the q|k|v GEMV's epilogue, from the
         # same per-forward table
         # (that kernel stages the T x D activations in 32 KB of LDS: LLaMA-7B at T = 4 is exactly the limit; wider models / more rows take the
         # stand-alone RMSNorm + RoPE-append kernels below)
-        fuse_append = cache is not None and past > 0 and T <= 4 and hd % 2 == 0 and D % 8 == 0 and T * D * 2 <= 32768
+        fuse_append = cache is not None and past > 0 and T <= 4 and hd % 2 == 0 and D % 8 == 0 and T * D * 2 <= 32768 and not f32
         rope_cs = ops.rope_table(pos, inv_freq, x.dtype) if (fuse_rope or fuse_append) else None
         all_h = []
         I = cfg.intermediate_size

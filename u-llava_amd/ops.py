@@ -15,7 +15,10 @@ from . import _lib
 
 BF16 = torch.bfloat16
 F16 = torch.float16
-_SFX = {BF16: "bf16", F16: "f16"}                           # entry-point suffix of the two builds of every dtype-dependent kernel
+F32 = torch.float32
+# entry-point suffix by element type: the two 16-bit builds of every dtype-dependent kernel, and the fp32 build of the inference path
+# (csrc/f32.hip: `--dtype fp32`, plain kernels on the exact fp32 matrix instruction -- a correctness path, no fused / tiled fast paths)
+_SFX = {BF16: "bf16", F16: "f16", F32: "f32"}
 DT_CODE = {torch.float32: 0, BF16: 1, F16: 2}               # ULL_DT_* of the dtype-coded entry points
 EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_RELU, EPI_RESID, EPI_SWIGLU, EPI_F32 = 1, 1 << 1, 2 << 1, 3 << 1, 8, 16, 32
 EPI_BIAS_ROUNDED = 256
@@ -44,6 +47,16 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _copy_sfx(dtype, D: int):
+    """(entry suffix, row width in that entry's elements) of a PURE data-movement kernel: fp32 rows go through the 16-bit kernel as rows of
+    twice as many 16-bit elements (the same bytes; csrc/f32.hip has no copy kernels of its own)."""
+    if dtype == F32:
+        if D % 4:
+            raise RuntimeError("u-llava_amd: fp32 rows must be a multiple of 4 elements wide")
+        return "bf16", 2 * D
+    return _SFX[dtype], D
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -55,8 +68,7 @@ def _chk(t: torch.Tensor, name: str, dtype=None):
         raise RuntimeError(f"u-llava_amd: `{name}` must live on the GPU (no CPU path exists)")
     if dtype is None:
         if t.dtype not in _SFX:
-            raise RuntimeError(f"u-llava_amd: `{name}` must be torch.bfloat16 or torch.float16, got {t.dtype} "
-                               "(the MI355X path has bf16 and fp16 kernel builds; fp32 models are not supported)")
+            raise RuntimeError(f"u-llava_amd: `{name}` must be torch.bfloat16, torch.float16 or torch.float32, got {t.dtype}")
     elif t.dtype != dtype:
         raise RuntimeError(f"u-llava_amd: `{name}` must be {dtype}, got {t.dtype}")
     if t.dim() and t.stride(-1) != 1:
@@ -89,7 +101,7 @@ def tile_major(w: torch.Tensor) -> torch.Tensor:
 
 def register_tiled(w: torch.Tensor) -> None:
     """Keep a tile-major copy of a weight for the prefill-shape GEMM (the row-major original still feeds the decode GEMV)."""
-    if w.dim() == 2 and w.shape[1] % 64 == 0 and w.shape[0] >= 512 and w.shape[1] >= 128 and w.is_contiguous():
+    if w.dim() == 2 and w.shape[1] % 64 == 0 and w.shape[0] >= 512 and w.shape[1] >= 128 and w.is_contiguous() and w.dtype != F32:
         ptr = w.data_ptr()
         _TILED[ptr] = [weakref.ref(w, lambda _r, _p=ptr: _TILED.pop(_p, None) if (_TILED.get(_p) or (None,))[0] is _r else None),
                        tile_major(w.detach()), w._version]    # the copy is dropped when the weight tensor dies
@@ -184,6 +196,25 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     lead = tuple(x.shape[:-1])
     if x.shape[-1] != K:
         raise RuntimeError(f"u-llava_amd.linear: K mismatch {x.shape[-1]} vs {K}")
+    if x.dtype == F32:
+        # fp32 build: one plain GEMM kernel for every shape (any M / N / K / strides), the preceding RMSNorm as its own launch
+        if rms_w is not None:
+            x = rmsnorm(x, rms_w, rms_eps)
+            M, ldx = _rows(x)
+        if w.stride(1) != 1:
+            w = w.contiguous()
+        n_out = N // 2 if swiglu else N
+        if out is None:
+            out = torch.empty(*lead, n_out, device=x.device, dtype=F32)
+        flags = ACTS[act] | (EPI_BIAS if bias is not None else 0) | (EPI_RESID if residual is not None else 0) | (EPI_SWIGLU if swiglu else 0)
+        if bias is not None:
+            _chk(bias, "bias", F32)
+        ldr = 0
+        if residual is not None:
+            _chk(residual, "residual", F32)
+            ldr = _rows(residual)[1]
+        _lib.call("ull_gemm_f32", _p(x), ldx, _p(w), w.stride(0), _p(out), _rows(out)[1], _p(bias), _p(residual), ldr, M, N, K, flags, None, 0, _stream())
+        return out
     # batched decode steps against LLaMA-sized weights: the weight stream on the matrix cores (the GEMV is FMA-bound from M = 4 on and
     # measured slower from M = 3 on (decode step at batch 3: 4.47 vs 4.24 ms; at batch 2 the GEMV wins, 4.00 vs 4.08); the tiled GEMM's grid
     # is a few dozen blocks at these M).  Small weights stay where they were.
@@ -374,6 +405,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     transpose on the fly (LLaMA / CLIP prefill) take it directly, for any other shape the V^T image is made here first."""
     _chk(q, "q"); _chk(k, "k", q.dtype); _chk(vt, "vt", q.dtype); _chk(out, "out", q.dtype)
     rel_mode, kh, kw = 0, 0, 0
+    if rel_h is not None and rel_pos_hw is not None and q.dtype == F32:
+        # fp32 build: the per-query bias tables come from their own kernel (rel_mode 1); the 16-bit kernels build them in place (rel_mode 2)
+        kh, kw = rel_pos_hw
+        rel_h, rel_w = sam_relpos(q, q_strides, fit_rel_pos(rel_h, kh), fit_rel_pos(rel_w, kw), B, H, kh, kw, hd)
+        rel_pos_hw = None
     if rel_h is not None:
         _chk(rel_h, "rel_h", q.dtype); _chk(rel_w, "rel_w", q.dtype)
         if rel_pos_hw is not None:
@@ -529,8 +565,9 @@ def embed_splice(ids: torch.Tensor, table: torch.Tensor, img_feat: Optional[torc
     if vid_feat is not None:
         _chk(vid_feat, "vid_feat", table.dtype)
         n_vid = vid_feat.shape[-2]
-    _lib.call("ull_embed_splice_" + _SFX[table.dtype], _p(ids), _p(table), _p(img_feat), img_tokens, img_pitch, img_off, _p(vid_feat), n_vid, _p(spans),
-              _p(out), B, S, D, table.shape[0], _stream())
+    sfx, De = _copy_sfx(table.dtype, D)
+    _lib.call("ull_embed_splice_" + sfx, _p(ids), _p(table), _p(img_feat), img_tokens, img_pitch, img_off, _p(vid_feat), n_vid, _p(spans),
+              _p(out), B, S, De, table.shape[0], _stream())
     return out
 
 
@@ -564,7 +601,9 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     n, D = idx.numel(), src.shape[-1]
     out = torch.empty(n, D, device=src.device, dtype=src.dtype)
     if n:
-        _lib.call("ull_gather_rows_" + _SFX[src.dtype], _p(src), src.stride(-2), _p(idx), _p(out), D, n, D, _stream())
+        sfx, De = _copy_sfx(src.dtype, D)
+        k = De // D
+        _lib.call("ull_gather_rows_" + sfx, _p(src), src.stride(-2) * k, _p(idx), _p(out), De, n, De, _stream())
     return out
 
 
@@ -585,7 +624,8 @@ def window_partition(x: torch.Tensor, B: int, H: int, W: int, ws: int) -> torch.
     C = x.shape[-1]
     nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
     out = torch.empty(B * nW * ws * ws, C, device=x.device, dtype=x.dtype)
-    _lib.call("ull_window_partition_" + _SFX[x.dtype], _p(x), _p(out), B, H, W, C, ws, _stream())
+    sfx, Ce = _copy_sfx(x.dtype, C)
+    _lib.call("ull_window_partition_" + sfx, _p(x), _p(out), B, H, W, Ce, ws, _stream())
     return out
 
 

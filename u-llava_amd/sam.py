@@ -130,7 +130,7 @@ class SamEngine:
         pk = {}
         w = enc.patch_embed.proj.weight
         pk["patch_w"] = w.reshape(C, -1).contiguous()                        # K = 3*16*16 = 768 (multiple of 64)
-        pk["patch_wp"] = ops.pack_patch_weight(w) if (cfg.patch_size <= 16 and cfg.patch_size % 2 == 0) else None
+        pk["patch_wp"] = ops.pack_patch_weight(w) if (cfg.patch_size <= 16 and cfg.patch_size % 2 == 0 and w.dtype != torch.float32) else None
         pk["pos"] = enc.pos_embed.reshape(-1, C).contiguous()
         pk["neck0"] = enc.neck[0].weight.reshape(D, C).contiguous()
         pk["neck2"] = enc.neck[2].weight.permute(0, 2, 3, 1).reshape(D, 9 * D).contiguous()   # (ky,kx,ci) columns
@@ -169,7 +169,7 @@ class SamEngine:
             trace["embed"] = x.view(B, g, g, C)
         I = enc.blocks[0].mlp.lin1.weight.shape[0] if len(enc.blocks) else 0
         coarse = (trace is None and ops.coarse_ok() and len(enc.blocks) > 0 and hd == 80 and g == 64 and cfg.window_size == 14 and C % 64 == 0
-                  and I % 64 == 0 and all(b.attn.qkv.bias is not None for b in enc.blocks))
+                  and I % 64 == 0 and all(b.attn.qkv.bias is not None for b in enc.blocks) and x.dtype != torch.float32)
         if coarse:
             # one C call for all blocks (csrc/layers.hip): the same launches as the loop below, bit-identical results
             stack = pk.get("_c_blocks")
@@ -186,7 +186,7 @@ class SamEngine:
             glob = i in cfg.global_attn_indexes
             ws = 0 if glob else cfg.window_size
             y = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, 1e-6)
-            if ws == 14 and hd == 80 and blk.attn.qkv.bias is not None:
+            if ws == 14 and hd == 80 and blk.attn.qkv.bias is not None and x.dtype != torch.float32:
                 # the path's own window shape: the tokens stay in image order, the attention kernel does the window addressing and
                 # takes the q|k|v of the reference's zero-padded positions from the qkv bias -- no partition / unpartition passes
                 # and no GEMM rows for the padding (25 windows x 196 = 4900 positions for 4096 tokens), and reads V through the
@@ -352,7 +352,7 @@ class SamEngine:
         out_tok = torch.cat([md.iou_token.weight, md.mask_tokens.weight], dim=0)                  # [1+nm, D]
         tokens = torch.cat([out_tok.unsqueeze(0).expand(n, -1, -1), text_embeds.unsqueeze(1)], dim=1).contiguous()   # [n, T, D]
         T = tokens.shape[1]
-        if trace is None and self.fused_decoder and self._fusable(D, P, T, nm):
+        if trace is None and self.fused_decoder and self._fusable(D, P, T, nm) and tokens.dtype != torch.float32:
             return self._decode_fused(image_embedding_tm, tokens, image_index, n, D, P, g, nm, T)
         src = ops.add_rows(image_embedding_tm.reshape(-1, D), self.sam.prompt_encoder.no_mask_embed.weight)   # + dense (no-mask) embedding
         if image_index is None:
