@@ -62,8 +62,11 @@ def test_core_load_reports_mismatches(tmp_path):
     m3 = M.UllavaCoreForCausalLM(C.UllavaCoreConfig(**_tiny_core_cfg()))
     missing, unexpected = K.load_into(m3, d, strict=False)
     assert missing == ["lm_head.weight"] and unexpected == ["bogus.weight"]
+    # `--dtype fp32` (inference_ullava.py:25,164-168): round 6 has an fp32 kernel build -- the checkpoint's 16-bit values load exactly
+    m32 = M.UllavaCoreForCausalLM.from_pretrained(d, torch_dtype=torch.float32, strict=False)
+    assert m32.dtype == torch.float32 and torch.equal(m32.model.norm.weight, m3.model.norm.weight.float())
     with pytest.raises(NotImplementedError):
-        M.UllavaCoreForCausalLM.from_pretrained(d, torch_dtype=torch.float32)       # bf16 and fp16 kernel builds exist, fp32 does not
+        M.UllavaCoreForCausalLM.from_pretrained(d, torch_dtype=torch.float64)
 
 
 def test_ullava_roundtrip_and_missing_sam_encoder(tmp_path):

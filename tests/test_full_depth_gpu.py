@@ -443,7 +443,7 @@ def _ref_models():
                mm_token_ids=dict(bench.MM), vocab_size=32011)
     models = {}
     with torch.no_grad():
-        for dt in (torch.bfloat16, torch.float16):
+        for dt in (torch.bfloat16, torch.float16, torch.float32):          # (float32: the fp32 build, holding the bf16-ROUNDED values -- the fixtures' "truth" model)
             m = MU.UllavaForCausalLM(C.UllavaConfig(llm_config=llm, seg_token_idx=bench.SEG, loc_token_idx=bench.LOC), device=DEV, dtype=dt)
             m.llm.strict_checks = False
             models[dt] = m
@@ -458,7 +458,7 @@ def _ref_models():
             for i in range(0, len(keys), 48):
                 for k, t in ex.map(gen, keys[i:i + 48]):
                     for dt in models:
-                        sds[dt][k].data.copy_(t.to(dt))
+                        sds[dt][k].data.copy_(t.to(dt) if dt != torch.float32 else t.to(torch.bfloat16).float())
         for m in models.values():
             m.llm._packed = None                                   # (the re-layouts are made from the filled parameters on first use)
             if hasattr(m, "_sam"):
@@ -563,6 +563,64 @@ def _res_against_reference_fixture(tag, dt):
 @pytest.mark.parametrize("tag,dt", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
 def test_res_full_depth_against_reference_fixture(tag, dt):
     _res_against_reference_fixture(tag, dt)
+
+
+def test_full_depth_fp32_against_the_references_fp32_runs():
+    """`--dtype fp32` (inference_ullava.py:25,164-168) at FULL size: the fp32 build (csrc/f32.hip) holding the bf16-rounded weights against the
+    reference's own fp32 runs on those weights -- the "truth" halves of the G15 / G16 bf16 fixtures (UllavaCoreForCausalLM.forward on C1,
+    UllavaForCausalLM.forward(inference=True) on batch-1 C3).  fp32 has no rounding points: the bound is summation-order noise through 32 LLaMA +
+    32 SAM blocks (1e-4 of each tensor's maximum), token ids equal wherever the fp32 top-1 / top-2 gap exceeds 1e-3, mask signs equal where
+    |logit| > 1e-3 of the maximum."""
+    from helpers import digest_matches
+    model = _ref_models()[torch.float32]
+    assert model.dtype == torch.float32
+    rec = {}
+    fx = load_fixture("g15_c1_full_depth_bf16.pt")
+    with torch.no_grad():
+        out = model.llm.forward(input_ids=fx["input_ids"].to(DEV), attention_mask=fx["attention_mask"].to(DEV), images=fx["images"].float().to(DEV),
+                                output_hidden_states=True)
+    assert out.logits.dtype == torch.float32 and tuple(out.logits.shape) == (1, 291, 32011)
+    st = fx["hid_stride"]
+    for li in fx["hid_layers"]:
+        e = float((out.hidden_states[li][0, :, ::st].cpu() - fx["truth_hidden"][li]).abs().max()) / fx["truth_hidden_absmax"][li]
+        rec[f"c1_hidden_{li}"] = e
+        assert e <= 1e-4, (li, e)
+
+    def logits_check(lg, lrec, what):
+        e_r = float((lg[lrec["rows"]].cpu() - lrec["truth_rows"]).abs().max()) / lrec["truth_absmax"]
+        e_c = float((lg[:, ::lrec["col_stride"]].cpu() - lrec["truth_cols"]).abs().max()) / lrec["truth_absmax"]
+        gap = lrec["truth_top_values"][:, 0] - lrec["truth_top_values"][:, 1]
+        am = lg.argmax(-1).cpu()
+        clear = gap > 1e-3
+        rec[what] = dict(rows=e_r, cols=e_c, ids_equal_all=float((am == lrec["truth_argmax"].long()).float().mean()), positions_clear=int(clear.sum()))
+        assert e_r <= 1e-4 and e_c <= 1e-4, rec[what]
+        assert bool((am == lrec["truth_argmax"].long())[clear].all()), f"{what}: fp32 token ids differ from the reference's fp32 ids"
+        assert int(clear.sum()) >= int(0.9 * gap.numel())
+    logits_check(out.logits[0], fx["logits"], "c1_logits")
+    fx = load_fixture("g16_res_full_depth_bf16.pt")
+    g = torch.Generator().manual_seed(fx["inputs_seed"])
+    torch.randint(5, 32000, (120,), generator=g)
+    torch.randn(1, 3, 224, 224, generator=g)
+    images_sam = torch.randn(1, 3, 1024, 1024, generator=g).to(torch.bfloat16)
+    assert digest_matches(images_sam, fx["images_sam_digest"])
+    sizes, resizes = [tuple(x) for x in fx["size_list"]], [tuple(x) for x in fx["resize_list"]]
+    with torch.no_grad():
+        o = model.forward(images_sam=images_sam.float().to(DEV), images=fx["images"].float().to(DEV), input_ids=fx["input_ids"].to(DEV), labels=None,
+                          attention_mask=fx["attention_mask"].to(DEV), mask_list=[None], size_list=sizes, resize_list=resizes, bbox_list=[None],
+                          inference=True)
+        emb = model.get_visual_embs(images_sam.float().to(DEV))
+    pm = o["pred_masks"][0]
+    assert pm.dtype == torch.float32 and tuple(pm.shape) == (3, 480, 640)
+    for name, hip, t_, amax in (("res_sam_embedding", emb[:, ::8, ::2, ::2], fx["truth_emb"], fx["truth_emb_absmax"]),
+                                ("res_masks", pm[:, ::4, ::4], fx["truth_masks"], fx["truth_masks_absmax"]),
+                                ("res_boxes", o["pred_boxes"][0], fx["truth_boxes"], float(fx["truth_boxes"].abs().max()))):
+        rec[name] = float((hip.cpu().float() - t_.float()).abs().max()) / amax
+        assert rec[name] <= 1e-4, (name, rec[name])
+    tm = fx["truth_masks"]
+    clear = tm.abs() > 1e-3 * fx["truth_masks_absmax"]
+    assert bool(((pm[:, ::4, ::4].cpu() > 0) == (tm > 0))[clear].all())
+    logits_check(o["logits"][0], fx["logits"], "res_logits")
+    print("fp32 build at full depth vs the reference's fp32 runs:", json.dumps(rec))
 
 
 RCCL_SCRIPT = r"""

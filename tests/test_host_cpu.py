@@ -274,11 +274,11 @@ def test_lora_adapter_is_merged_at_load(tmp_path):
                 sd[f"base_model.model.{mod}.lora_B.weight"] = B
                 want[mod] = (w.detach().float() + (B @ A) * (alpha / r)).to(w.dtype)
             else:
-                # adapter cast to the weights' 16-bit dtype: 16-bit product, 16-bit scaling, 16-bit sum (checkpoint.lora_merged_weight)
+                # adapter FILE stored in the weights' 16-bit dtype: PeftModel.from_pretrained loads it into fp32 parameters (PEFT 0.4.0) and the
+                # reference never casts them back, so the merge is still the fp32 delta of the upcast values with ONE rounding
                 sd[f"base_model.model.{mod}.lora_A.weight"] = A.to(w.dtype)
                 sd[f"base_model.model.{mod}.lora_B.weight"] = B.to(w.dtype)
-                delta = ((B.to(w.dtype).float() @ A.to(w.dtype).float()).to(w.dtype).float() * (alpha / r)).to(w.dtype)
-                want[mod] = (w.detach().float() + delta.float()).to(w.dtype)
+                want[mod] = (w.detach().float() + (B.to(w.dtype).float() @ A.to(w.dtype).float()) * (alpha / r)).to(w.dtype)
     assert not CK.has_lora_adapter(d)
     save_file(sd, os.path.join(d, "adapter_model.safetensors"))
     json.dump({"peft_type": "LORA", "r": r, "lora_alpha": alpha, "target_modules": ["q_proj", "v_proj"], "fan_in_fan_out": False},
@@ -494,14 +494,14 @@ def test_peft_shim_runs_the_references_lora_call_sites(tmp_path, capsys):
         ad = load_file(str(tmp_path / "adapter_model.safetensors"))
         assert len(ad) == 3 * 2 * 2 and all(k.startswith("base_model.model.model.layers.") for k in ad)
         # inference_ullava.py:43: PeftModel.from_pretrained(model.llm, llm_path, torch_dtype=dtype) on a fresh model: the adapter is folded in with
-        # PEFT's merge arithmetic (16-bit product, 16-bit scaling, 16-bit sum)
+        # PEFT 0.4.0's arithmetic for an adapter FILE: from_pretrained loads it into fp32 lora_A / lora_B whatever the file stores, so the merge
+        # is the fp32 delta of the upcast values with one rounding into the weight (checkpoint.lora_merged_weight)
         fresh = build()
         w0 = fresh.llm.model.layers[1].self_attn.v_proj.weight.detach().clone()
         k0 = fresh.llm.model.layers[1].self_attn.k_proj.weight.detach().clone()
         fresh.llm = PeftModel.from_pretrained(fresh.llm, str(tmp_path), torch_dtype=torch.bfloat16)
         lin = core.model.layers[1].self_attn.v_proj
-        d = (lin.lora_B.weight.float() @ lin.lora_A.weight.float()).to(torch.bfloat16)
-        want = (w0.float() + (d.float() * 2.0).to(torch.bfloat16).float()).to(torch.bfloat16)
+        want = (w0.float() + (lin.lora_B.weight.float() @ lin.lora_A.weight.float()) * 2.0).to(torch.bfloat16)
         merged = fresh.llm.get_base_model().model.layers[1].self_attn
         got = merged.v_proj.weight.detach()
         assert torch.equal(got, want) and not torch.equal(got, w0)

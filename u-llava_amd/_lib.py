@@ -149,11 +149,18 @@ def load():
 
 
 def call(name: str, *args):
-    rc = getattr(load(), name)(*args)
+    fn = getattr(load(), name, None)
+    if fn is None or name not in SIGNATURES:
+        # (an op whose dtype has no kernel build: e.g. a backward / fused entry asked for float32 -- the fp32 build covers the inference path only)
+        raise RuntimeError(f"u-llava_amd: the library has no entry point `{name}` (no kernel build of this op for that element type)")
+    rc = fn(*args)
     if rc != 0:
         raise RuntimeError(f"u-llava_amd: {name} failed: {ERRORS.get(rc, rc)}")
 
 
 def query(name: str, *args):
     """A VALUE_RETURNING entry point: returns its value."""
-    return getattr(load(), name)(*args)
+    fn = getattr(load(), name, None)
+    if fn is None or name not in SIGNATURES:
+        raise RuntimeError(f"u-llava_amd: the library has no entry point `{name}` (no kernel build of this op for that element type)")
+    return fn(*args)

@@ -162,13 +162,14 @@ def save_lora_adapter(core: torch.nn.Module, path: str) -> None:
 
 def _dtype_arg(torch_dtype):
     """reference: inference_ullava.py:26,164-168 `--dtype {fp32,bf16,fp16}` -> torch_dtype.  The MI355X path has bf16 (default, the
-    reference's training dtype) and fp16 kernel builds."""
+    reference's training dtype), fp16 and -- round 6, inference only -- fp32 kernel builds."""
     if torch_dtype in (None, torch.bfloat16, "bfloat16", "bf16"):
         return torch.bfloat16
     if torch_dtype in (torch.float16, "float16", "fp16", "half"):
         return torch.float16
-    raise NotImplementedError("the MI355X path has bf16 and fp16 kernel builds; pass torch_dtype=torch.bfloat16 or torch.float16 "
-                              "(fp32 models are not supported)")
+    if torch_dtype in (torch.float32, "float32", "fp32", "float"):
+        return torch.float32
+    raise NotImplementedError(f"torch_dtype {torch_dtype!r}: the MI355X path has bf16, fp16 and fp32 kernel builds")
 
 
 def _merge_config(raw: dict, config_overrides: dict) -> dict:
@@ -219,17 +220,21 @@ def ullava_from_pretrained(cls, path: str, torch_dtype=None, device=None, strict
 # `PeftModel.merge_and_unload()` leaves behind.  Reads the files PEFT writes (adapter_config.json + adapter_model.safetensors / .bin,
 # keys `base_model.model.<module path>.lora_A[.<adapter>].weight` [r, in] and `.lora_B[...].weight` [out, r]).  Host-side weight
 # preparation like the rest of this file, with PEFT's own rounding points for the adapter's stored dtype (lora_merged_weight).
-def lora_merged_weight(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float) -> torch.Tensor:
+def lora_merged_weight(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scaling: float, live_adapter_dtype: bool = False) -> torch.Tensor:
     """PEFT 0.4.0 (the reference's pin, shells/requirements.txt:25) tuners/lora.py `Linear.merge`:
-    `self.weight.data += (lora_B.weight @ lora_A.weight) * scaling`, evaluated in the dtypes PEFT's tensors have.  PEFT creates lora_A /
-    lora_B as default-dtype (fp32) nn.Linear and only moves them to the device, and adapter files written by the reference's training
-    hold fp32 tensors: the delta is then an fp32 matrix and the in-place add rounds ONCE, to the weight's 16-bit dtype.  An adapter that
-    was itself cast to 16 bits (model.half() after get_peft_model) gives three roundings: the product B A (fp32 accumulation over r),
-    the scaling, the sum.  The rounding points follow the adapter tensors' stored dtype (weight preparation, not the forward path)."""
+    `self.weight.data += (lora_B.weight @ lora_A.weight) * scaling`.
+    Adapter FILES (default): `PeftModel.from_pretrained` creates lora_A / lora_B as fp32 nn.Linear, moves them by device only, and
+    `load_state_dict` upcasts a 16-bit adapter file into those fp32 parameters; the reference does no `.half()` afterwards
+    (inference_ullava.py:43, eval_ullava.py:138) -- so whatever dtype the file stores, the delta is an fp32 matrix of the (upcast) values and
+    the in-place add rounds ONCE, to the weight's dtype.
+    live_adapter_dtype=True (the model's own attached adapters: merge_lora / the inference packs of a model under training): the rounding
+    points follow the adapter PARAMETERS' dtype as PEFT's `merge` would see them -- fp32 parameters (what get_peft_model creates) give the same
+    single rounding; parameters that were cast with the model (`model.half()` after get_peft_model) give three (the 16-bit product B A, the
+    scaling, the sum)."""
     dt = w.dtype
     adt = torch.promote_types(A.dtype, B.dtype)
     d = B.detach().float() @ A.detach().float()
-    if adt in (torch.float16, torch.bfloat16):
+    if live_adapter_dtype and adt in (torch.float16, torch.bfloat16):
         d = (d.to(adt).float() * float(scaling)).to(adt).float()
     else:
         d = d * float(scaling)
@@ -281,7 +286,7 @@ def merge_lora_adapter(llm: torch.nn.Module, path: str, adapter_name: str = "def
                 raise NotImplementedError("fan_in_fan_out adapters (Conv1D targets) do not occur on this path: every target is an nn.Linear")
             if (B.shape[0], A.shape[1]) != tuple(w.shape):
                 raise RuntimeError(f"u-llava_amd: adapter delta {(B.shape[0], A.shape[1])} does not fit {mod}.weight {tuple(w.shape)}")
-            w.copy_(lora_merged_weight(w.detach().cpu(), A, B, alpha / r).to(w.device))      # rounding points by the adapter's stored dtype
+            w.copy_(lora_merged_weight(w.detach().cpu(), A, B, alpha / r).to(w.device))      # fp32 delta of the (upcast) file values, one rounding
             merged.append(mod)
     if hasattr(llm, "_packed"):
         llm._packed = None                                   # fused q|k|v / tile-major copies describe the old weights

@@ -2336,6 +2336,10 @@ extern "C" int ULL_FN(ull_attention_)(const void* Q, int64_t q_bs, int64_t q_hs,
     if ((q_ss & 7) || (k_ss & 7) || (vt_ds & 7) || (q_hs & 7) || (k_hs & 7) || (q_bs & 7) || (k_bs & 7) || (vt_hs & 7) || (vt_bs & 7) ||
         (o_ss & 3) || (o_hs & 3) || (o_bs & 3))
         return ULL_ERR_SHAPE;
+    // V-as-rows forms (LLaMA / CLIP prefill, SAM global): the epilogue stores whole O rows through the LDS as 16-byte pieces -- the output needs
+    // 8-element strides and a 16-byte base, not only the 8 bytes of the register-direct epilogue (no kernel of that form otherwise: -2, and
+    // the host falls back to the V^T path)
+    if (vt_len == 0 && (((o_ss | o_hs | o_bs) & 7) || ((uintptr_t)O & 15))) return ULL_ERR_SHAPE;
     AttnArgs a;
     a.Q = (const elem_t*)Q; a.K = (const elem_t*)K; a.Vt = (const elem_t*)Vt; a.O = (elem_t*)O;
     a.key_mask = (const int32_t*)key_mask;

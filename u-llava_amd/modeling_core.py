@@ -41,6 +41,19 @@ def _clear_transposes():
     clear_transpose_cache()
 
 
+_ALIAS_WARNED = [False]
+
+
+def _warn_alias_fallback(why: str) -> None:
+    """one line, once per process: the training path fell back from aliased q|k|v / gate|up buffers to a per-step torch.cat (correct, slower)."""
+    if not _ALIAS_WARNED[0]:
+        _ALIAS_WARNED[0] = True
+        import warnings
+        warnings.warn("u-llava_amd: training forward concatenates q|k|v / gate|up under autograd on every step instead of aliasing them: " + why +
+                      ".  Results are identical; call model._apply(lambda t: t) (or .to(device)) after taking ownership back to re-enable aliasing.",
+                      RuntimeWarning, stacklevel=3)
+
+
 def _dealias_state_dict(module, state_dict, prefix, local_metadata):
     """state-dict hook: the training path makes q|k|v and gate|up row slices of one buffer each (_alias_pack); a state dict must hold
     tensors that own their storage (safetensors refuses shared memory; HF Trainer._save writes state_dict() as it is)."""
@@ -396,7 +409,7 @@ class UllavaCoreForCausalLM(nn.Module):
             if lora is None or not hasattr(lin, "lora_A"):
                 return lin.weight
             from .checkpoint import lora_merged_weight
-            return lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, lora["lora_alpha"] / lora["r"])
+            return lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, lora["lora_alpha"] / lora["r"], live_adapter_dtype=True)
         for l in self.model.layers:
             a, m = l.self_attn, l.mlp
             pk["llama"].append(dict(
@@ -633,7 +646,7 @@ class UllavaCoreForCausalLM(nn.Module):
             for l in self.model.layers:
                 for t in cfg["target_modules"]:
                     lin = getattr(l.self_attn, t)
-                    lin.weight.copy_(lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, s_))
+                    lin.weight.copy_(lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, s_, live_adapter_dtype=True))
                     del lin.lora_A, lin.lora_B
         self._lora = None
         self._packed = None
@@ -692,12 +705,15 @@ class UllavaCoreForCausalLM(nn.Module):
                 return packed, ws
             object.__setattr__(holder, slot, None)
             object.__setattr__(holder, slot + "_external", True)          # storage re-bound by an external owner: leave it alone
+            _warn_alias_fallback("the parameters no longer point into the packed buffer (an external owner re-bound their storage)")
             return None, ws
         # First call on this holder.  A parameter that is already a VIEW into a larger storage has an owner: deepspeed.initialize
         # (ZeRO-1/2: p.data = a slice of the flat bit16 group) or an FSDP wrap (flat parameter) ran before the first training forward --
         # the order HF Trainer uses.  Taking the storage away here would leave the owner updating a buffer nobody reads.
         if any(w.storage_offset() != 0 or w.untyped_storage().nbytes() > w.numel() * w.element_size() + 64 for w in ws):
             object.__setattr__(holder, slot + "_external", True)
+            _warn_alias_fallback("a parameter is already a view into a larger storage (DeepSpeed / FSDP flat buffer, load_state_dict(assign=True) "
+                                 "from an mmap, or a user-side flat parameter)")
             return None, ws
         with torch.no_grad():
             packed = torch.cat([w.data for w in ws], dim=0).contiguous()

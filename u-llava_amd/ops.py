@@ -120,7 +120,13 @@ def _tiled_of(w: torch.Tensor):
     if e[2] != w._version:
         # a NEW tensor, not copy_: a copy first made under torch.inference_mode() (the reference wraps generate / evaluate in it,
         # inference_ullava_core.py:72, models/ullava.py:349) is an inference tensor and may not be updated in place outside that mode
-        e[1] = tile_major(w.detach())
+        # ... in place where that is allowed (a training run re-tiles every weight after every optimizer step: no allocator churn)
+        N, K = w.shape
+        if not e[1].is_inference() and not torch.is_inference_mode_enabled() and N % 256 == 0 and tuple(e[1].shape) == (N // 256, K // 64, 256, 64):
+            with torch.no_grad():
+                e[1].copy_(w.detach().view(N // 256, 256, K // 64, 64).permute(0, 2, 1, 3))
+        else:
+            e[1] = tile_major(w.detach())
         e[2] = w._version
     return e[1]
 
