@@ -48,5 +48,5 @@ rec = {"kernel": "big::gemm256w4_kernel<true> (gate/up + SwiGLU, M=20576 N=22016
        "hbm_bytes_bounds": {"lower_compulsory": alg, "upper_all_fabric_traffic": fetch_kb * 1024 * 2 + write_kb * 1024,
                             "note": "no post-Infinity-Cache counter exists here; tools/mall_probe.py (profiles/r03_mall_probe.txt) shows re-read working sets "
                                     "up to 256 MiB served above HBM rate, and the GEMM re-reads each 2-MiB operand panel from all 8 XCDs within one round of tiles"},
-       "source": "tools/prof_r03.sh (separate rocprofv3 --pmc passes on tools/gemm_one.py 20576 22016 4096 sw)"}
+       "source": "tools/prof_r03.sh / prof_r06.sh (separate rocprofv3 --pmc passes on tools/gemm_one.py 20576 22016 4096 sw)"}
 print(json.dumps(rec, indent=1))
