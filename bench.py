@@ -732,7 +732,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="fp16 = the reference's --dtype fp16 option (side check; default bf16 like inference_ullava.py:165)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="fp16 / fp32 = the reference's --dtype options (side checks; default bf16 like inference_ullava.py:165).  fp32 is the plain-kernel "
+                         "correctness build (csrc/f32.hip, ~1/50 of the bf16 speed): use it with --batch 1 or 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-res", action="store_true", help="skip the C3 RES sub-record of the default (c4) run")
@@ -746,8 +748,8 @@ def main():
     ap.add_argument("--train-config", default="full", choices=sorted(TRAIN_CONFIGS), help="--workload train: which trainable set / batch")
     a = ap.parse_args()
     global DTYPE
-    DTYPE = torch.float16 if a.dtype == "fp16" else torch.bfloat16
-    if a.dtype == "fp16":                                         # the roofline / parity legs are bf16 records: not part of a side check
+    DTYPE = {"fp16": torch.float16, "fp32": torch.float32}.get(a.dtype, torch.bfloat16)
+    if a.dtype != "bf16":                                         # the roofline / parity legs are bf16 records: not part of a side check
         a.no_roofline = a.no_cpu_baseline = True
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -227,10 +227,12 @@ def lora_merged_weight(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, scalin
     `load_state_dict` upcasts a 16-bit adapter file into those fp32 parameters; the reference does no `.half()` afterwards
     (inference_ullava.py:43, eval_ullava.py:138) -- so whatever dtype the file stores, the delta is an fp32 matrix of the (upcast) values and
     the in-place add rounds ONCE, to the weight's dtype.
-    live_adapter_dtype=True (the model's own attached adapters: merge_lora / the inference packs of a model under training): the rounding
-    points follow the adapter PARAMETERS' dtype as PEFT's `merge` would see them -- fp32 parameters (what get_peft_model creates) give the same
-    single rounding; parameters that were cast with the model (`model.half()` after get_peft_model) give three (the 16-bit product B A, the
-    scaling, the sum)."""
+    The model's own attached adapters (merge_lora, the inference packs of a model under training) take the same arithmetic: under PEFT 0.4.0
+    `get_peft_model` creates fp32 adapter parameters as well, so whatever dtype THIS path stores its adapters in, the merge is the fp32 delta
+    of their values, rounded once.
+    live_adapter_dtype=True is an explicit opt-in to the other reading -- adapter parameters that were cast with the model (`model.half()` after
+    get_peft_model) make PEFT's `merge` a 16-bit computation with three roundings (the product B A, the scaling, the sum); nothing in the
+    package passes it."""
     dt = w.dtype
     adt = torch.promote_types(A.dtype, B.dtype)
     d = B.detach().float() @ A.detach().float()

@@ -409,7 +409,7 @@ class UllavaCoreForCausalLM(nn.Module):
             if lora is None or not hasattr(lin, "lora_A"):
                 return lin.weight
             from .checkpoint import lora_merged_weight
-            return lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, lora["lora_alpha"] / lora["r"], live_adapter_dtype=True)
+            return lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, lora["lora_alpha"] / lora["r"])
         for l in self.model.layers:
             a, m = l.self_attn, l.mlp
             pk["llama"].append(dict(
@@ -646,7 +646,7 @@ class UllavaCoreForCausalLM(nn.Module):
             for l in self.model.layers:
                 for t in cfg["target_modules"]:
                     lin = getattr(l.self_attn, t)
-                    lin.weight.copy_(lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, s_, live_adapter_dtype=True))
+                    lin.weight.copy_(lora_merged_weight(lin.weight, lin.lora_A.weight, lin.lora_B.weight, s_))
                     del lin.lora_A, lin.lora_B
         self._lora = None
         self._packed = None
@@ -660,6 +660,10 @@ class UllavaCoreForCausalLM(nn.Module):
         is frozen by both training scripts and always runs the inference kernels without a graph."""
         if not torch.is_grad_enabled():
             return False                     # no_grad / eval with adapters attached: inference kernels on a temporarily merged pack (_pk)
+        if self.dtype == torch.float32:
+            # the fp32 build (csrc/f32.hip) is the INFERENCE path (`--dtype fp32` of inference_ullava.py): there are no fp32 backward kernels, so an
+            # fp32 model never builds a graph -- its outputs carry no grad_fn, like the reference's under torch.inference_mode()
+            return False
         if getattr(self, "_lora", None) is not None:
             return True
         return any(p.requires_grad for p in self.lm_head.parameters()) or any(p.requires_grad for p in self.model.parameters()) or \

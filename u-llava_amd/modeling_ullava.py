@@ -118,7 +118,7 @@ class UllavaForCausalLM(nn.Module):
     def _heads_training_graph(self) -> bool:
         """gradients enabled and one of the heads on top of the language model is trainable (train_ullava.py:248-261: seg / det
         projectors, det_decoder, mask_decoder)."""
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() or self.dtype == torch.float32:        # (the fp32 build is inference-only: csrc/f32.hip has no backward)
             return False
         mods = (self.seg_projector, self.det_projector, self.det_decoder, self.visual_model.mask_decoder)
         return any(p.requires_grad for m in mods for p in m.parameters())
