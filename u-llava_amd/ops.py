@@ -1104,14 +1104,9 @@ class LayerStack:
         self.refresh()
 
     def _fingerprint(self):
-        fp = []
-        for d in self.layers:
-            for n in self._lin_fields:
-                w = d[n][0]
-                wt = _tiled_of(w)
-                fp.append(w.data_ptr())
-                fp.append(0 if wt is None else wt.data_ptr())
-        return fp
+        # (address, version) of every weight: an in-place update (optimizer step, load_state_dict) bumps the version, and only then is the
+        # tile-major copy re-made (`_tiled_of`, in refresh below) -- between updates the copy's address cannot change
+        return [v for d in self.layers for n in self._lin_fields for v in (d[n][0].data_ptr(), d[n][0]._version)]
 
     def refresh(self):
         fp = self._fingerprint()
