@@ -2,7 +2,6 @@
 fp32 matrix instruction, against torch fp32 references per kernel and against the REFERENCE's fp32 fixtures (G1 / G7 / G8: tiny models run by
 /root/reference in fp32).  fp32 has no rounding points to reproduce: the tolerance is the fp32 summation-order noise (1e-5 of the tensor's
 maximum; token ids, [SEG] / [LOC] bookkeeping and shapes exact)."""
-import math
 import os
 import sys
 

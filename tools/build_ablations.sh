@@ -5,7 +5,7 @@
 # compile to byte-identical device code when no switch is given)
 set -e
 cd "$(dirname "$0")/../u-llava_amd/csrc"
-OTHERS=$(ls *.o | grep -E '^[a-z_]+(\.f16)?\.o$' | grep -v '^gemm\.o$')     # the Makefile's objects only (no -save-temps leftovers)
+OTHERS=$(ls *.o | grep -E '^[a-z_0-9]+(\.f16)?\.o$' | grep -v '^gemm\.o$')     # the Makefile's objects only (no -save-temps leftovers)
 for abl in "$@"; do
   # A+B = both switches; a switch with '=' is a schedule knob: BAR_A=16 -> -DULL_W4_BAR_A=16
   DEFS=$(echo $abl | tr '+' '\n' | sed -e '/=/s/^/-DULL_W4_/' -e '/^W4_/s/^/-DULL_/' -e '/^-D/!s/^/-DULL_ABL_/' | tr '\n' ' ')

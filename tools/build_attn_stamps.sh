@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../u-llava_amd/csrc"
 make -j8 >/dev/null
-OTHERS=$(ls *.o | grep -E '^[a-z_]+(\.f16)?\.o$' | grep -v '^attention\.o$')
+OTHERS=$(ls *.o | grep -E '^[a-z_0-9]+(\.f16)?\.o$' | grep -v '^attention\.o$')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DULL_ATTN_STAMPS "$@" -I. -c ../../tools/probes/lab/attention_lab_r05.hip -o /tmp/attention_stamps.o
 mkdir -p ../../tools/debug
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/debug/libullava_attn_stamps.so /tmp/attention_stamps.o $OTHERS

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU time of one step through the coarse layer-stack entries vs through one ctypes call per launch (same kernels, same box, interleaved):
 usage: python tools/coarse_vs_per_op.py [c4|c2|c5|res]"""
-import importlib, os, sys, time
+import importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where does the HOST time of one enqueue go?  cProfile of N un-synchronised C4 steps (and of KV-cached decode steps) on an idle GPU.
 usage: python tools/host_profile.py [c4|decode]"""
-import cProfile, importlib, os, pstats, sys, time
+import cProfile, os, pstats, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -7,7 +7,6 @@ operand; the other operands must match), row-major, last dim contiguous.
 import weakref
 from typing import Optional
 
-import os
 
 import torch
 
