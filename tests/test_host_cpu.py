@@ -542,3 +542,37 @@ def test_sampling_distribution_and_draws_match_hf_warpers():
             torch.manual_seed(seed)
             b = torch.multinomial(got, 1)
             assert torch.equal(a, b)
+
+
+def test_layer_stack_structs_follow_the_weights():
+    """ops.LayerStack (the ctypes array behind the coarse C-ABI entries, csrc/layers.hip): fields carry the tensors' addresses and shapes, the
+    tile-major copy where one is registered, NULL where there is no bias -- and a refresh picks up a weight that moved or was updated in place."""
+    ops, L = pkg("ops"), pkg("_lib")
+    D, I = 128, 512
+
+    def lin(n, k):
+        return torch.randn(n, k).to(torch.bfloat16)
+    layers = []
+    for _ in range(2):
+        d = dict(ln1=torch.ones(D, dtype=torch.bfloat16), ln2=torch.ones(D, dtype=torch.bfloat16), qkv=(lin(3 * D, D), None), o=(lin(D, D), None),
+                 gu=(lin(2 * I, D), None), down=(lin(D, I), None))
+        layers.append(d)
+    big = layers[1]["gu"][0]                                       # [1024, 128]: large enough for a tile-major copy
+    ops.register_tiled(big)
+    st = ops.LayerStack(L.LlamaLayer, layers)
+    arr = st.refresh()
+    assert len(arr) == 2 and arr[0].ln1 == layers[0]["ln1"].data_ptr() and arr[1].down.w == layers[1]["down"][0].data_ptr()
+    assert (arr[0].qkv.n, arr[0].qkv.k, arr[0].qkv.ldw) == (3 * D, D, D) and arr[0].qkv.bias is None and arr[0].qkv.w_tiled is None
+    t0 = arr[1].gu.w_tiled
+    assert t0 is not None and t0 == ops._tiled_of(big).data_ptr()
+    assert st.refresh() is arr                                     # nothing moved: same array, no rebuild
+    with torch.no_grad():
+        big.mul_(2.0)                                              # an in-place update: the tile-major copy must describe the new values
+    arr = st.refresh()
+    tm = ops._tiled_of(big)
+    assert arr[1].gu.w_tiled == tm.data_ptr() and torch.equal(tm, ops.tile_major(big))
+    layers[0]["o"] = (lin(D, D), torch.zeros(D, dtype=torch.bfloat16))      # a re-bound weight (and a bias): new addresses
+    arr = st.refresh()
+    assert arr[0].o.w == layers[0]["o"][0].data_ptr() and arr[0].o.bias == layers[0]["o"][1].data_ptr()
+    with pytest.raises(RuntimeError, match="row-major"):
+        ops.LayerStack(L.LlamaLayer, [dict(layers[0], o=(lin(D, D).t(), None))])
