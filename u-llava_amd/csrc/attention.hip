@@ -2257,7 +2257,7 @@ int dispatch_nt(const AttnArgs& a, hipStream_t st) {
     if (fl == FL_SAM_ENC && HDP == 128 && a.hd != 80) fl = FL_RUNTIME;
     if (a.v_rows) {                      // V handed over row-major: the kernels that transpose on the fly (see the C entry)
         if constexpr (HDP == 128) {
-constexpr int ULL_ATTN_NWV = 4;
+            constexpr int ULL_ATTN_NWV = 4;
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 11) return launch_attn<128, 11, FL_LLAMA, ULL_ATTN_NWV, false, true>(a, st);
             if (fl == FL_LLAMA && a.Sq > 16 && nt <= 16) return launch_attn<128, 16, FL_LLAMA, 8, false, true>(a, st);
             if (fl == FL_SAM_ENC && a.rel_mode == 2 && a.KW == 64 && a.KH == 64 && a.Sk == 4096 && (a.Sq & 15) == 0 && a.Sq > 16 &&
