@@ -206,3 +206,62 @@ def test_full_forward_fixture_g8_fp32():
         eb = rel_err(out["pred_boxes"][i], fx["pred_boxes"][i])
         print(f"G8 fp32 sample {i}: mask err {em:.2e} box err {eb:.2e}")
         assert em <= 5e-5 and eb <= 2e-5
+
+
+def test_evaluate_fp32_against_the_oracle():
+    """`evaluate(temperature=0)` of an fp32 model (models/ullava.py:335-434: generate -> [SEG] / [LOC] states -> SAM decode -> postprocess), with and
+    without the KV cache, against the oracle's fp32 evaluate on the same weights (the G11 model and inputs, weights promoted from bf16): ids equal,
+    masks / boxes at fp32 noise."""
+    from oracle import ullava_oracle as O
+    C, M = pkg("configuration"), pkg("modeling_ullava")
+    fx = load_fixture("g11_evaluate_bf16.pt")
+    cfg, cd = fx["cfg"], fx["cfg"]["llm"]
+    ucfg = C.UllavaConfig(llm_config=dict(vision_config=cd["vision_config"], vision_hidden_layer=cd["vision_hidden_layer"], projector_type="mlp",
+                                          projector_from_scratch=bool(cd.get("projector_from_scratch", False)), mm_token_ids=cd["mm_token_ids"],
+                                          vocab_size=cd["vocab_size"], hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
+                                          num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"]),
+                          seg_token_idx=cfg["seg_token_idx"], loc_token_idx=cfg["loc_token_idx"], sam_config=dict(cfg["sam"]))
+    sd = {k: v.float() for k, v in fixture_sd(fx, torch.bfloat16).items()}
+    model = M.UllavaForCausalLM(ucfg, device=DEV, dtype=F32)
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(fx["images_sam_seed"])
+    _ = torch.randn(2, 3, 28, 28, generator=g)
+    images_sam = torch.randn(2, 3, 1024, 1024, generator=g).to(torch.bfloat16)[:1].float()
+    images = fx["images"].float()
+    want_seq, want_masks, want_boxes = O.ullava_evaluate(sd, cfg, images_sam, images, fx["input_ids"], [fx["size"]], [fx["resize"]], max_new_tokens=6)
+    for use_cache in (False, True):
+        model.llm.config.use_cache = use_cache
+        seq, masks, boxes = model.evaluate(images_sam.to(DEV), images.to(DEV), fx["input_ids"].to(DEV), [fx["size"]], [fx["resize"]], max_new_tokens=6,
+                                           temperature=0)
+        assert torch.equal(seq.cpu(), want_seq), (seq.tolist(), want_seq.tolist())
+        assert masks[0].dtype == F32 and tuple(masks[0].shape) == tuple(want_masks[0].shape)
+        em, eb = rel_err(masks[0], want_masks[0]), rel_err(boxes[0], want_boxes[0]) if want_boxes[0].numel() else 0.0
+        print(f"fp32 evaluate(use_cache={use_cache}): mask err {em:.2e}, box err {eb:.2e}, ids {seq[0, fx['input_ids'].shape[1]:].tolist()}")
+        assert em <= 5e-5 and eb <= 5e-5
+
+
+@pytest.mark.parametrize("name", ["g3_video_bf16.pt", "g4_mixed_bf16.pt"])
+def test_video_and_mixed_batches_fp32_against_the_oracle(name):
+    """The video branch (per-frame ViT, temporal + spatial pooling, models/ullava_core.py:160-180,248-269) and a mixed batch with a text-only row and
+    right padding (:205-226) in fp32: the G3 / G4 models and inputs with the weights promoted to fp32, against the oracle's fp32 forward, plus the
+    shifted CE loss (:327-338)."""
+    from oracle import ullava_oracle as O
+    fx = load_fixture(name)
+    model = _core_model(fx)
+    sd = {k: v.float() for k, v in fixture_sd(fx, torch.bfloat16).items()}
+    model.load_state_dict(sd, strict=True)
+    ids = fx["input_ids"]
+    mask = fx.get("attention_mask", torch.ones_like(ids))
+    kw_o = dict(videos=fx["videos"].float()) if "videos" in fx else dict(images=fx["images"].float())
+    labels = ids.clone()
+    labels[mask == 0] = -100
+    with torch.no_grad():
+        out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), output_hidden_states=True,
+                    **{k: v.to(DEV) for k, v in kw_o.items()})
+    want = O.core_forward(sd, fx["cfg"], ids, mask, kw_o.get("images"), kw_o.get("videos"), labels=labels)
+    valid = mask.bool()
+    e = rel_err(out.logits.cpu()[valid], want["logits"][valid])
+    eh = rel_err(out.hidden_states[-1].cpu()[valid], want["hidden_states"][-1][valid])
+    el = abs(float(out.loss) - float(want["loss"])) / abs(float(want["loss"]))
+    print(f"{name} in fp32: logits err {e:.2e}, last hidden {eh:.2e}, loss {float(out.loss):.6f} vs {float(want['loss']):.6f}")
+    assert out.logits.dtype == F32 and e <= 1e-5 and eh <= 1e-5 and el <= 1e-5
