@@ -202,6 +202,24 @@ class KVCache:
     def __len__(self):
         return len(self.k)
 
+    def to_legacy_cache(self):
+        """The HF view of this cache (what `outputs.past_key_values` is in the reference under transformers 4.29.1, models/ullava_core.py:349-355):
+        a tuple of per-layer (key, value) pairs, each [B, H, length, hd] with post-RoPE keys.  Pure data movement (a slice of the K buffer;
+        the key-permuted V^T image gathered back into natural key order and transposed); `KVCache.from_hf` is the inverse."""
+        n = self.length
+        idx = ops.vt_unpermute_index(self.smax).to(self.k[0].device)[:n]
+        return tuple((k[:, :, :n].contiguous(), vt[..., idx].transpose(-1, -2).contiguous()) for k, vt in zip(self.k, self.vt))
+
+    def __iter__(self):
+        return iter(self.to_legacy_cache())
+
+    def __getitem__(self, i):
+        """layer i's (key, value) pair -- so that code written against a tuple of pairs (`past_key_values[0][0].shape[2]`, the idiom of
+        4.29-era callers) reads this object too."""
+        n = self.length
+        idx = ops.vt_unpermute_index(self.smax).to(self.k[i].device)[:n]
+        return self.k[i][:, :, :n], self.vt[i][..., idx].transpose(-1, -2)
+
     @classmethod
     def from_hf(cls, past, headroom: int = 512):
         """A caller-supplied HF `past_key_values` -> KVCache (reference models/ullava_core.py:279-292 takes `past_key_values:
