@@ -765,4 +765,16 @@ if __name__ == "__main__":
     if want("losses"):
         gen_losses("g10_train_losses_fp32.pt", torch.float32, 8)
         gen_losses("g10_train_losses_bf16.pt", torch.bfloat16, 8)
+    if which & {"g15", "g16", "fulldepth"}:
+        # G15 / G16: the reference at FULL size (7 B parameters, ~35 min and ~45 GB of host memory for all four): only on request,
+        #   python tests/golden/gen_golden.py fulldepth          (or g15 / g16; or run tests/golden/gen_golden_full_depth.py directly)
+        # (the sibling imports this file as the module `gen_golden`: hand it THIS module, whose reference imports and stubs are already set up)
+        sys.modules.setdefault("gen_golden", sys.modules["__main__"])
+        sys.path.insert(0, OUT)
+        import gen_golden_full_depth as FD
+        for key, fn, tag, dt in [("g15", FD.gen_g15, "bf16", torch.bfloat16), ("g15", FD.gen_g15, "fp16", torch.float16),
+                                 ("g16", FD.gen_g16, "bf16", torch.bfloat16), ("g16", FD.gen_g16, "fp16", torch.float16)]:
+            if "fulldepth" in which or key in which:
+                fn(tag, dt)
+                print(f"{key}_{tag}: reference == oracle bit-exact at full depth ({tag} and fp32)", flush=True)
     print("all fixtures bit-exact between reference and oracle")
